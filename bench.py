@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: trajectories/s for 8-segment, N=10, 3-D minimum-snap solveLinear().
+
+One "step" = one pass of the hot path (fused updateSegmentTimes + constructR + solve + coefficient recovery,
+one kernel launch) over one batch of `--batch` synthetic random-waypoint trajectories that is already resident
+in HBM.  N GPUs = N processes (torch.distributed / RCCL only for the barrier + max-reduce of the timing; the
+path shards embarrassingly, no data-path collective) each solving its own batch => weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` = algorithmic bytes per launch (8*(K + D*n_fixed +
+K*D*N) = 2392 B/trajectory) / mean kernel duration measured with hipEvents on the launch stream;
+`cpu_baseline` = the reference algorithm's CPU restatement (oracle/) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(n_sample, seed):
+    """oracle (reference-algorithm port) timed on host cores over a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    t, f = m.random_waypoint_batch(n_sample, 8, 3, 10, masks, seed=seed, device="cpu")
+    t, f = t.numpy(), f.numpy()
+    try:
+        from oracle import cpu_ref  # C++ restatement (oracle/cpu_ref.cpp) if built
+        return cpu_ref.timed_baseline(10, 4, masks, t, f)
+    except Exception:
+        from oracle import oracle_np
+        n = min(n_sample, 3000)
+        t0 = time.perf_counter()
+        oracle_np.solve_batch(10, 4, masks, t[:n], f[:n])
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+                "sample": f"{n} trajectories of the bench workload, numpy restatement of the reference algorithm "
+                          f"(setup+solve), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=10_000, help="trajectories per step per GPU (BASELINE configs[1])")
+    ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time the 125k / 1M per-launch batches")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mav_trajectory_generation_amd as m
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    dev = torch.device("cuda", local)
+
+    N, K, D, d = 10, 8, 3, 4
+    masks = m.ends_full_masks(N, K)
+    ctx = m.Context(local)
+    plan = m.Plan(ctx, N, D, K, d, masks)
+    B = args.batch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(ctx.stream):
+        t, f = m.random_waypoint_batch(B, K, D, N, masks, seed=1234 + rank, device=dev, layout=args.layout)
+        coeffs = torch.empty((B, K, D, N), dtype=torch.float64, device=dev)
+        for _ in range(args.warmup):
+            plan.solve(t, f, layout=args.layout, coeffs=coeffs)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.solve(t, f, layout=args.layout, coeffs=coeffs)
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.sync()  # raises if any trajectory flagged bad time / singular
+        assert torch.isfinite(coeffs).all()
+
+        # kernel-only duration: hipEvents on the launch stream (inside the library)
+        kern_us = plan.time_last_solve(max(50, args.steps))
+        extra = {}
+        if args.extra and rank == 0:
+            for big in (125_000, 1_000_000):
+                tb, fb = m.random_waypoint_batch(big, K, D, N, masks, seed=99, device=dev, layout=args.layout)
+                cb = torch.empty((big, K, D, N), dtype=torch.float64, device=dev)
+                plan.solve(tb, fb, layout=args.layout, coeffs=cb)
+                torch.cuda.synchronize()
+                us = plan.time_last_solve(20)
+                extra[f"batch_{big}"] = {"kernel_us": us, "traj_per_s": big / us * 1e6,
+                                         "GBps": big * plan.bytes_per_trajectory / us * 1e-3,
+                                         "frac_of_8TBps": big * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
+                del tb, fb, cb
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        bytes_per_launch = B * plan.bytes_per_trajectory
+        achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)",
+            "value": world * B * args.steps / dt,
+            "unit": "trajectories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch of {B} random-waypoint trajectories per GPU per step, 8 segments, N=10, "
+                                   f"dim=3, snap (BASELINE configs[1]); inputs {args.layout.upper()} resident in HBM, "
+                                   f"coeffs [B][K][D][N]",
+                       "kernel_variant": plan.kernel_variant, "bytes_per_trajectory": plan.bytes_per_trajectory},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch},
+        }
+        if extra:
+            out["extra"] = extra
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(20_000, 4321)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

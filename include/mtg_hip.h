@@ -1,0 +1,135 @@
+/*
+ * mtg_hip.h -- C ABI of libmtg_hip.so: batched PolynomialOptimization<N>::solveLinear()
+ * for AMD MI355X (gfx950).  Eigen-free, torch-free: plain pointers and sizes.
+ *
+ * This is the drop-in boundary for the reference's linear-optimiser hot path.  The
+ * reference exposes that path only as a header-only C++ class template, so "what the
+ * reference's FFI would bind" is the set of member functions below; each entry point
+ * cites the reference interface it replaces, with
+ *   LINH = mav_trajectory_generation/include/mav_trajectory_generation/polynomial_optimization_linear.h
+ *   LIN  = mav_trajectory_generation/include/mav_trajectory_generation/impl/polynomial_optimization_linear_impl.h
+ *
+ * Data conventions (all IEEE double):
+ *   N  = coefficients per polynomial (even, 2..12; polynomial.h:44 kMaxN), h = N/2
+ *   K  = segments, D = dimensions, B = independent trajectories in the batch
+ *   fixed_mask[v] bit p set  <=>  derivative p is a fixed constraint at vertex v
+ *       (a vertex keeps exactly h slots; LIN:206-221.  Constraints of order >= h are
+ *        dropped by the reference, LIN:84-105 -- callers drop them before building masks)
+ *   d_fixed : values of the fixed slots, ordered lexicographically by (vertex, derivative)
+ *             = the reference's fixed_constraints_compact_ (LINH:288-295, LIN:238-246)
+ *   d_free  : the free slots in the same order = free_constraints_compact_ (LINH:194-206)
+ *   coeffs  : [B][K][D][N], increasing powers c0..c(N-1) (LINH:43-44, polynomial.h:34-35),
+ *             i.e. segments_[k][dim].getCoefficients() of trajectory b (LIN:276-280)
+ * Input layouts are described by element strides so that both
+ *   AoS  times[B][K], d_fixed[B][D][n_fixed]   (what a host caller naturally holds) and
+ *   SoA  times[K][B], d_fixed[D][n_fixed][B]   (fully coalesced on the device)
+ * are accepted; mtg_layout_aos()/mtg_layout_soa() fill the stride block.
+ *
+ * Error convention: every function returns MTG_OK (0) or a negative mtg_status; nothing
+ * aborts or throws (the reference CHECK-aborts; the C++ veneer maps codes back to that).
+ */
+#ifndef MTG_HIP_H_
+#define MTG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTG_MAX_N 12
+
+typedef enum mtg_status {
+  MTG_OK = 0,
+  MTG_ERR_INVALID_ARGUMENT = -1, /* LIN:60-65, :76, :289, :502-504 CHECKs                  */
+  MTG_ERR_BAD_SEGMENT_TIME = -2, /* LIN:297 CHECK_GT(segment_time, 0)                      */
+  MTG_ERR_SINGULAR = -3,         /* non-positive pivot in R_PP (rank-deficient problem)    */
+  MTG_ERR_DEVICE = -4,           /* HIP runtime error; see mtg_last_error_string           */
+  MTG_ERR_NO_DEVICE = -5,        /* no gfx950 device / HIP runtime unusable                */
+  MTG_ERR_UNSUPPORTED = -6
+} mtg_status;
+
+typedef struct mtg_context mtg_context; /* (device, stream, scratch) -- one per host thread */
+typedef struct mtg_plan mtg_plan;       /* a7 gather tables for one (N, K, D, d, masks)     */
+
+/* Replaces the constructor + setupFromVertices() structure part: LINH:57, LIN:57-109 and
+ * setupConstraintReorderingMatrix LIN:182-260 (pure indexing, done once per plan). */
+typedef struct mtg_plan_desc {
+  int32_t n_coeffs;               /* N                                                      */
+  int32_t dimension;              /* D (LINH:57)                                            */
+  int32_t n_segments;             /* K = vertices - 1 (LIN:72)                              */
+  int32_t derivative_to_optimize; /* d in [0, N/2-1] (LIN:60-65)                            */
+  const uint32_t* fixed_mask;     /* [K+1], see above                                       */
+} mtg_plan_desc;
+
+typedef struct mtg_plan_info {
+  int32_t n_all;          /* getNumberAllConstraints()   LINH:218 = N*K                     */
+  int32_t n_fixed;        /* getNumberFixedConstraints() LINH:219                           */
+  int32_t n_free;         /* getNumberFreeConstraints()  LINH:220                           */
+  int32_t kernel_variant; /* 0 = generic (runtime K/masks), 1 = specialised register kernel */
+  int64_t algorithmic_bytes_per_trajectory; /* 8*(K + D*n_fixed + K*D*N), SURVEY 8(d)       */
+} mtg_plan_info;
+
+typedef struct mtg_layout {
+  int64_t times_stride_b, times_stride_k;               /* times[b*sb + k*sk]               */
+  int64_t fixed_stride_b, fixed_stride_d, fixed_stride_c; /* d_fixed[b*sb + dim*sd + col*sc] */
+  int64_t free_stride_b, free_stride_d, free_stride_c;    /* d_free likewise                 */
+} mtg_layout;
+
+enum {
+  MTG_FLAG_HOST_POINTERS = 1u << 0, /* all buffers are host memory: the library stages them  */
+  MTG_FLAG_GENERIC_KERNEL = 1u << 1 /* force the generic kernel (tests / A-B measurements)   */
+};
+
+/* ---- context ------------------------------------------------------------------------- */
+/* stream: a hipStream_t (as void*) to enqueue on, or NULL for the library's own stream.   */
+int mtg_context_create(int device, void* stream, mtg_context** out);
+int mtg_context_destroy(mtg_context* ctx);
+/* Waits for everything enqueued on the context; returns MTG_ERR_BAD_SEGMENT_TIME /
+ * MTG_ERR_SINGULAR if any trajectory of a solve since the last sync raised it.            */
+int mtg_context_sync(mtg_context* ctx);
+const char* mtg_last_error_string(const mtg_context* ctx);
+const char* mtg_status_string(int status);
+
+/* ---- plan ---------------------------------------------------------------------------- */
+int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out);
+int mtg_plan_destroy(mtg_plan* plan);
+int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
+void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
+void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+/* Replaces updateSegmentTimes() + solveLinear() (LINH:101,108; LIN:286-305, :339-379,
+ * incl. constructR :308-336 and updateSegmentsFromCompactConstraints :263-283) for `batch`
+ * trajectories sharing one plan.  Asynchronous on the context's stream.
+ *   times   in   segment times (> 0)
+ *   d_fixed in   fixed constraint values
+ *   coeffs  out  [batch][K][D][N]
+ *   d_free  out  optional (NULL): optimised free constraints  (getFreeConstraints LINH:194)
+ *   cost    out  optional (NULL): [batch], computeCost() LIN:124-140 = 0.5 * sum c^T Q c  */
+int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
+                     const double* times, const double* d_fixed, double* coeffs,
+                     double* d_free, double* cost, uint32_t flags);
+
+/* Replaces updateSegmentTimes() + setFreeConstraints() (LIN:500-508): coefficients from
+ * caller-provided free constraints, no solve (the nonlinear optimiser's path,
+ * polynomial_optimization_nonlinear_impl.h:695-696).  d_free is an INPUT here.            */
+int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
+                                  const double* times, const double* d_fixed,
+                                  const double* d_free, double* coeffs, double* cost,
+                                  uint32_t flags);
+
+/* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
+/* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the
+ * context's stream, bracketed by hipEvents recorded on that same stream; returns the mean
+ * kernel-side duration per launch in microseconds.                                        */
+int mtg_time_last_solve(mtg_plan* plan, int iters, double* mean_us);
+/* Accuracy self-test of the device reciprocal used by the LDL^T pivots: max relative error
+ * of rcp(x) vs 1/x over n pseudo-random positive doubles.                                 */
+int mtg_selftest_rcp(mtg_context* ctx, int n, double* max_rel_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTG_HIP_H_ */

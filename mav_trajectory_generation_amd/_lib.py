@@ -1,0 +1,69 @@
+"""ctypes binding of libmtg_hip.so (include/mtg_hip.h).  Fails loudly if the HIP library is missing."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmtg_hip.so")
+
+c_double_p = ctypes.c_void_p  # raw device or host addresses
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [("n_coeffs", ctypes.c_int32), ("dimension", ctypes.c_int32), ("n_segments", ctypes.c_int32),
+                ("derivative_to_optimize", ctypes.c_int32), ("fixed_mask", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("n_all", ctypes.c_int32), ("n_fixed", ctypes.c_int32), ("n_free", ctypes.c_int32),
+                ("kernel_variant", ctypes.c_int32), ("algorithmic_bytes_per_trajectory", ctypes.c_int64)]
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        "times_stride_b", "times_stride_k", "fixed_stride_b", "fixed_stride_d", "fixed_stride_c",
+        "free_stride_b", "free_stride_d", "free_stride_c")]
+
+
+EXPORTS = {
+    "mtg_context_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_context_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_context_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_last_error_string": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "mtg_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "mtg_plan_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_plan_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]),
+    "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
+    "mtg_layout_soa": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
+    "mtg_solve_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
+                                        c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
+    "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
+                                                     c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
+    "mtg_time_last_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "mtg_selftest_rcp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+}
+
+FLAG_HOST_POINTERS = 1
+FLAG_GENERIC_KERNEL = 2
+
+_lib = None
+
+
+def load():
+    """Load libmtg_hip.so and attach prototypes.  Raises if it was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the solver.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

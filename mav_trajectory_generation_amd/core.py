@@ -1,0 +1,205 @@
+"""Thin object layer over the C ABI: Context (device, stream), Plan (N, K, D, d, masks), solve.
+
+Mirrors the reference call sequence (polynomial_optimization_linear.h:57-108):
+    PolynomialOptimization<N> opt(D); opt.setupFromVertices(vertices, times, d); opt.solveLinear();
+as  plan = Plan(ctx, N, D, K, d, fixed_mask); plan.solve(times, d_fixed) -> coeffs [B][K][D][N]
+for a whole batch of trajectories sharing the constraint structure.
+torch is used only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+library_path = L.LIB_PATH
+
+
+class MtgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mtg error {code}: {msg}")
+        self.code = code
+
+
+def _check(lib, code: int, ctx_handle=None):
+    if code != 0:
+        msg = lib.mtg_status_string(code).decode()
+        if ctx_handle:
+            extra = lib.mtg_last_error_string(ctx_handle).decode()
+            if extra:
+                msg += " (" + extra + ")"
+        raise MtgError(code, msg)
+
+
+class Context:
+    """(device, stream, scratch).  Owns a torch.cuda.Stream (`.stream`) that the library enqueues on;
+    solve calls are ordered after work already queued on torch's current stream and vice versa."""
+
+    def __init__(self, device: int = 0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("mav_trajectory_generation_amd needs a HIP device (no CPU fallback)")
+        self.lib = L.load()
+        self.device = int(device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.mtg_context_create(self.device, ctypes.c_void_p(self.stream.cuda_stream),
+                                                     ctypes.byref(h)))
+        self.handle = h
+
+    def _enter(self):
+        """Order the library's stream after torch's current stream (no-op when they are the same)."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+        return cur
+
+    def _leave(self, cur):
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+
+    def sync(self):
+        _check(self.lib, self.lib.mtg_context_sync(self.handle), self.handle)
+
+    def selftest_rcp(self, n: int = 1 << 20) -> float:
+        out = ctypes.c_double(0)
+        _check(self.lib, self.lib.mtg_selftest_rcp(self.handle, n, ctypes.byref(out)), self.handle)
+        return out.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mtg_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    def __init__(self, ctx: Context, n_coeffs: int, dimension: int, n_segments: int,
+                 derivative_to_optimize: Optional[int], fixed_mask: Sequence[int]):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.N, self.D, self.K = int(n_coeffs), int(dimension), int(n_segments)
+        self.deriv = self.N // 2 - 1 if derivative_to_optimize is None else int(derivative_to_optimize)
+        if len(fixed_mask) != self.K + 1:
+            raise MtgError(-1, "fixed_mask must have n_segments + 1 entries")
+        self.fixed_mask = [int(m) for m in fixed_mask]
+        arr = (ctypes.c_uint32 * (self.K + 1))(*self.fixed_mask)
+        desc = L.PlanDesc(self.N, self.D, self.K, self.deriv, arr)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.mtg_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)), ctx.handle)
+        self.handle = h
+        info = L.PlanInfo()
+        _check(self.lib, self.lib.mtg_plan_get_info(h, ctypes.byref(info)))
+        self.n_all, self.n_fixed, self.n_free = info.n_all, info.n_fixed, info.n_free
+        self.kernel_variant = info.kernel_variant
+        self.bytes_per_trajectory = info.algorithmic_bytes_per_trajectory
+
+    def layout(self, batch: int, kind: str) -> L.Layout:
+        lay = L.Layout()
+        if kind == "aos":
+            self.lib.mtg_layout_aos(self.handle, batch, ctypes.byref(lay))
+        elif kind == "soa":
+            self.lib.mtg_layout_soa(self.handle, batch, ctypes.byref(lay))
+        else:
+            raise ValueError(kind)
+        return lay
+
+    @staticmethod
+    def _ptr(t):
+        return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
+              coeffs=None, d_free=None, cost=None, generic: bool = False):
+        """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
+        'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost)."""
+        import torch
+        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        assert times.dtype == torch.float64 and times.is_cuda and times.is_contiguous()
+        assert d_fixed.dtype == torch.float64 and d_fixed.is_cuda and d_fixed.is_contiguous()
+        dev = times.device
+        if coeffs is None:
+            coeffs = torch.empty((batch, self.K, self.D, self.N), dtype=torch.float64, device=dev)
+        if want_free and d_free is None:
+            shape = (batch, self.D, self.n_free) if layout == "aos" else (self.D, self.n_free, batch)
+            d_free = torch.empty(shape, dtype=torch.float64, device=dev)
+        if want_cost and cost is None:
+            cost = torch.empty((batch,), dtype=torch.float64, device=dev)
+        lay = self.layout(batch, layout)
+        flags = L.FLAG_GENERIC_KERNEL if generic else 0
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), self._ptr(times), self._ptr(d_fixed),
+                                       self._ptr(coeffs), self._ptr(d_free), self._ptr(cost), flags)
+        self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+        return coeffs, d_free, cost
+
+    def update_from_free(self, times, d_fixed, d_free, layout: str = "aos", want_cost: bool = False):
+        """setFreeConstraints() path: coefficients from given free constraints, no solve."""
+        import torch
+        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        dev = times.device
+        coeffs = torch.empty((batch, self.K, self.D, self.N), dtype=torch.float64, device=dev)
+        cost = torch.empty((batch,), dtype=torch.float64, device=dev) if want_cost else None
+        lay = self.layout(batch, layout)
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_update_segments_from_free(self.handle, batch, ctypes.byref(lay), self._ptr(times),
+                                                    self._ptr(d_fixed), self._ptr(d_free), self._ptr(coeffs),
+                                                    self._ptr(cost), 0)
+        self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+        return coeffs, cost
+
+    def solve_host(self, times: np.ndarray, d_fixed: np.ndarray, want_free=True, want_cost=True, generic=False):
+        """Host-buffer convenience (AoS numpy in/out, staged through the device by the library)."""
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        d_fixed = np.ascontiguousarray(d_fixed, dtype=np.float64)
+        batch = times.shape[0]
+        coeffs = np.empty((batch, self.K, self.D, self.N))
+        d_free = np.empty((batch, self.D, self.n_free)) if want_free else None
+        cost = np.empty((batch,)) if want_cost else None
+        lay = self.layout(batch, "aos")
+        p = lambda a: ctypes.c_void_p(0) if a is None else ctypes.c_void_p(a.ctypes.data)
+        flags = L.FLAG_HOST_POINTERS | (L.FLAG_GENERIC_KERNEL if generic else 0)
+        rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), p(times), p(d_fixed), p(coeffs),
+                                       p(d_free), p(cost), flags)
+        _check(self.lib, rc, self.ctx.handle)
+        return coeffs, d_free, cost
+
+    def time_last_solve(self, iters: int = 100) -> float:
+        """Mean device duration (us) of the last solve launch, hipEvents on the context stream."""
+        out = ctypes.c_double(0)
+        _check(self.lib, self.lib.mtg_time_last_solve(self.handle, iters, ctypes.byref(out)), self.ctx.handle)
+        return out.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mtg_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_linear_batch(n_coeffs, derivative, fixed_mask, times: np.ndarray, d_fixed: np.ndarray, device: int = 0,
+                       generic: bool = False):
+    """One-shot host convenience: numpy AoS in -> (coeffs, d_free, cost) numpy out, via the HIP path."""
+    ctx = Context(device)
+    dim = d_fixed.shape[1]
+    plan = Plan(ctx, n_coeffs, dim, times.shape[1], derivative, fixed_mask)
+    out = plan.solve_host(times, d_fixed, generic=generic)
+    ctx.sync()
+    plan.close()
+    ctx.close()
+    return out

@@ -1,0 +1,552 @@
+// mtg_hip.hip -- gfx950 kernels and the C ABI of include/mtg_hip.h.
+//
+// Kernel inventory:
+//   mtg_solve_kernel<Cfg, WITH_COST>  fused updateSegmentTimes + constructR + solve + coefficient
+//       recovery (impl/polynomial_optimization_linear_impl.h:286-379, :263-283).  Workgroup =
+//       two wavefronts (forward / backward chain direction) x 64 trajectories; persistent
+//       grid-stride over 64-trajectory tiles; Schur complements of the middle vertex exchanged
+//       through LDS.  Cfg::kStatic variants keep the back-substitution data in registers
+//       (fully unrolled, compile-time masks); the generic variant streams it through a
+//       lane-coalesced global workspace and takes K / masks at run time.
+//   mtg_update_kernel<Cfg, WITH_COST> setFreeConstraints path (impl/...:500-508): recovery only.
+//   mtg_rcp_selftest_kernel           accuracy probe of the pivot reciprocal.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mtg_hip.h"
+#include "mtg_lane.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: direction B
+
+template <class C, bool WITH_COST>
+__global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntiles) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int dir = threadIdx.x >> 6;  // wave-uniform
+  const int K = mtg_nseg<C>(P);
+  const int vm = (K + 1) / 2;
+  const int mm = mtg_mask<C>(P, vm);
+  const int nslots = mtg_mid_slots<C>(mm);
+  double* mine = lds + (size_t)dir * nslots * kWave + lane;
+  const double* other = lds + (size_t)(1 - dir) * nslots * kWave + lane;
+  double* wsl = P.ws ? P.ws + ((long long)blockIdx.x * kBlock + threadIdx.x) : nullptr;
+  MtgLane<C> ln;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b = (long long)tile * kWave + lane;
+    const bool active = b < P.B;
+    if (active) {
+      if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl);
+      else mtg_lane_forward<C, -1>(P, b, ln, wsl);
+      mtg_pack_mid<C>(ln, mm, mine, kWave);
+    }
+    __syncthreads();
+    if (active) {
+      if (dir == 0) mtg_lane_finish<C, 1, WITH_COST>(P, b, ln, wsl, other, kWave);
+      else mtg_lane_finish<C, -1, WITH_COST>(P, b, ln, wsl, other, kWave);
+    }
+    __syncthreads();
+  }
+}
+
+template <class C, bool WITH_COST>
+__global__ __launch_bounds__(256) void mtg_update_kernel(MtgParams P) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < P.B) mtg_lane_update<C, WITH_COST>(P, b);
+}
+
+__global__ void mtg_rcp_selftest_kernel(int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double err = 0.0;
+  if (i < n) {
+    // deterministic pseudo-random positive doubles over ~24 binades
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+    const double m = 1.0 + (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    const int e = (int)((z & 0x3FF) % 49) - 24;
+    const double x = ldexp(m, e);
+    const double r = mtg_rcp(x);
+    const double ref = 1.0 / x;
+    err = fabs(r - ref) / ref;
+  }
+  // block max -> atomic max on the bit pattern (values are non-negative)
+  __shared__ double sm[256];
+  sm[threadIdx.x] = err;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(sm[0]));
+}
+
+// ---------------------------------------------------------------------------------------------
+using SolveFn = void (*)(MtgParams, int);
+using UpdateFn = void (*)(MtgParams);
+
+template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
+
+template <int H, int D>
+SolveFn generic_solve(bool with_cost) {
+  return with_cost ? (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, true>
+                   : (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, false>;
+}
+template <int H, int D>
+UpdateFn generic_update(bool with_cost) {
+  return with_cost ? (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, true>
+                   : (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, false>;
+}
+
+template <int H>
+SolveFn generic_solve_h(int d, bool wc) {
+  switch (d) {
+    case 1: return generic_solve<H, 1>(wc);
+    case 2: return generic_solve<H, 2>(wc);
+    case 3: return generic_solve<H, 3>(wc);
+    case 4: return generic_solve<H, 4>(wc);
+  }
+  return nullptr;
+}
+template <int H>
+UpdateFn generic_update_h(int d, bool wc) {
+  switch (d) {
+    case 1: return generic_update<H, 1>(wc);
+    case 2: return generic_update<H, 2>(wc);
+    case 3: return generic_update<H, 3>(wc);
+    case 4: return generic_update<H, 4>(wc);
+  }
+  return nullptr;
+}
+SolveFn pick_generic_solve(int h, int d, bool wc) {
+  switch (h) {
+    case 1: return generic_solve_h<1>(d, wc);
+    case 2: return generic_solve_h<2>(d, wc);
+    case 3: return generic_solve_h<3>(d, wc);
+    case 4: return generic_solve_h<4>(d, wc);
+    case 5: return generic_solve_h<5>(d, wc);
+    case 6: return generic_solve_h<6>(d, wc);
+  }
+  return nullptr;
+}
+UpdateFn pick_generic_update(int h, int d, bool wc) {
+  switch (h) {
+    case 1: return generic_update_h<1>(d, wc);
+    case 2: return generic_update_h<2>(d, wc);
+    case 3: return generic_update_h<3>(d, wc);
+    case 4: return generic_update_h<4>(d, wc);
+    case 5: return generic_update_h<5>(d, wc);
+    case 6: return generic_update_h<6>(d, wc);
+  }
+  return nullptr;
+}
+
+// Specialised register-resident variants: (H, D, K, start mask, interior mask, end mask).
+struct StaticEntry {
+  int h, d, k, ms, mi, me;
+  SolveFn fn[2];
+};
+#define MTG_STATIC(H, D, K, MS, MI, ME)                                                     \
+  {H, D, K, MS, MI, ME,                                                                     \
+   {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME>, false>,                          \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME>, true>}},
+const StaticEntry kStaticTable[] = {
+#include "mtg_variants.inc"
+};
+#undef MTG_STATIC
+
+const StaticEntry* find_static(int h, int d, int k, const std::vector<int>& mask) {
+  for (const StaticEntry& e : kStaticTable) {
+    if (e.h != h || e.d != d || e.k != k) continue;
+    bool ok = mask[0] == e.ms && mask[k] == e.me;
+    for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
+    if (ok) return &e;
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+struct mtg_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int* d_status = nullptr;
+  int* h_status = nullptr;  // pinned
+  int n_cu = 256;
+  std::string last_error;
+  std::mutex mu;
+};
+
+struct LaunchRecord {
+  bool valid = false;
+  SolveFn fn = nullptr;
+  MtgParams params;
+  int ntiles = 0, grid = 0;
+  size_t lds = 0;
+};
+
+struct mtg_plan {
+  mtg_context* ctx = nullptr;
+  int N = 0, H = 0, D = 0, K = 0, deriv = 0;
+  std::vector<int> mask;            // [K+1]
+  std::vector<int> offF, offP;      // [K+2]
+  int n_fixed = 0, n_free = 0;
+  int* d_tables = nullptr;          // vmask | offF | offP
+  const StaticEntry* fast = nullptr;
+  double* ws = nullptr;
+  size_t ws_bytes = 0;
+  // staging for MTG_FLAG_HOST_POINTERS
+  double* stage = nullptr;
+  size_t stage_bytes = 0;
+  std::vector<LaunchRecord> last;
+};
+
+namespace {
+
+int set_err(mtg_context* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+#define MTG_HIP_TRY(ctx, expr)                                                                 \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return set_err(ctx, MTG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+  } while (0)
+
+int ensure_buffer(mtg_context* ctx, double** buf, size_t* cur, size_t need) {
+  if (*cur >= need) return MTG_OK;
+  if (*buf) MTG_HIP_TRY(ctx, hipFree(*buf));
+  *buf = nullptr;
+  *cur = 0;
+  MTG_HIP_TRY(ctx, hipMalloc((void**)buf, need));
+  *cur = need;
+  return MTG_OK;
+}
+
+void fill_common(const mtg_plan* p, MtgParams& P, int64_t batch, const mtg_layout* L) {
+  std::memset(&P, 0, sizeof(P));
+  P.ts_b = L->times_stride_b; P.ts_k = L->times_stride_k;
+  P.fs_b = L->fixed_stride_b; P.fs_d = L->fixed_stride_d; P.fs_c = L->fixed_stride_c;
+  P.ps_b = L->free_stride_b; P.ps_d = L->free_stride_d; P.ps_c = L->free_stride_c;
+  P.status = p->ctx->d_status;
+  P.vmask = p->d_tables;
+  P.offF = p->d_tables + (p->K + 1);
+  P.offP = p->d_tables + (p->K + 1) + (p->K + 2);
+  P.B = batch;
+  P.K = p->K;
+  P.Dtot = p->D;
+  P.deriv = p->deriv;
+  // host copies of the table offsets (same values as the __constant__ ones)
+  static const int ainv_off[7] = {0, 0, 2, 10, 28, 60, 110};
+  P.ainvoff = ainv_off[p->H];
+  int off = 0;
+  for (int n = 2; n < p->N; n += 2) off += (n / 2) * n * n;
+  P.h1off = off + p->deriv * p->N * p->N;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mtg_status_string(int status) {
+  switch (status) {
+    case MTG_OK: return "ok";
+    case MTG_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MTG_ERR_BAD_SEGMENT_TIME: return "segment times need to be greater than zero";
+    case MTG_ERR_SINGULAR: return "non-positive pivot: free-constraint system is rank deficient";
+    case MTG_ERR_DEVICE: return "HIP runtime error";
+    case MTG_ERR_NO_DEVICE: return "no usable HIP device";
+    case MTG_ERR_UNSUPPORTED: return "unsupported configuration";
+  }
+  return "unknown status";
+}
+
+const char* mtg_last_error_string(const mtg_context* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int mtg_context_create(int device, void* stream, mtg_context** out) {
+  if (!out) return MTG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MTG_ERR_NO_DEVICE;
+  mtg_context* ctx = new (std::nothrow) mtg_context();
+  if (!ctx) return MTG_ERR_DEVICE;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return MTG_ERR_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MTG_ERR_DEVICE; }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+      hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream) != hipSuccess) {
+    delete ctx;
+    return MTG_ERR_DEVICE;
+  }
+  *ctx->h_status = 0;
+  *out = ctx;
+  return MTG_OK;
+}
+
+int mtg_context_destroy(mtg_context* ctx) {
+  if (!ctx) return MTG_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->d_status) hipFree(ctx->d_status);
+  if (ctx->h_status) hipHostFree(ctx->h_status);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MTG_OK;
+}
+
+int mtg_context_sync(mtg_context* ctx) {
+  if (!ctx) return MTG_ERR_INVALID_ARGUMENT;
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int st = *ctx->h_status;
+  if (st & MTG_FLAG_BAD_TIME) return set_err(ctx, MTG_ERR_BAD_SEGMENT_TIME, mtg_status_string(MTG_ERR_BAD_SEGMENT_TIME));
+  if (st & MTG_FLAG_SINGULAR) return set_err(ctx, MTG_ERR_SINGULAR, mtg_status_string(MTG_ERR_SINGULAR));
+  return MTG_OK;
+}
+
+int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out) {
+  if (!ctx || !desc || !out || !desc->fixed_mask) return MTG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  const int N = desc->n_coeffs, D = desc->dimension, K = desc->n_segments, d = desc->derivative_to_optimize;
+  if (N < 2 || N > MTG_MAX_N || (N & 1)) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "n_coeffs must be even in [2,12]");
+  if (D < 1 || K < 1) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "dimension and n_segments must be >= 1");
+  if (d < 0 || d > N / 2 - 1) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "derivative_to_optimize out of range");
+  mtg_plan* p = new (std::nothrow) mtg_plan();
+  if (!p) return MTG_ERR_DEVICE;
+  p->ctx = ctx; p->N = N; p->H = N / 2; p->D = D; p->K = K; p->deriv = d;
+  const int full = (1 << p->H) - 1;
+  p->mask.resize(K + 1);
+  p->offF.assign(K + 2, 0);
+  p->offP.assign(K + 2, 0);
+  for (int v = 0; v <= K; ++v) {
+    p->mask[v] = (int)(desc->fixed_mask[v] & (uint32_t)full);
+    const int nf = __builtin_popcount((unsigned)p->mask[v]);
+    p->offF[v + 1] = p->offF[v] + nf;
+    p->offP[v + 1] = p->offP[v] + (p->H - nf);
+  }
+  p->n_fixed = p->offF[K + 1];
+  p->n_free = p->offP[K + 1];
+  p->fast = find_static(p->H, D, K, p->mask);
+  std::vector<int> tab;
+  tab.insert(tab.end(), p->mask.begin(), p->mask.end());
+  tab.insert(tab.end(), p->offF.begin(), p->offF.end());
+  tab.insert(tab.end(), p->offP.begin(), p->offP.end());
+  if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&p->d_tables, tab.size() * sizeof(int)) != hipSuccess ||
+      hipMemcpy(p->d_tables, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    delete p;
+    return set_err(ctx, MTG_ERR_DEVICE, "plan table upload failed");
+  }
+  *out = p;
+  return MTG_OK;
+}
+
+int mtg_plan_destroy(mtg_plan* p) {
+  if (!p) return MTG_OK;
+  hipSetDevice(p->ctx->device);
+  hipStreamSynchronize(p->ctx->stream);
+  if (p->d_tables) hipFree(p->d_tables);
+  if (p->ws) hipFree(p->ws);
+  if (p->stage) hipFree(p->stage);
+  delete p;
+  return MTG_OK;
+}
+
+int mtg_plan_get_info(const mtg_plan* p, mtg_plan_info* out) {
+  if (!p || !out) return MTG_ERR_INVALID_ARGUMENT;
+  out->n_all = p->N * p->K;
+  out->n_fixed = p->n_fixed;
+  out->n_free = p->n_free;
+  out->kernel_variant = p->fast ? 1 : 0;
+  out->algorithmic_bytes_per_trajectory = 8ll * (p->K + (int64_t)p->D * p->n_fixed + (int64_t)p->K * p->D * p->N);
+  return MTG_OK;
+}
+
+void mtg_layout_aos(const mtg_plan* p, int64_t batch, mtg_layout* L) {
+  (void)batch;
+  L->times_stride_b = p->K; L->times_stride_k = 1;
+  L->fixed_stride_b = (int64_t)p->D * p->n_fixed; L->fixed_stride_d = p->n_fixed; L->fixed_stride_c = 1;
+  L->free_stride_b = (int64_t)p->D * p->n_free; L->free_stride_d = p->n_free; L->free_stride_c = 1;
+}
+
+void mtg_layout_soa(const mtg_plan* p, int64_t batch, mtg_layout* L) {
+  L->times_stride_b = 1; L->times_stride_k = batch;
+  L->fixed_stride_b = 1; L->fixed_stride_d = (int64_t)p->n_fixed * batch; L->fixed_stride_c = batch;
+  L->free_stride_b = 1; L->free_stride_d = (int64_t)p->n_free * batch; L->free_stride_c = batch;
+}
+
+static int64_t span(int64_t batch, int64_t sb, int64_t n1, int64_t s1, int64_t n2, int64_t s2) {
+  return (batch - 1) * sb + (n1 - 1) * s1 + (n2 - 1) * s2 + 1;
+}
+
+static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                      double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only) {
+  if (!p || !L || !times || !coeffs || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = p->ctx;
+  if (p->n_fixed > 0 && !d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_fixed is null");
+  if (update_only && p->n_free > 0 && !d_free) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_free is null");
+  if (batch == 0) return MTG_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  const int64_t n_times = span(batch, L->times_stride_b, p->K, L->times_stride_k, 1, 0);
+  const int64_t n_fix = p->n_fixed ? span(batch, L->fixed_stride_b, p->D, L->fixed_stride_d, p->n_fixed, L->fixed_stride_c) : 0;
+  const int64_t n_fre = p->n_free ? span(batch, L->free_stride_b, p->D, L->free_stride_d, p->n_free, L->free_stride_c) : 0;
+  const int64_t n_coef = batch * p->K * p->D * p->N;
+
+  const double* dt = times; const double* dfx = d_fixed; double* dco = coeffs; double* dfr = d_free; double* dcs = cost;
+  const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
+  if (host) {
+    const size_t need = (size_t)(n_times + n_fix + n_fre + n_coef + batch) * sizeof(double);
+    int rc = ensure_buffer(ctx, &p->stage, &p->stage_bytes, need);
+    if (rc != MTG_OK) return rc;
+    double* s = p->stage;
+    double* s_t = s; s += n_times;
+    double* s_f = s; s += n_fix;
+    double* s_p = s; s += n_fre;
+    double* s_c = s; s += n_coef;
+    double* s_j = s;
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, times, n_times * sizeof(double), hipMemcpyHostToDevice, st));
+    if (n_fix) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_f, d_fixed, n_fix * sizeof(double), hipMemcpyHostToDevice, st));
+    if (update_only && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_p, d_free, n_fre * sizeof(double), hipMemcpyHostToDevice, st));
+    dt = s_t; dfx = s_f; dco = s_c;
+    dfr = (d_free && n_fre) ? s_p : nullptr;
+    dcs = cost ? s_j : nullptr;
+  }
+  if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, batch * sizeof(double), st));
+
+  MtgParams P;
+  fill_common(p, P, batch, L);
+  P.times = dt; P.dfix = dfx; P.coeffs = dco; P.dfree = (p->n_free ? dfr : nullptr); P.cost = dcs;
+  const bool wc = dcs != nullptr;
+  const int ntiles = (int)((batch + kWave - 1) / kWave);
+  p->last.clear();
+
+  if (update_only) {
+    for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
+      const int dc = std::min(4, p->D - dim0);
+      UpdateFn fn = pick_generic_update(p->H, dc, wc);
+      if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no update kernel");
+      MtgParams Q = P;
+      Q.dim0 = dim0;
+      const int grid = (int)((batch + 255) / 256);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, Q);
+    }
+  } else {
+    const bool use_fast = p->fast && !(flags & MTG_FLAG_GENERIC_KERNEL);
+    const int vm = (p->K + 1) / 2;
+    const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
+    for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
+      const int dc = use_fast ? p->D : std::min(4, p->D - dim0);
+      MtgParams Q = P;
+      Q.dim0 = dim0;
+      SolveFn fn;
+      int grid;
+      if (use_fast) {
+        fn = p->fast->fn[wc ? 1 : 0];
+        grid = std::min(ntiles, ctx->n_cu * 8);
+      } else {
+        fn = pick_generic_solve(p->H, dc, wc);
+        if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
+        grid = std::min(ntiles, ctx->n_cu * 4);
+        const int kc = (p->K + 1) / 2;
+        const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
+        const size_t need = (size_t)kc * E * (size_t)grid * kBlock * sizeof(double);
+        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+        if (rc != MTG_OK) return rc;
+        Q.ws = p->ws;
+        Q.ws_stride = (long long)grid * kBlock;
+      }
+      const size_t lds = (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, st, Q, ntiles);
+      LaunchRecord r;
+      r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.lds = lds;
+      p->last.push_back(r);
+      if (use_fast) break;
+    }
+  }
+  MTG_HIP_TRY(ctx, hipGetLastError());
+
+  if (host) {
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(coeffs, dco, n_coef * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
+    MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  return MTG_OK;
+}
+
+int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
+                     const double* d_fixed, double* coeffs, double* d_free, double* cost, uint32_t flags) {
+  return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false);
+}
+
+int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
+                                  const double* d_fixed, const double* d_free, double* coeffs, double* cost,
+                                  uint32_t flags) {
+  return solve_impl(plan, batch, layout, times, d_fixed, coeffs, const_cast<double*>(d_free), cost, flags, true);
+}
+
+int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
+  if (!p || !mean_us || iters < 1) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = p->ctx;
+  if (p->last.empty()) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "no recorded solve launch");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipEvent_t e0, e1;
+  MTG_HIP_TRY(ctx, hipEventCreate(&e0));
+  MTG_HIP_TRY(ctx, hipEventCreate(&e1));
+  MTG_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < iters; ++i) {
+    for (const LaunchRecord& r : p->last) {
+      if (r.params.cost) hipMemsetAsync(r.params.cost, 0, r.params.B * sizeof(double), ctx->stream);
+      hipLaunchKernelGGL(r.fn, dim3(r.grid), dim3(kBlock), r.lds, ctx->stream, r.params, r.ntiles);
+    }
+  }
+  MTG_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+  MTG_HIP_TRY(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  MTG_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *mean_us = (double)ms * 1000.0 / iters;
+  return MTG_OK;
+}
+
+int mtg_selftest_rcp(mtg_context* ctx, int n, double* max_rel_err) {
+  if (!ctx || !max_rel_err || n < 1) return MTG_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double* d = nullptr;
+  MTG_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(double)));
+  MTG_HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(mtg_rcp_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d);
+  MTG_HIP_TRY(ctx, hipMemcpyAsync(max_rel_err, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  MTG_HIP_TRY(ctx, hipFree(d));
+  return MTG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,696 @@
+// mtg_lane.h -- per-lane algorithm of the batched solveLinear() kernels (gfx950).
+//
+// One trajectory is solved by TWO lanes that live in two different wavefronts of one
+// workgroup: wave A walks the vertex chain forward from vertex 0, wave B walks it backward
+// from vertex K; they meet at the middle vertex (a "twisted" block-LDL^T factorisation of
+// the block-tridiagonal R_PP of impl/polynomial_optimization_linear_impl.h:360-367), swap
+// their Schur complements through LDS, and back-substitute outwards, recovering polynomial
+// coefficients segment by segment (impl/...:263-283) as the free derivatives become known.
+// Direction is wave-uniform, so every mask test / table lookup below is scalar.
+//
+// Maths.  With S(T) = diag(T^0..T^(h-1)) on both segment ends,
+//   H(T) = A(T)^-T Q(T) A(T)^-1 = T^(1-2d) S H(1) S        (impl/...:318 without the N^3 products)
+//   coeffs_j = T^-j * sum_k A(1)^-1[j][k] * (S d)_k         (impl/...:276-277)
+// H(1), A(1)^-1 are exact rational constants (mtg_tables.inc).  Time reversal maps the
+// end/end block onto the start/start block with signs (-1)^(a+b); wave B therefore runs the
+// very same code with the signed scale vector s_p = (-T)^p.
+//
+// The file is plain C++17 so that tests/host_emu.cpp can run the identical code on the CPU
+// (test infrastructure only; the product path is the HIP build).
+#ifndef MTG_LANE_H_
+#define MTG_LANE_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MTG_HD __device__ __forceinline__
+#define MTG_TABLE_QUAL __constant__ const
+#else
+#include <cmath>
+#define MTG_HD inline
+#define MTG_TABLE_QUAL static const
+#endif
+
+#include "mtg_tables.inc"
+
+enum { MTG_FLAG_BAD_TIME = 1, MTG_FLAG_SINGULAR = 2 };
+
+struct MtgParams {
+  const double* times;  long long ts_b, ts_k;
+  const double* dfix;   long long fs_b, fs_d, fs_c;
+  double* coeffs;                                   // [B][K][Dtot][N]
+  double* dfree;        long long ps_b, ps_d, ps_c; // optional output (solve) / input (update)
+  double* cost;                                     // optional, pre-zeroed, atomically accumulated
+  double* ws;           long long ws_stride;        // generic mode back-substitution store
+  int* status;                                      // OR of MTG_FLAG_* over the batch
+  const int* vmask;                                 // [K+1] fixed masks        (generic mode)
+  const int* offF;                                  // [K+2] prefix of fixed slots
+  const int* offP;                                  // [K+2] prefix of free slots
+  long long B;
+  int K, Dtot, dim0, deriv, h1off, ainvoff;
+};
+
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_>
+struct MtgCfg {
+  static constexpr int H = H_, N = 2 * H_, D = D_, KT = KT_;
+  static constexpr bool kStatic = KT_ > 0;
+  static constexpr int MS = MS_, MI = MI_, ME = ME_;
+  static constexpr int KA = (KT_ + 1) / 2, KB = KT_ / 2;
+  static constexpr int KCS = kStatic ? ((KT_ + 1) / 2) : 1;
+  static constexpr int FULL = (1 << H_) - 1;
+};
+
+MTG_HD int mtg_popc(int x) {
+#if defined(__HIPCC__)
+  return __builtin_popcount(x);
+#else
+  return __builtin_popcount((unsigned)x);
+#endif
+}
+
+MTG_HD double mtg_fma(double a, double b, double c) {
+#if defined(__HIPCC__)
+  return __builtin_fma(a, b, c);
+#else
+  return std::fma(a, b, c);
+#endif
+}
+
+// 1/x for the LDL^T pivots and segment times.  v_rcp_f64 seed + Newton steps (no IEEE
+// division sequence); accuracy is checked on the device by mtg_selftest_rcp().
+MTG_HD double mtg_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
+  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
+template <class C> MTG_HD int mtg_nseg(const MtgParams& P) { if constexpr (C::kStatic) return C::KT; else return P.K; }
+
+template <class C> MTG_HD int mtg_mask(const MtgParams& P, int v) {
+  if constexpr (C::kStatic) return v == 0 ? C::MS : (v == C::KT ? C::ME : C::MI);
+  else return P.vmask[v];
+}
+template <class C> MTG_HD int mtg_offF(const MtgParams& P, int v) {
+  if constexpr (C::kStatic) return v == 0 ? 0 : mtg_popc(C::MS) + (v - 1) * mtg_popc(C::MI);
+  else return P.offF[v];
+}
+template <class C> MTG_HD int mtg_offP(const MtgParams& P, int v) {
+  if constexpr (C::kStatic) return v == 0 ? 0 : (C::H - mtg_popc(C::MS)) + (v - 1) * (C::H - mtg_popc(C::MI));
+  else return P.offP[v];
+}
+
+// chain step j of direction DIR: actual segment index, left (already reached) and right vertex
+template <int DIR> MTG_HD int mtg_seg(int K, int j) { return DIR > 0 ? j : K - 1 - j; }
+template <int DIR> MTG_HD int mtg_vl(int K, int j) { return DIR > 0 ? j : K - j; }
+template <int DIR> MTG_HD int mtg_vr(int K, int j) { return DIR > 0 ? j + 1 : K - 1 - j; }
+
+template <class C>
+struct MtgLane {
+  double G[C::KCS][C::H][C::H];   // G_v = Dtilde_v^-1 U_v          (static mode: registers)
+  double g[C::KCS][C::D][C::H];   // g_v = Dtilde_v^-1 rtilde_v
+  double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
+  double rc[C::D][C::H];          // its right-hand side
+  int flags;
+};
+
+// fixed values of vertex v (zeros at free slots)
+template <class C>
+MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, double (&out)[C::D][C::H]) {
+  const int off = mtg_offF<C>(P, v);
+#pragma unroll
+  for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < C::H; ++p) {
+      if ((mask >> p) & 1) {
+        const int col = off + mtg_popc(mask & ((1 << p) - 1));
+        out[dm][p] = P.dfix[b * P.fs_b + (long long)(P.dim0 + dm) * P.fs_d + (long long)col * P.fs_c];
+      } else {
+        out[dm][p] = 0.0;
+      }
+    }
+  }
+}
+
+// in-place LDL^T on the index set {p : bit p of `fixed` clear}; A lower triangle in, L (strict
+// lower) out, dinv = 1/d.
+template <int H>
+MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, int& flags) {
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    if ((fixed >> j) & 1) continue;
+    const double dj = A[j][j];
+    if (!(dj > 0.0)) flags |= MTG_FLAG_SINGULAR;
+    const double r = mtg_rcp(dj);
+    dinv[j] = r;
+    double l[H];
+#pragma unroll
+    for (int i = j + 1; i < H; ++i) {
+      if ((fixed >> i) & 1) continue;
+      l[i] = A[i][j] * r;
+    }
+#pragma unroll
+    for (int i = j + 1; i < H; ++i) {
+      if ((fixed >> i) & 1) continue;
+#pragma unroll
+      for (int k = j + 1; k <= i; ++k) {
+        if ((fixed >> k) & 1) continue;
+        A[i][k] = mtg_fma(-l[i], A[k][j], A[i][k]);
+      }
+    }
+#pragma unroll
+    for (int i = j + 1; i < H; ++i) {
+      if ((fixed >> i) & 1) continue;
+      A[i][j] = l[i];
+    }
+  }
+}
+
+// x <- (L D L^T)^-1 x on the free index set
+template <int H>
+MTG_HD void mtg_ldl_solve(const double (&L)[H][H], const double (&dinv)[H], int fixed, double (&x)[H]) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if ((fixed >> i) & 1) continue;
+#pragma unroll
+    for (int k = 0; k < i; ++k) {
+      if ((fixed >> k) & 1) continue;
+      x[i] = mtg_fma(-L[i][k], x[k], x[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if ((fixed >> i) & 1) continue;
+    x[i] *= dinv[i];
+  }
+#pragma unroll
+  for (int i = H - 1; i >= 0; --i) {
+    if ((fixed >> i) & 1) continue;
+#pragma unroll
+    for (int k = i + 1; k < H; ++k) {
+      if ((fixed >> k) & 1) continue;
+      x[i] = mtg_fma(-L[k][i], x[k], x[i]);
+    }
+  }
+}
+
+// per-segment scale vectors: s[p] = (DIR*T)^p, bs[p] = T^(1-2d) * s[p]
+template <int H, int DIR>
+MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], double& tinv, int& flags) {
+  if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
+  tinv = mtg_rcp(T);
+  double base;
+  if (deriv == 0) {
+    base = T;
+  } else {
+    base = tinv;
+    for (int i = 1; i < 2 * deriv - 1; ++i) base *= tinv;
+  }
+  const double ts = DIR > 0 ? T : -T;
+  s[0] = 1.0;
+  bs[0] = base;
+#pragma unroll
+  for (int p = 1; p < H; ++p) {
+    s[p] = s[p - 1] * ts;
+    bs[p] = base * s[p];
+  }
+}
+
+// One forward elimination step (chain step j): completes the left vertex, produces
+// (G, g) for back-substitution and the carried Schur complement for the right vertex.
+template <class C, int DIR>
+MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
+                         double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
+  constexpr int H = C::H, D = C::D, N = C::N;
+  const int K = mtg_nseg<C>(P);
+  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
+  const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
+  const double* h1 = kH1 + P.h1off;
+
+  const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
+  double s[H], bs[H], tinv;
+  mtg_scales<H, DIR>(T, P.deriv, s, bs, tinv, ln.flags);
+
+  double val_l[D][H], val_r[D][H];
+  mtg_load_vals<C>(P, b, vl, ml, val_l);
+  mtg_load_vals<C>(P, b, vr, mr, val_r);
+  // scaled fixed values
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      val_l[dm][p] *= s[p];
+      val_r[dm][p] *= s[p];
+    }
+  }
+
+  // rhs of the left vertex and of the right vertex (fixed-value couplings)
+  double rv[D][H], rnext[D][H];
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      rv[dm][p] = 0.0;
+      rnext[dm][p] = 0.0;
+      if (!((ml >> p) & 1)) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+          if ((ml >> q) & 1) acc = mtg_fma(h1[p * N + q], val_l[dm][q], acc);
+          if ((mr >> q) & 1) acc = mtg_fma(h1[p * N + H + q], val_r[dm][q], acc);
+        }
+        rv[dm][p] = mtg_fma(-bs[p], acc, ln.rc[dm][p]);
+      }
+      if (!((mr >> p) & 1)) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+          if ((mr >> q) & 1) acc = mtg_fma(h1[(H + p) * N + H + q], val_r[dm][q], acc);
+          if ((ml >> q) & 1) acc = mtg_fma(h1[q * N + H + p], val_l[dm][q], acc);
+        }
+        rnext[dm][p] = -bs[p] * acc;
+      }
+    }
+  }
+
+  // Dtilde_l = Sc + a_ll (free x free, lower), U = a_lr (free_l x free_r)
+  double A[H][H], U[H][H], dinv[H];
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    dinv[p] = 0.0;
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      A[p][q] = 0.0;
+      U[p][q] = 0.0;
+      if (!((ml >> p) & 1)) {
+        if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(bs[p] * s[q], h1[p * N + q], ln.Sc[p][q]);
+        if (!((mr >> q) & 1)) U[p][q] = bs[p] * s[q] * h1[p * N + H + q];
+      }
+    }
+  }
+  mtg_ldl<H>(A, dinv, ml, ln.flags);
+
+  // G = Dtilde^-1 U (column by column), g = Dtilde^-1 rv
+#pragma unroll
+  for (int q = 0; q < H; ++q) {
+    if ((mr >> q) & 1) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) G[p][q] = 0.0;
+      continue;
+    }
+    double col[H];
+#pragma unroll
+    for (int p = 0; p < H; ++p) col[p] = U[p][q];
+    mtg_ldl_solve<H>(A, dinv, ml, col);
+#pragma unroll
+    for (int p = 0; p < H; ++p) G[p][q] = ((ml >> p) & 1) ? 0.0 : col[p];
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+    double col[H];
+#pragma unroll
+    for (int p = 0; p < H; ++p) col[p] = rv[dm][p];
+    mtg_ldl_solve<H>(A, dinv, ml, col);
+#pragma unroll
+    for (int p = 0; p < H; ++p) g[dm][p] = ((ml >> p) & 1) ? 0.0 : col[p];
+  }
+
+  // carried onto the right vertex: Sc' = a_rr - U^T G,  rc' = rnext - U^T g
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      ln.Sc[p][q] = 0.0;
+      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) {
+        double acc = bs[p] * s[q] * h1[(H + p) * N + H + q];
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+          if (!((ml >> m) & 1)) acc = mtg_fma(-U[m][p], G[m][q], acc);
+        }
+        ln.Sc[p][q] = acc;
+      }
+    }
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      double acc = rnext[dm][p];
+      if (!((mr >> p) & 1)) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+          if (!((ml >> m) & 1)) acc = mtg_fma(-U[m][p], g[dm][m], acc);
+        }
+      }
+      ln.rc[dm][p] = acc;
+    }
+  }
+}
+
+// Coefficient recovery for one segment (impl/polynomial_optimization_linear_impl.h:274-280):
+// xS / xE = all h derivatives at the segment's start / end vertex.
+template <class C, bool WITH_COST>
+MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
+                          const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H]) {
+  constexpr int H = C::H, D = C::D, N = C::N;
+  const double* ai = kAinvLo + P.ainvoff;   // [H][N]
+  int dummy = 0;
+  double s[H], bs[H], tinv;
+  mtg_scales<H, 1>(T, P.deriv, s, bs, tinv, dummy);
+  double tp[H];                    // T^-(H+j)
+  {
+    double t = tinv;
+#pragma unroll
+    for (int p = 1; p < H; ++p) t *= tinv;
+    tp[0] = t;
+#pragma unroll
+    for (int p = 1; p < H; ++p) tp[p] = tp[p - 1] * tinv;
+  }
+  double invfact[H];
+  {
+    double f = 1.0;
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if (p > 0) f *= (double)p;
+      invfact[p] = 1.0 / f;   // compile-time constant after unrolling
+    }
+  }
+  double cost = 0.0;
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+    double dl[N];
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      dl[p] = s[p] * xS[dm][p];
+      dl[H + p] = s[p] * xE[dm][p];
+    }
+    double c[N], qs[N];
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      c[p] = xS[dm][p] * invfact[p];
+      qs[p] = dl[p] * invfact[p];
+    }
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc = mtg_fma(ai[jj * N + k], dl[k], acc);
+      qs[H + jj] = acc;
+      c[H + jj] = acc * tp[jj];
+    }
+    double* out = P.coeffs + (((long long)b * P.K + seg) * P.Dtot + (P.dim0 + dm)) * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = c[k];
+    if constexpr (WITH_COST) {
+      // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140)
+      // Q(1) is symmetric and zero below row/column d: static full loops, no runtime indexing.
+      const double* q1 = kQ1 + P.h1off;
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        double row = 0.5 * q1[r * N + r] * qs[r];
+#pragma unroll
+        for (int cc = 0; cc < r; ++cc) row = mtg_fma(q1[r * N + cc], qs[cc], row);
+        acc = mtg_fma(row, qs[r], acc);
+      }
+      cost = mtg_fma(bs[0], acc, cost);
+    }
+  }
+  return cost;
+}
+
+// number of doubles a lane publishes for the middle vertex
+template <class C> MTG_HD int mtg_mid_slots(int mm) {
+  const int f = C::H - mtg_popc(mm);
+  return f * (f + 1) / 2 + C::D * f;
+}
+
+template <class C>
+MTG_HD void mtg_pack_mid(const MtgLane<C>& ln, int mm, double* buf, int stride) {
+  int slot = 0;
+#pragma unroll
+  for (int p = 0; p < C::H; ++p) {
+    if ((mm >> p) & 1) continue;
+#pragma unroll
+    for (int q = 0; q <= p; ++q) {
+      if ((mm >> q) & 1) continue;
+      buf[slot * stride] = ln.Sc[p][q];
+      ++slot;
+    }
+  }
+#pragma unroll
+  for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < C::H; ++p) {
+      if ((mm >> p) & 1) continue;
+      buf[slot * stride] = ln.rc[dm][p];
+      ++slot;
+    }
+  }
+}
+
+// merge with the other direction's contribution, solve the middle vertex -> xm (all h slots)
+template <class C>
+MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int vm, int mm,
+                          const double* other, int stride, double (&xm)[C::D][C::H]) {
+  constexpr int H = C::H, D = C::D;
+  double A[H][H], dinv[H];
+  int slot = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    dinv[p] = 0.0;
+#pragma unroll
+    for (int q = 0; q < H; ++q) A[p][q] = 0.0;
+  }
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    if ((mm >> p) & 1) continue;
+#pragma unroll
+    for (int q = 0; q <= p; ++q) {
+      if ((mm >> q) & 1) continue;
+      A[p][q] = ln.Sc[p][q] + other[slot * stride];
+      ++slot;
+    }
+  }
+  mtg_load_vals<C>(P, b, vm, mm, xm);
+  double r[D][H];
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      r[dm][p] = 0.0;
+      if ((mm >> p) & 1) continue;
+      r[dm][p] = ln.rc[dm][p] + other[slot * stride];
+      ++slot;
+    }
+  }
+  mtg_ldl<H>(A, dinv, mm, ln.flags);
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+    mtg_ldl_solve<H>(A, dinv, mm, r[dm]);
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if (!((mm >> p) & 1)) xm[dm][p] = r[dm][p];
+    }
+  }
+}
+
+template <class C>
+MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, const double (&x)[C::D][C::H]) {
+  if (P.dfree == nullptr) return;
+  const int off = mtg_offP<C>(P, v);
+#pragma unroll
+  for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < C::H; ++p) {
+      if ((mask >> p) & 1) continue;
+      const int col = off + (p - mtg_popc(mask & ((1 << p) - 1)));
+      P.dfree[b * P.ps_b + (long long)(P.dim0 + dm) * P.ps_d + (long long)col * P.ps_c] = x[dm][p];
+    }
+  }
+}
+
+// One back-substitution step + coefficient recovery of the segment it completes.
+// xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
+template <class C, int DIR, bool WITH_COST>
+MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const double (&G)[C::H][C::H],
+                           const double (&g)[C::D][C::H], double (&xr)[C::D][C::H]) {
+  constexpr int H = C::H, D = C::D;
+  const int K = mtg_nseg<C>(P);
+  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
+  const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
+  double xl[D][H];
+  mtg_load_vals<C>(P, b, vl, ml, xl);
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if ((ml >> p) & 1) continue;
+      double acc = g[dm][p];
+#pragma unroll
+      for (int q = 0; q < H; ++q) {
+        if (!((mr >> q) & 1)) acc = mtg_fma(-G[p][q], xr[dm][q], acc);
+      }
+      xl[dm][p] = acc;
+    }
+  }
+  mtg_store_free<C>(P, b, vl, ml, xl);
+  const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
+  double cost;
+  if (DIR > 0) cost = mtg_recover<C, WITH_COST>(P, b, seg, T, xl, xr);
+  else cost = mtg_recover<C, WITH_COST>(P, b, seg, T, xr, xl);
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) xr[dm][p] = xl[dm][p];
+  }
+  return cost;
+}
+
+// ---- whole-lane phases -----------------------------------------------------------------
+// wsl: this lane's slab of the generic-mode workspace (element stride P.ws_stride)
+template <class C, int DIR>
+MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, double* wsl) {
+  constexpr int H = C::H, D = C::D;
+  ln.flags = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) ln.rc[dm][p] = 0.0;
+  }
+  if constexpr (C::kStatic) {
+    constexpr int KC = DIR > 0 ? C::KA : C::KB;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) mtg_fwd_step<C, DIR>(P, b, j, ln, ln.G[j], ln.g[j]);
+  } else {
+    const int K = P.K;
+    const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
+    constexpr int E = H * H + D * H;
+    for (int j = 0; j < kc; ++j) {
+      double G[H][H], g[D][H];
+      mtg_fwd_step<C, DIR>(P, b, j, ln, G, g);
+      double* w = wsl + (long long)j * E * P.ws_stride;
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+#pragma unroll
+        for (int q = 0; q < H; ++q) w[(long long)(p * H + q) * P.ws_stride] = G[p][q];
+      }
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+        for (int p = 0; p < H; ++p) w[(long long)(H * H + dm * H + p) * P.ws_stride] = g[dm][p];
+      }
+    }
+  }
+}
+
+template <class C, int DIR, bool WITH_COST>
+MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
+                            const double* other, int stride) {
+  constexpr int H = C::H, D = C::D;
+  const int K = mtg_nseg<C>(P);
+  const int vm = (K + 1) / 2;
+  const int mm = mtg_mask<C>(P, vm);
+  double xr[D][H];
+  mtg_solve_mid<C>(P, b, ln, vm, mm, other, stride, xr);
+  if (DIR > 0) mtg_store_free<C>(P, b, vm, mm, xr);
+  double cost = 0.0;
+  if constexpr (C::kStatic) {
+    constexpr int KC = DIR > 0 ? C::KA : C::KB;
+#pragma unroll
+    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, WITH_COST>(P, b, j, ln.G[j], ln.g[j], xr);
+  } else {
+    const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
+    constexpr int E = H * H + D * H;
+    for (int j = kc - 1; j >= 0; --j) {
+      double G[H][H], g[D][H];
+      const double* w = wsl + (long long)j * E * P.ws_stride;
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+#pragma unroll
+        for (int q = 0; q < H; ++q) G[p][q] = w[(long long)(p * H + q) * P.ws_stride];
+      }
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+        for (int p = 0; p < H; ++p) g[dm][p] = w[(long long)(H * H + dm * H + p) * P.ws_stride];
+      }
+      cost += mtg_bwd_step<C, DIR, WITH_COST>(P, b, j, G, g, xr);
+    }
+  }
+  if constexpr (WITH_COST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(P.cost + b, cost);
+#else
+    P.cost[b] += cost;
+#endif
+  }
+  if (ln.flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(P.status, ln.flags);
+#else
+    *P.status |= ln.flags;
+#endif
+  }
+}
+
+// ---- setFreeConstraints path: coefficients from given d_free (no solve) ------------------
+template <class C, bool WITH_COST>
+MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
+  constexpr int H = C::H, D = C::D;
+  const int K = P.K;
+  double xa[D][H], xb[D][H];
+  double cost = 0.0;
+  int flags = 0;
+  auto load_vertex = [&](int v, double (&x)[D][H]) {
+    const int m = mtg_mask<C>(P, v);
+    mtg_load_vals<C>(P, b, v, m, x);
+    const int off = mtg_offP<C>(P, v);
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+        if ((m >> p) & 1) continue;
+        const int col = off + (p - mtg_popc(m & ((1 << p) - 1)));
+        x[dm][p] = P.dfree[b * P.ps_b + (long long)(P.dim0 + dm) * P.ps_d + (long long)col * P.ps_c];
+      }
+    }
+  };
+  load_vertex(0, xa);
+  for (int i = 0; i < K; ++i) {
+    load_vertex(i + 1, xb);
+    const double T = P.times[b * P.ts_b + (long long)i * P.ts_k];
+    if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
+    cost += mtg_recover<C, WITH_COST>(P, b, i, T, xa, xb);
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) xa[dm][p] = xb[dm][p];
+    }
+  }
+  if constexpr (WITH_COST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(P.cost + b, cost);
+#else
+    P.cost[b] += cost;
+#endif
+  }
+  if (flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(P.status, flags);
+#else
+    *P.status |= flags;
+#endif
+  }
+}
+
+#endif  // MTG_LANE_H_

@@ -1,0 +1,124 @@
+// host_emu.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles the device lane code of
+// mav_trajectory_generation_amd/csrc/mtg_lane.h for the host and runs it sequentially
+// (lane A, lane B, exchange, finish) so that the exact kernel arithmetic can be checked
+// against the oracle without a GPU.  Never linked into libmtg_hip.so; the product path has
+// no CPU fallback.
+#include <cstring>
+#include <vector>
+
+#include "../mav_trajectory_generation_amd/csrc/mtg_lane.h"
+
+namespace {
+
+template <class C, bool WC>
+void emu_solve(MtgParams P) {
+  constexpr int H = C::H, D = C::D;
+  const int K = mtg_nseg<C>(P);
+  const int vm = (K + 1) / 2;
+  const int mm = mtg_mask<C>(P, vm);
+  const int nslots = mtg_mid_slots<C>(mm);
+  const int kc = (K + 1) / 2;
+  const size_t E = (size_t)H * H + (size_t)D * H;
+  std::vector<double> wsa(kc * E + 1), wsb(kc * E + 1), bufa(nslots + 1), bufb(nslots + 1);
+  P.ws_stride = 1;
+  for (long long b = 0; b < P.B; ++b) {
+    MtgLane<C> la, lb;
+    mtg_lane_forward<C, 1>(P, b, la, wsa.data());
+    mtg_lane_forward<C, -1>(P, b, lb, wsb.data());
+    mtg_pack_mid<C>(la, mm, bufa.data(), 1);
+    mtg_pack_mid<C>(lb, mm, bufb.data(), 1);
+    mtg_lane_finish<C, 1, WC>(P, b, la, wsa.data(), bufb.data(), 1);
+    mtg_lane_finish<C, -1, WC>(P, b, lb, wsb.data(), bufa.data(), 1);
+  }
+}
+
+template <class C, bool WC>
+void emu_update(MtgParams P) {
+  for (long long b = 0; b < P.B; ++b) mtg_lane_update<C, WC>(P, b);
+}
+
+using Fn = void (*)(MtgParams);
+template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
+
+template <int H>
+Fn pick_h(int d, bool wc, bool upd) {
+#define CASE(DD)                                                                         \
+  case DD:                                                                               \
+    if (upd) return wc ? (Fn)emu_update<GenericCfg<H, DD>, true> : (Fn)emu_update<GenericCfg<H, DD>, false>; \
+    return wc ? (Fn)emu_solve<GenericCfg<H, DD>, true> : (Fn)emu_solve<GenericCfg<H, DD>, false>;
+  switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) }
+#undef CASE
+  return nullptr;
+}
+Fn pick(int h, int d, bool wc, bool upd) {
+  switch (h) {
+    case 1: return pick_h<1>(d, wc, upd);
+    case 2: return pick_h<2>(d, wc, upd);
+    case 3: return pick_h<3>(d, wc, upd);
+    case 4: return pick_h<4>(d, wc, upd);
+    case 5: return pick_h<5>(d, wc, upd);
+    case 6: return pick_h<6>(d, wc, upd);
+  }
+  return nullptr;
+}
+
+struct StaticEntry { int h, d, k, ms, mi, me; Fn fn[2]; };
+#define MTG_STATIC(H, D, K, MS, MI, ME) \
+  {H, D, K, MS, MI, ME, {(Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME>, false>, (Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME>, true>}},
+const StaticEntry kStatic[] = {
+#include "../mav_trajectory_generation_amd/csrc/mtg_variants.inc"
+};
+#undef MTG_STATIC
+
+}  // namespace
+
+// AoS layouts: times[B][K], dfix[B][D][n_fixed], dfree[B][D][n_free], coeffs[B][K][D][N].
+// mode: 0 = generic solve, 1 = static variant if one matches (returns -2 if none), 2 = update-from-free.
+extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long long B, const double* times,
+                           const double* dfix, double* coeffs, double* dfree, double* cost, int mode, int* status) {
+  const int H = N / 2;
+  std::vector<int> offF(K + 2, 0), offP(K + 2, 0);
+  for (int v = 0; v <= K; ++v) {
+    const int nf = __builtin_popcount((unsigned)mask[v]);
+    offF[v + 1] = offF[v] + nf;
+    offP[v + 1] = offP[v] + H - nf;
+  }
+  const int n_fixed = offF[K + 1], n_free = offP[K + 1];
+  MtgParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.times = times; P.ts_b = K; P.ts_k = 1;
+  P.dfix = dfix; P.fs_b = (long long)D * n_fixed; P.fs_d = n_fixed; P.fs_c = 1;
+  P.coeffs = coeffs;
+  P.dfree = n_free ? dfree : nullptr; P.ps_b = (long long)D * n_free; P.ps_d = n_free; P.ps_c = 1;
+  P.cost = cost;
+  int st = 0;
+  P.status = &st;
+  P.vmask = mask; P.offF = offF.data(); P.offP = offP.data();
+  P.B = B; P.K = K; P.Dtot = D; P.deriv = deriv;
+  P.ainvoff = kAinvLoOff[H];
+  P.h1off = kH1Off[H][deriv];
+  if (cost) for (long long b = 0; b < B; ++b) cost[b] = 0.0;
+  const bool wc = cost != nullptr;
+  if (mode == 1) {
+    for (const StaticEntry& e : kStatic) {
+      if (e.h != H || e.d != D || e.k != K) continue;
+      bool ok = mask[0] == e.ms && mask[K] == e.me;
+      for (int v = 1; v < K && ok; ++v) ok = mask[v] == e.mi;
+      if (!ok) continue;
+      e.fn[wc ? 1 : 0](P);
+      if (status) *status = st;
+      return 0;
+    }
+    return -2;
+  }
+  for (int dim0 = 0; dim0 < D; dim0 += 4) {
+    const int dc = D - dim0 < 4 ? D - dim0 : 4;
+    Fn fn = pick(H, dc, wc, mode == 2);
+    if (!fn) return -1;
+    MtgParams Q = P;
+    Q.dim0 = dim0;
+    fn(Q);
+  }
+  if (status) *status = st;
+  return 0;
+}

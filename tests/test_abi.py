@@ -1,0 +1,56 @@
+"""CPU tests of the drop-in boundary: libmtg_hip.so loads and exports every symbol include/mtg_hip.h declares
+(no compute calls without a GPU), argument validation that needs no device, and loud failure without one."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mtg_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtg_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("mtg_context_create", "mtg_plan_create", "mtg_solve_linear", "mtg_update_segments_from_free",
+              "mtg_context_sync", "mtg_time_last_solve"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from mav_trajectory_generation_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert set(declared_symbols()) == set(_lib.EXPORTS.keys())
+
+
+def test_status_strings_and_no_device_is_loud():
+    import torch
+    from mav_trajectory_generation_amd import _lib
+    lib = _lib.load()
+    assert lib.mtg_status_string(0) == b"ok"
+    assert b"greater than zero" in lib.mtg_status_string(-2)
+    if not torch.cuda.is_available():
+        import ctypes
+        h = ctypes.c_void_p()
+        assert lib.mtg_context_create(0, None, ctypes.byref(h)) == -5  # MTG_ERR_NO_DEVICE, no silent fallback
+        import mav_trajectory_generation_amd as m
+        with pytest.raises(RuntimeError):
+            m.Context(0)
+
+
+def test_product_package_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "mav_trajectory_generation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert "oracle/" not in txt or f.endswith(".py") and "lives in oracle/" in txt, f

@@ -1,0 +1,197 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libmtg_hip.so), against the oracle, the committed
+golden fixtures and the mpmath truth; size-independent properties at BASELINE.json's full batch sizes.
+Tolerances: SURVEY.md 8(d) norm-wise metric max_poly ||c - c_ref||_inf / ||c_ref||_inf <= 1e-9 for N <= 10 with
+d = h-1; looser where float64 evaluation of the reference's own formulas is itself less accurate (N = 12, d < h-1)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "solve_linear_golden.npz"))
+NAMES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def case(name):
+    pre = name + "/"
+    return {k[len(pre):]: GOLD[k] for k in GOLD.files if k.startswith(pre)}
+
+
+def tol_for(n, d):
+    if n == 12 and d < n // 2 - 1:
+        return 1e-5
+    if n == 12 or d < n // 2 - 1:
+        return 5e-7
+    return 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import mav_trajectory_generation_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_solve(ctx, n, d, masks, times, d_fixed, layout="aos", generic=False, want=True):
+    import torch
+    import mav_trajectory_generation_amd as m
+    dim, k = d_fixed.shape[1], times.shape[1]
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t = torch.from_numpy(np.ascontiguousarray(times)).cuda()
+    f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda()
+    if layout == "soa":
+        t = t.t().contiguous()
+        f = f.permute(1, 2, 0).contiguous()
+    co, fr, cost = plan.solve(t, f, layout=layout, want_free=want, want_cost=want, generic=generic)
+    ctx.sync()
+    if fr is not None and layout == "soa":
+        fr = fr.permute(2, 0, 1)
+    out = (co.cpu().numpy(), None if fr is None else fr.cpu().numpy(), None if cost is None else cost.cpu().numpy(),
+           plan.kernel_variant)
+    plan.close()
+    return out
+
+
+def test_native_library_is_the_loaded_one(ctx):
+    from mav_trajectory_generation_amd import _lib
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(_lib.LIB_PATH) in maps
+
+
+def test_device_reciprocal_accuracy(ctx):
+    """v_rcp_f64 + 2 Newton steps used for LDL^T pivots and 1/T: must be at rounding level."""
+    assert ctx.selftest_rcp(1 << 20) < 4.5e-16
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_golden_fixtures(ctx, name, generic, layout):
+    c = case(name)
+    n, d = int(c["n"]), int(c["d"])
+    masks = [int(m) for m in c["masks"]]
+    co, fr, cost, variant = gpu_solve(ctx, n, d, masks, c["times"], c["d_fixed"], layout, generic)
+    assert helpers.poly_relerr(co, c["coeffs_lit"]) < tol_for(n, d)
+    if "coeffs_mp" in c:
+        assert helpers.poly_relerr(co, c["coeffs_mp"]) < (1e-7 if n == 12 else 1e-11)
+        if c["d_free_mp"].size:
+            assert np.abs(fr - c["d_free_mp"]).max() <= 1e-7 * max(1.0, np.abs(c["d_free_mp"]).max())
+        assert np.allclose(cost, c["cost_mp"], rtol=1e-7)
+    assert helpers.check_path(masks, c["times"], c["d_fixed"], co) < 1e-6
+    if name == "two_vertices":
+        assert np.abs(co[0, 0, 0] - c["matlab_coeffs"]).max() < 1e-12   # TOPT:777-780
+
+
+def test_specialised_variant_is_selected_for_baseline_config(ctx):
+    import mav_trajectory_generation_amd as m
+    plan = m.Plan(ctx, 10, 3, 8, 4, m.ends_full_masks(10, 8))
+    assert plan.kernel_variant == 1 and plan.n_fixed == 17 and plan.n_free == 28
+    assert plan.bytes_per_trajectory == 2392
+    plan.close()
+
+
+@pytest.mark.parametrize("bsz", [1, 63, 64, 65, 1000])
+def test_ragged_batch_sizes_vs_oracle(ctx, bsz):
+    masks, times, d_fixed = helpers.reference_batch(bsz, 8, 10, 3, 31337)
+    c_lit, f_lit, j_lit = onp.solve_batch(10, 4, masks, times, d_fixed)
+    for generic in (False, True):
+        co, fr, cost, _ = gpu_solve(ctx, 10, 4, masks, times, d_fixed, generic=generic)
+        assert helpers.poly_relerr(co, c_lit) < 1e-9
+        assert np.abs(fr - f_lit).max() <= 1e-8 * max(1.0, np.abs(f_lit).max())
+        assert np.allclose(cost, j_lit, rtol=1e-8)
+
+
+@pytest.mark.parametrize("n,d,k,dim,masks", [
+    (10, 4, 6, 3, [31, 1, 3, 1, 5, 9, 31]),
+    (10, 4, 5, 5, None),
+    (10, 4, 9, 7, None),
+    (10, 4, 3, 2, [3, 1, 1, 7]),
+    (10, 4, 1, 3, None),
+    (2, 0, 3, 2, None), (4, 1, 3, 2, None), (6, 2, 4, 3, None),
+    (8, 3, 32, 3, None), (12, 5, 7, 4, None), (10, 4, 50, 1, None), (10, 4, 100, 3, None),
+])
+def test_edge_shapes_vs_oracle(ctx, n, d, k, dim, masks):
+    masks, times, d_fixed = helpers.reference_batch(5, k, n, dim, 4242, masks)
+    c_lit, f_lit, j_lit = onp.solve_batch(n, d, masks, times, d_fixed)
+    co, fr, cost, _ = gpu_solve(ctx, n, d, masks, times, d_fixed)
+    assert helpers.poly_relerr(co, c_lit) < tol_for(n, d)
+    assert helpers.check_path(masks, times, d_fixed, co) < 1e-6
+    assert np.allclose(cost, j_lit, rtol=1e-6)
+
+
+def test_host_pointer_path_and_update_from_free(ctx):
+    import torch
+    import mav_trajectory_generation_amd as m
+    c = case("config2")
+    masks = [int(x) for x in c["masks"]]
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    co, fr, cost = plan.solve_host(c["times"], c["d_fixed"])
+    ctx.sync()
+    assert helpers.poly_relerr(co, c["coeffs_lit"]) < 1e-9
+    t = torch.from_numpy(c["times"]).cuda()
+    f = torch.from_numpy(c["d_fixed"]).cuda()
+    p = torch.from_numpy(fr).cuda()
+    co2, cost2 = plan.update_from_free(t, f, p, want_cost=True)
+    ctx.sync()
+    assert helpers.poly_relerr(co2.cpu().numpy(), co) < 1e-13
+    assert np.allclose(cost2.cpu().numpy(), cost, rtol=1e-12)
+    # setFreeConstraints with perturbed d_P costs more (optimality, SURVEY.md section 4 gap)
+    co3, cost3 = plan.update_from_free(t, f, p * 1.01, want_cost=True)
+    ctx.sync()
+    assert np.all(cost3.cpu().numpy() >= cost * (1 - 1e-12))
+    plan.close()
+
+
+def test_error_codes(ctx):
+    import torch
+    import mav_trajectory_generation_amd as m
+    with pytest.raises(m.MtgError) as e:
+        m.Plan(ctx, 11, 3, 8, 4, [1] * 9)
+    assert e.value.code == -1
+    with pytest.raises(m.MtgError):
+        m.Plan(ctx, 10, 3, 8, 5, [1] * 9)          # derivative > N/2-1 (LIN:60-65)
+    c = case("config2")
+    masks = [int(x) for x in c["masks"]]
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t = c["times"].copy()
+    t[2, 5] = -1.0                                  # LIN:297
+    plan.solve(torch.from_numpy(t).cuda(), torch.from_numpy(c["d_fixed"]).cuda())
+    with pytest.raises(m.MtgError) as e:
+        ctx.sync()
+    assert e.value.code == -2
+    ctx.sync()                                      # status is cleared by the failing sync
+    plan.close()
+
+
+@pytest.mark.parametrize("bsz", [10_000, 125_000])
+def test_full_size_properties(ctx, bsz):
+    """BASELINE config 2 (10k) and the per-GPU share of config 3 (1M / 8): properties that need no oracle --
+    checkPath at 1e-6, specialised vs generic kernel agreement, linearity in d_F, and oracle parity on a
+    strided 500-trajectory subset."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(bsz, 8, 3, 10, masks, seed=1, device="cuda")
+    co, fr, cost = plan.solve(t, f, want_free=True, want_cost=True)
+    co_g, _, _ = plan.solve(t, f, generic=True)
+    co_2, _, _ = plan.solve(t, f * 2.0)
+    ctx.sync()
+    assert torch.isfinite(co).all()
+    den = co.abs().amax(dim=-1).clamp_min(1e-300)
+    assert float(((co - co_g).abs().amax(dim=-1) / den).max()) < 1e-11
+    assert float(((co_2 - 2 * co).abs().amax(dim=-1) / den).max()) < 1e-13
+    tn, fn, cn = t.cpu().numpy(), f.cpu().numpy(), co.cpu().numpy()
+    assert helpers.check_path(masks, tn, fn, cn) < 1e-6
+    idx = np.arange(0, bsz, bsz // 500)[:500]
+    c_lit, f_lit, j_lit = onp.solve_batch(10, 4, masks, tn[idx], fn[idx])
+    assert helpers.poly_relerr(cn[idx], c_lit) < 1e-9
+    assert np.allclose(cost.cpu().numpy()[idx], j_lit, rtol=1e-8)
+    plan.close()

@@ -1,0 +1,86 @@
+"""CPU tests of the DEVICE lane code (mtg_lane.h) compiled for the host by tests/host_emu.cpp: same
+arithmetic as the HIP kernels (twisted block-LDL^T, unit-time tables), checked against the oracle and the
+mpmath truth.  The emulation is test infrastructure; the product has no CPU path."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle_np as onp
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "solve_linear_golden.npz"))
+
+
+def case(name):
+    pre = name + "/"
+    return {k[len(pre):]: GOLD[k] for k in GOLD.files if k.startswith(pre)}
+
+
+NAMES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def tol_for(n, d):
+    # float64 evaluation of the reference's formulas is itself only this accurate (see test_oracle.py)
+    if n == 12 and d < n // 2 - 1:
+        return 1e-5   # e.g. the yaw instantiation of test_feasibility.cpp:109-113: cond(R_PP) ~ 1e8
+    if n == 12 or d < n // 2 - 1:
+        return 5e-7
+    return 1e-9
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_emulated_kernel_matches_oracle_on_golden(host_emu, name, mode):
+    c = case(name)
+    n, d = int(c["n"]), int(c["d"])
+    masks = [int(m) for m in c["masks"]]
+    k = c["times"].shape[1]
+    dim = c["d_fixed"].shape[1]
+    rc, co, fr, cost, st = helpers.emu_run(host_emu, n, dim, k, d, masks, c["times"], c["d_fixed"], mode)
+    if mode == 1 and rc == -2:
+        pytest.skip("no specialised variant for this shape")
+    assert rc == 0 and st == 0
+    assert helpers.poly_relerr(co, c["coeffs_lit"]) < tol_for(n, d)
+    if "coeffs_mp" in c:
+        # the kernel algorithm is closer to the truth than the literal evaluation
+        assert helpers.poly_relerr(co, c["coeffs_mp"]) < (1e-7 if n == 12 else 1e-11)
+        if c["d_free_mp"].size:
+            assert np.abs(fr - c["d_free_mp"]).max() <= 1e-7 * max(1.0, np.abs(c["d_free_mp"]).max())
+        assert np.allclose(cost, c["cost_mp"], rtol=1e-7)
+    assert helpers.check_path(masks, c["times"], c["d_fixed"], co) < 1e-6
+
+
+def test_update_from_free_matches_solve(host_emu):
+    c = case("config2")
+    masks = [int(m) for m in c["masks"]]
+    rc, co, fr, cost, st = helpers.emu_run(host_emu, 10, 3, 8, 4, masks, c["times"], c["d_fixed"], 0)
+    rc2, co2, _, cost2, st2 = helpers.emu_run(host_emu, 10, 3, 8, 4, masks, c["times"], c["d_fixed"], 2, d_free_in=fr)
+    assert rc2 == 0 and st2 == 0
+    assert helpers.poly_relerr(co2, co) < 1e-13
+    assert np.allclose(cost, cost2, rtol=1e-12)
+
+
+def test_bad_time_and_singular_flags(host_emu):
+    c = case("config2")
+    masks = [int(m) for m in c["masks"]]
+    t = c["times"].copy()
+    t[3, 2] = 0.0
+    rc, _, _, _, st = helpers.emu_run(host_emu, 10, 3, 8, 4, masks, t, c["d_fixed"], 0)
+    assert st & 1  # MTG_FLAG_BAD_TIME (LIN:297 CHECK_GT)
+
+
+@pytest.mark.parametrize("n,d,k,dim,masks", [
+    (10, 4, 6, 3, [31, 1, 3, 1, 5, 9, 31]),      # ragged interior masks
+    (10, 4, 5, 5, None),                          # D > 4 -> dimension chunks
+    (10, 4, 3, 2, [3, 1, 1, 7]),                  # free end-vertex derivatives
+    (2, 0, 3, 2, None), (4, 1, 3, 2, None), (6, 2, 4, 3, None),
+    (12, 5, 7, 4, None),
+])
+def test_emulated_kernel_edge_shapes(host_emu, n, d, k, dim, masks):
+    masks, times, d_fixed = helpers.reference_batch(6, k, n, dim, 4242, masks)
+    c_lit, f_lit, j_lit = onp.solve_batch(n, d, masks, times, d_fixed)
+    rc, co, fr, cost, st = helpers.emu_run(host_emu, n, dim, k, d, masks, times, d_fixed, 0)
+    assert rc == 0 and st == 0
+    assert helpers.poly_relerr(co, c_lit) < tol_for(n, d)
+    assert helpers.check_path(masks, times, d_fixed, co) < 1e-6
