@@ -28,7 +28,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: direction B
 
-template <class C, bool WITH_COST>
+template <class C, int OUT>
 __global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntiles) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -51,17 +51,17 @@ __global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntil
     }
     __syncthreads();
     if (active) {
-      if (dir == 0) mtg_lane_finish<C, 1, WITH_COST>(P, b, ln, wsl, other, kWave);
-      else mtg_lane_finish<C, -1, WITH_COST>(P, b, ln, wsl, other, kWave);
+      if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave);
+      else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave);
     }
     __syncthreads();
   }
 }
 
-template <class C, bool WITH_COST>
+template <class C, int OUT>
 __global__ __launch_bounds__(256) void mtg_update_kernel(MtgParams P) {
   const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < P.B) mtg_lane_update<C, WITH_COST>(P, b);
+  if (b < P.B) mtg_lane_update<C, OUT>(P, b);
 }
 
 __global__ void mtg_rcp_selftest_kernel(int n, double* out) {
@@ -97,13 +97,14 @@ template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
 
 template <int H, int D>
 SolveFn generic_solve(bool with_cost) {
-  return with_cost ? (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, true>
-                   : (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, false>;
+  // generic kernels: OUT=3 handles cost / d_free behind run-time null checks
+  return with_cost ? (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, 3>
+                   : (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, 0>;
 }
 template <int H, int D>
 UpdateFn generic_update(bool with_cost) {
-  return with_cost ? (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, true>
-                   : (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, false>;
+  return with_cost ? (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, 1>
+                   : (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, 0>;
 }
 
 template <int H>
@@ -151,21 +152,21 @@ UpdateFn pick_generic_update(int h, int d, bool wc) {
 
 // Specialised register-resident variants: (H, D, K, start mask, interior mask, end mask).
 struct StaticEntry {
-  int h, d, k, ms, mi, me;
+  int h, d, k, ms, mi, me, dv;
   SolveFn fn[2];
 };
-#define MTG_STATIC(H, D, K, MS, MI, ME)                                                     \
-  {H, D, K, MS, MI, ME,                                                                     \
-   {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME>, false>,                          \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME>, true>}},
+#define MTG_STATIC(H, D, K, MS, MI, ME, DV)                                                     \
+  {H, D, K, MS, MI, ME, DV,                                                                     \
+   {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,                              \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>}},
 const StaticEntry kStaticTable[] = {
 #include "mtg_variants.inc"
 };
 #undef MTG_STATIC
 
-const StaticEntry* find_static(int h, int d, int k, const std::vector<int>& mask) {
+const StaticEntry* find_static(int h, int d, int k, int deriv, const std::vector<int>& mask) {
   for (const StaticEntry& e : kStaticTable) {
-    if (e.h != h || e.d != d || e.k != k) continue;
+    if (e.h != h || e.d != d || e.k != k || e.dv != deriv) continue;
     bool ok = mask[0] == e.ms && mask[k] == e.me;
     for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
     if (ok) return &e;
@@ -348,7 +349,7 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   }
   p->n_fixed = p->offF[K + 1];
   p->n_free = p->offP[K + 1];
-  p->fast = find_static(p->H, D, K, p->mask);
+  p->fast = find_static(p->H, D, K, d, p->mask);
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
   tab.insert(tab.end(), p->offF.begin(), p->offF.end());
@@ -440,7 +441,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   MtgParams P;
   fill_common(p, P, batch, L);
   P.times = dt; P.dfix = dfx; P.coeffs = dco; P.dfree = (p->n_free ? dfr : nullptr); P.cost = dcs;
-  const bool wc = dcs != nullptr;
+  const bool wc = dcs != nullptr || (!update_only && P.dfree != nullptr);
   const int ntiles = (int)((batch + kWave - 1) / kWave);
   p->last.clear();
 

@@ -50,15 +50,50 @@ struct MtgParams {
   int K, Dtot, dim0, deriv, h1off, ainvoff;
 };
 
-template <int H_, int D_, int KT_, int MS_, int MI_, int ME_>
+// offsets into the generated tables (same formulas as gen_tables.py)
+constexpr int mtg_h1_offset(int n, int d) {
+  int off = 0;
+  for (int m = 2; m < n; m += 2) off += (m / 2) * m * m;
+  return off + d * n * n;
+}
+constexpr int mtg_ainv_offset(int n) {
+  int off = 0;
+  for (int m = 2; m < n; m += 2) off += (m / 2) * m;
+  return off;
+}
+
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0>
 struct MtgCfg {
   static constexpr int H = H_, N = 2 * H_, D = D_, KT = KT_;
   static constexpr bool kStatic = KT_ > 0;
+  static constexpr int DV = DV_;   // static mode: derivative_to_optimize (table offsets fold to immediates)
+  static constexpr int H1OFF = mtg_h1_offset(2 * H_, DV_), AINVOFF = mtg_ainv_offset(2 * H_);
   static constexpr int MS = MS_, MI = MI_, ME = ME_;
   static constexpr int KA = (KT_ + 1) / 2, KB = KT_ / 2;
   static constexpr int KCS = kStatic ? ((KT_ + 1) / 2) : 1;
   static constexpr int FULL = (1 << H_) - 1;
+  // static mode: fixed-slot column prefix and the column range each direction touches
+  static constexpr int popc(int x) { int c = 0; for (; x; x &= x - 1) ++c; return c; }
+  static constexpr int offF(int v) { return v == 0 ? 0 : popc(MS_) + (v - 1) * popc(MI_); }
+  static constexpr int offFEnd = kStatic ? offF(KT_) + popc(ME_) : 0;
+  static constexpr int colBeginA = 0, colEndA = kStatic ? offF(KA + 1 > KT_ ? KT_ : KA + 1) + (KA + 1 > KT_ ? popc(ME_) : 0) : 0;
+  static constexpr int colBeginB = kStatic ? offF(KA) : 0, colEndB = offFEnd;
+  static constexpr int NCA = colEndA - colBeginA, NCB = colEndB - colBeginB;
+  static constexpr int NC = kStatic ? (NCA > NCB ? NCA : NCB) : 1;
 };
+
+// Opaque re-definition of a (wave-uniform) table pointer.  Without it LICM hoists every scalar
+// table load out of the tile loop, the ~250 live constants overflow the SGPR file and come back as
+// v_readlane traffic (measured: 2231 v_readlane in the K=8 kernel).  With it the s_loads stay
+// inside the phase that uses them.
+// (The offset, not the pointer, is laundered: a pointer that went through inline asm loses its
+// constant address space and the loads degrade to per-lane flat_load.)
+MTG_HD int mtg_launder(int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(off));
+#endif
+  return off;
+}
 
 MTG_HD int mtg_popc(int x) {
 #if defined(__HIPCC__)
@@ -89,6 +124,21 @@ MTG_HD double mtg_rcp(double x) {
 #endif
 }
 
+// Table bases.  Static mode: compile-time offset => every entry folds to an immediate (no SGPR
+// pressure, trivially rematerialisable).  Generic mode: runtime offset, laundered (see above).
+template <class C> MTG_HD const double* mtg_h1(const MtgParams& P) {
+  if constexpr (C::kStatic) return kH1 + C::H1OFF; else return kH1 + mtg_launder(P.h1off);
+}
+template <class C> MTG_HD const double* mtg_q1(const MtgParams& P) {
+  if constexpr (C::kStatic) return kQ1 + C::H1OFF; else return kQ1 + mtg_launder(P.h1off);
+}
+template <class C> MTG_HD const double* mtg_ainv(const MtgParams& P) {
+  if constexpr (C::kStatic) return kAinvLo + C::AINVOFF; else return kAinvLo + mtg_launder(P.ainvoff);
+}
+template <class C> MTG_HD int mtg_deriv(const MtgParams& P) {
+  if constexpr (C::kStatic) return C::DV; else return P.deriv;
+}
+
 template <class C> MTG_HD int mtg_nseg(const MtgParams& P) { if constexpr (C::kStatic) return C::KT; else return P.K; }
 
 template <class C> MTG_HD int mtg_mask(const MtgParams& P, int v) {
@@ -115,12 +165,44 @@ struct MtgLane {
   double g[C::KCS][C::D][C::H];   // g_v = Dtilde_v^-1 rtilde_v
   double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
   double rc[C::D][C::H];          // its right-hand side
+  double T[C::KCS];               // static mode: this lane's segment times, chain order
+  double fx[C::D][C::NC];         // static mode: this lane's fixed values (columns colBegin..colEnd)
   int flags;
 };
 
+// Static mode: issue every input load of this lane's half-chain up front with incrementally
+// advanced per-lane pointers (one v_lshl_add_u64 per load, no hoistable 64-bit stride products).
+template <class C, int DIR>
+MTG_HD void mtg_preload(const MtgParams& P, long long b, MtgLane<C>& ln) {
+  if constexpr (C::kStatic) {
+    constexpr int KC = DIR > 0 ? C::KA : C::KB;
+    constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
+    constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
+    const double* pt = P.times + b * P.ts_b + (long long)(DIR > 0 ? 0 : C::KT - 1) * P.ts_k;
+    const long long tstep = DIR > 0 ? P.ts_k : -P.ts_k;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      ln.T[j] = *pt;
+      pt += tstep;
+    }
+    const double* pd = P.dfix + b * P.fs_b + (long long)P.dim0 * P.fs_d + (long long)c0 * P.fs_c;
+#pragma unroll
+    for (int dm = 0; dm < C::D; ++dm) {
+      const double* pc = pd;
+#pragma unroll
+      for (int c = 0; c < nc; ++c) {
+        ln.fx[dm][c] = *pc;
+        pc += P.fs_c;
+      }
+      pd += P.fs_d;
+    }
+  }
+}
+
 // fixed values of vertex v (zeros at free slots)
-template <class C>
-MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, double (&out)[C::D][C::H]) {
+template <class C, int DIR>
+MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, const MtgLane<C>& ln,
+                          double (&out)[C::D][C::H]) {
   const int off = mtg_offF<C>(P, v);
 #pragma unroll
   for (int dm = 0; dm < C::D; ++dm) {
@@ -128,7 +210,11 @@ MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, doub
     for (int p = 0; p < C::H; ++p) {
       if ((mask >> p) & 1) {
         const int col = off + mtg_popc(mask & ((1 << p) - 1));
-        out[dm][p] = P.dfix[b * P.fs_b + (long long)(P.dim0 + dm) * P.fs_d + (long long)col * P.fs_c];
+        if constexpr (C::kStatic) {
+          out[dm][p] = ln.fx[dm][col - (DIR > 0 ? C::colBeginA : C::colBeginB)];
+        } else {
+          out[dm][p] = P.dfix[b * P.fs_b + (long long)(P.dim0 + dm) * P.fs_d + (long long)col * P.fs_c];
+        }
       } else {
         out[dm][p] = 0.0;
       }
@@ -208,7 +294,10 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
     base = T;
   } else {
     base = tinv;
-    for (int i = 1; i < 2 * deriv - 1; ++i) base *= tinv;
+#pragma unroll
+    for (int i = 1; i < 2 * H - 1; ++i) {
+      if (i < 2 * deriv - 1) base *= tinv;
+    }
   }
   const double ts = DIR > 0 ? T : -T;
   s[0] = 1.0;
@@ -229,15 +318,16 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
   const int K = mtg_nseg<C>(P);
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
   const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
-  const double* h1 = kH1 + P.h1off;
 
-  const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
+  double T;
+  if constexpr (C::kStatic) T = ln.T[j];
+  else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   double s[H], bs[H], tinv;
-  mtg_scales<H, DIR>(T, P.deriv, s, bs, tinv, ln.flags);
+  mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, ln.flags);
 
   double val_l[D][H], val_r[D][H];
-  mtg_load_vals<C>(P, b, vl, ml, val_l);
-  mtg_load_vals<C>(P, b, vr, mr, val_r);
+  mtg_load_vals<C, DIR>(P, b, vl, ml, ln, val_l);
+  mtg_load_vals<C, DIR>(P, b, vr, mr, ln, val_r);
   // scaled fixed values
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
@@ -248,47 +338,66 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
     }
   }
 
-  // rhs of the left vertex and of the right vertex (fixed-value couplings)
+  // rhs of the left vertex and of the right vertex (fixed-value couplings).  Loop order: table
+  // entry outermost, dimensions innermost, so every scalar constant is consumed at once.
   double rv[D][H], rnext[D][H];
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
+  {
+    const double* hc = mtg_h1<C>(P);
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      rv[dm][p] = 0.0;
-      rnext[dm][p] = 0.0;
-      if (!((ml >> p) & 1)) {
-        double acc = 0.0;
+      double accl[D], accr[D];
 #pragma unroll
-        for (int q = 0; q < H; ++q) {
-          if ((ml >> q) & 1) acc = mtg_fma(h1[p * N + q], val_l[dm][q], acc);
-          if ((mr >> q) & 1) acc = mtg_fma(h1[p * N + H + q], val_r[dm][q], acc);
+      for (int dm = 0; dm < D; ++dm) { accl[dm] = 0.0; accr[dm] = 0.0; }
+#pragma unroll
+      for (int q = 0; q < H; ++q) {
+        if (!((ml >> p) & 1)) {
+          if ((ml >> q) & 1) {
+            const double c = hc[p * N + q];
+#pragma unroll
+            for (int dm = 0; dm < D; ++dm) accl[dm] = mtg_fma(c, val_l[dm][q], accl[dm]);
+          }
+          if ((mr >> q) & 1) {
+            const double c = hc[p * N + H + q];
+#pragma unroll
+            for (int dm = 0; dm < D; ++dm) accl[dm] = mtg_fma(c, val_r[dm][q], accl[dm]);
+          }
         }
-        rv[dm][p] = mtg_fma(-bs[p], acc, ln.rc[dm][p]);
+        if (!((mr >> p) & 1)) {
+          if ((mr >> q) & 1) {
+            const double c = hc[(H + p) * N + H + q];
+#pragma unroll
+            for (int dm = 0; dm < D; ++dm) accr[dm] = mtg_fma(c, val_r[dm][q], accr[dm]);
+          }
+          if ((ml >> q) & 1) {
+            const double c = hc[q * N + H + p];
+#pragma unroll
+            for (int dm = 0; dm < D; ++dm) accr[dm] = mtg_fma(c, val_l[dm][q], accr[dm]);
+          }
+        }
       }
-      if (!((mr >> p) & 1)) {
-        double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < H; ++q) {
-          if ((mr >> q) & 1) acc = mtg_fma(h1[(H + p) * N + H + q], val_r[dm][q], acc);
-          if ((ml >> q) & 1) acc = mtg_fma(h1[q * N + H + p], val_l[dm][q], acc);
-        }
-        rnext[dm][p] = -bs[p] * acc;
+      for (int dm = 0; dm < D; ++dm) {
+        rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[dm], ln.rc[dm][p]);
+        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -bs[p] * accr[dm];
       }
     }
   }
 
   // Dtilde_l = Sc + a_ll (free x free, lower), U = a_lr (free_l x free_r)
   double A[H][H], U[H][H], dinv[H];
+  {
+    const double* hc = mtg_h1<C>(P);
 #pragma unroll
-  for (int p = 0; p < H; ++p) {
-    dinv[p] = 0.0;
+    for (int p = 0; p < H; ++p) {
+      dinv[p] = 0.0;
 #pragma unroll
-    for (int q = 0; q < H; ++q) {
-      A[p][q] = 0.0;
-      U[p][q] = 0.0;
-      if (!((ml >> p) & 1)) {
-        if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(bs[p] * s[q], h1[p * N + q], ln.Sc[p][q]);
-        if (!((mr >> q) & 1)) U[p][q] = bs[p] * s[q] * h1[p * N + H + q];
+      for (int q = 0; q < H; ++q) {
+        A[p][q] = 0.0;
+        U[p][q] = 0.0;
+        if (!((ml >> p) & 1)) {
+          if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(bs[p] * s[q], hc[p * N + q], ln.Sc[p][q]);
+          if (!((mr >> q) & 1)) U[p][q] = bs[p] * s[q] * hc[p * N + H + q];
+        }
       }
     }
   }
@@ -320,13 +429,14 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
   }
 
   // carried onto the right vertex: Sc' = a_rr - U^T G,  rc' = rnext - U^T g
+  const double* hrr = mtg_h1<C>(P);
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       ln.Sc[p][q] = 0.0;
       if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) {
-        double acc = bs[p] * s[q] * h1[(H + p) * N + H + q];
+        double acc = bs[p] * s[q] * hrr[(H + p) * N + H + q];
 #pragma unroll
         for (int m = 0; m < H; ++m) {
           if (!((ml >> m) & 1)) acc = mtg_fma(-U[m][p], G[m][q], acc);
@@ -352,15 +462,15 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
 }
 
 // Coefficient recovery for one segment (impl/polynomial_optimization_linear_impl.h:274-280):
-// xS / xE = all h derivatives at the segment's start / end vertex.
-template <class C, bool WITH_COST>
+// xS / xE = all h derivatives at the segment's start / end vertex.  Table entries are the outer
+// loops and the D dimensions the inner one, so each scalar constant is consumed immediately.
+template <class C, int OUT>
 MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
                           const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D, N = C::N;
-  const double* ai = kAinvLo + P.ainvoff;   // [H][N]
   int dummy = 0;
   double s[H], bs[H], tinv;
-  mtg_scales<H, 1>(T, P.deriv, s, bs, tinv, dummy);
+  mtg_scales<H, 1>(T, mtg_deriv<C>(P), s, bs, tinv, dummy);
   double tp[H];                    // T^-(H+j)
   {
     double t = tinv;
@@ -379,46 +489,72 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
       invfact[p] = 1.0 / f;   // compile-time constant after unrolling
     }
   }
-  double cost = 0.0;
+  double dl[D][N], c[D][N], qs[D][N];
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
-    double dl[N];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      dl[p] = s[p] * xS[dm][p];
-      dl[H + p] = s[p] * xE[dm][p];
+      dl[dm][p] = s[p] * xS[dm][p];
+      dl[dm][H + p] = s[p] * xE[dm][p];
+      c[dm][p] = xS[dm][p] * invfact[p];
+      qs[dm][p] = dl[dm][p] * invfact[p];
     }
-    double c[N], qs[N];
-#pragma unroll
-    for (int p = 0; p < H; ++p) {
-      c[p] = xS[dm][p] * invfact[p];
-      qs[p] = dl[p] * invfact[p];
-    }
+  }
+  {
+    const double* ai = mtg_ainv<C>(P);   // [H][N]
 #pragma unroll
     for (int jj = 0; jj < H; ++jj) {
-      double acc = 0.0;
+      double acc[D];
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc = mtg_fma(ai[jj * N + k], dl[k], acc);
-      qs[H + jj] = acc;
-      c[H + jj] = acc * tp[jj];
-    }
-    double* out = P.coeffs + (((long long)b * P.K + seg) * P.Dtot + (P.dim0 + dm)) * N;
+      for (int dm = 0; dm < D; ++dm) acc[dm] = 0.0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = c[k];
-    if constexpr (WITH_COST) {
-      // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140)
-      // Q(1) is symmetric and zero below row/column d: static full loops, no runtime indexing.
-      const double* q1 = kQ1 + P.h1off;
-      double acc = 0.0;
+      for (int k = 0; k < N; ++k) {
+        const double a = ai[jj * N + k];
 #pragma unroll
-      for (int r = 0; r < N; ++r) {
-        double row = 0.5 * q1[r * N + r] * qs[r];
-#pragma unroll
-        for (int cc = 0; cc < r; ++cc) row = mtg_fma(q1[r * N + cc], qs[cc], row);
-        acc = mtg_fma(row, qs[r], acc);
+        for (int dm = 0; dm < D; ++dm) acc[dm] = mtg_fma(a, dl[dm][k], acc[dm]);
       }
-      cost = mtg_fma(bs[0], acc, cost);
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) {
+        qs[dm][H + jj] = acc[dm];
+        c[dm][H + jj] = acc[dm] * tp[jj];
+      }
     }
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+    double* out;
+    if constexpr (C::kStatic) out = P.coeffs + (((long long)b * C::KT + seg) * D + dm) * N;
+    else out = P.coeffs + (((long long)b * P.K + seg) * P.Dtot + (P.dim0 + dm)) * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = c[dm][k];
+  }
+  double cost = 0.0;
+  if constexpr ((OUT & 1) != 0) {
+    // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140).
+    // Q(1) is symmetric and zero below row/column d: static full loops, no runtime indexing.
+    const double* q1 = mtg_q1<C>(P);
+    double acc[D];
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) acc[dm] = 0.0;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      double row[D];
+      {
+        const double qd = 0.5 * q1[r * N + r];
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) row[dm] = qd * qs[dm][r];
+      }
+#pragma unroll
+      for (int cc = 0; cc < r; ++cc) {
+        const double qv = q1[r * N + cc];
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) row[dm] = mtg_fma(qv, qs[dm][cc], row[dm]);
+      }
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) acc[dm] = mtg_fma(row[dm], qs[dm][r], acc[dm]);
+    }
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) cost = mtg_fma(bs[0], acc[dm], cost);
   }
   return cost;
 }
@@ -454,7 +590,7 @@ MTG_HD void mtg_pack_mid(const MtgLane<C>& ln, int mm, double* buf, int stride) 
 }
 
 // merge with the other direction's contribution, solve the middle vertex -> xm (all h slots)
-template <class C>
+template <class C, int DIR>
 MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int vm, int mm,
                           const double* other, int stride, double (&xm)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D;
@@ -476,7 +612,7 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
       ++slot;
     }
   }
-  mtg_load_vals<C>(P, b, vm, mm, xm);
+  mtg_load_vals<C, DIR>(P, b, vm, mm, ln, xm);
   double r[D][H];
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
@@ -499,8 +635,9 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
   }
 }
 
-template <class C>
+template <class C, int OUT>
 MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, const double (&x)[C::D][C::H]) {
+  if constexpr ((OUT & 2) == 0) return;
   if (P.dfree == nullptr) return;
   const int off = mtg_offP<C>(P, v);
 #pragma unroll
@@ -516,15 +653,16 @@ MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, con
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
-template <class C, int DIR, bool WITH_COST>
-MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const double (&G)[C::H][C::H],
-                           const double (&g)[C::D][C::H], double (&xr)[C::D][C::H]) {
+template <class C, int DIR, int OUT>
+MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane<C>& ln,
+                           const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
+                           double (&xr)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
   const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
   double xl[D][H];
-  mtg_load_vals<C>(P, b, vl, ml, xl);
+  mtg_load_vals<C, DIR>(P, b, vl, ml, ln, xl);
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
@@ -538,11 +676,13 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const double 
       xl[dm][p] = acc;
     }
   }
-  mtg_store_free<C>(P, b, vl, ml, xl);
-  const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
+  mtg_store_free<C, OUT>(P, b, vl, ml, xl);
+  double T;
+  if constexpr (C::kStatic) T = ln.T[j];
+  else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   double cost;
-  if (DIR > 0) cost = mtg_recover<C, WITH_COST>(P, b, seg, T, xl, xr);
-  else cost = mtg_recover<C, WITH_COST>(P, b, seg, T, xr, xl);
+  if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr);
+  else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl);
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
@@ -557,6 +697,7 @@ template <class C, int DIR>
 MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, double* wsl) {
   constexpr int H = C::H, D = C::D;
   ln.flags = 0;
+  mtg_preload<C, DIR>(P, b, ln);
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
@@ -593,7 +734,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
   }
 }
 
-template <class C, int DIR, bool WITH_COST>
+template <class C, int DIR, int OUT>
 MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
                             const double* other, int stride) {
   constexpr int H = C::H, D = C::D;
@@ -601,13 +742,13 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   const int vm = (K + 1) / 2;
   const int mm = mtg_mask<C>(P, vm);
   double xr[D][H];
-  mtg_solve_mid<C>(P, b, ln, vm, mm, other, stride, xr);
-  if (DIR > 0) mtg_store_free<C>(P, b, vm, mm, xr);
+  mtg_solve_mid<C, DIR>(P, b, ln, vm, mm, other, stride, xr);
+  if (DIR > 0) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
-    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, WITH_COST>(P, b, j, ln.G[j], ln.g[j], xr);
+    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr);
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
     constexpr int E = H * H + D * H;
@@ -624,15 +765,17 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 #pragma unroll
         for (int p = 0; p < H; ++p) g[dm][p] = w[(long long)(H * H + dm * H + p) * P.ws_stride];
       }
-      cost += mtg_bwd_step<C, DIR, WITH_COST>(P, b, j, G, g, xr);
+      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, G, g, xr);
     }
   }
-  if constexpr (WITH_COST) {
+  if constexpr ((OUT & 1) != 0) {
+    if (P.cost != nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicAdd(P.cost + b, cost);
+      atomicAdd(P.cost + b, cost);
 #else
-    P.cost[b] += cost;
+      P.cost[b] += cost;
 #endif
+    }
   }
   if (ln.flags) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -644,16 +787,18 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 }
 
 // ---- setFreeConstraints path: coefficients from given d_free (no solve) ------------------
-template <class C, bool WITH_COST>
+template <class C, int OUT>
 MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
   constexpr int H = C::H, D = C::D;
   const int K = P.K;
   double xa[D][H], xb[D][H];
   double cost = 0.0;
   int flags = 0;
+  static_assert(!C::kStatic, "update path is generic only");
+  MtgLane<C> dummy_lane;
   auto load_vertex = [&](int v, double (&x)[D][H]) {
     const int m = mtg_mask<C>(P, v);
-    mtg_load_vals<C>(P, b, v, m, x);
+    mtg_load_vals<C, 1>(P, b, v, m, dummy_lane, x);
     const int off = mtg_offP<C>(P, v);
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
@@ -670,14 +815,14 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
     load_vertex(i + 1, xb);
     const double T = P.times[b * P.ts_b + (long long)i * P.ts_k];
     if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
-    cost += mtg_recover<C, WITH_COST>(P, b, i, T, xa, xb);
+    cost += mtg_recover<C, OUT>(P, b, i, T, xa, xb);
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
       for (int p = 0; p < H; ++p) xa[dm][p] = xb[dm][p];
     }
   }
-  if constexpr (WITH_COST) {
+  if constexpr ((OUT & 1) != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(P.cost + b, cost);
 #else

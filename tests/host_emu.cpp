@@ -10,7 +10,7 @@
 
 namespace {
 
-template <class C, bool WC>
+template <class C, int WC>
 void emu_solve(MtgParams P) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
@@ -32,7 +32,7 @@ void emu_solve(MtgParams P) {
   }
 }
 
-template <class C, bool WC>
+template <class C, int WC>
 void emu_update(MtgParams P) {
   for (long long b = 0; b < P.B; ++b) mtg_lane_update<C, WC>(P, b);
 }
@@ -44,8 +44,8 @@ template <int H>
 Fn pick_h(int d, bool wc, bool upd) {
 #define CASE(DD)                                                                         \
   case DD:                                                                               \
-    if (upd) return wc ? (Fn)emu_update<GenericCfg<H, DD>, true> : (Fn)emu_update<GenericCfg<H, DD>, false>; \
-    return wc ? (Fn)emu_solve<GenericCfg<H, DD>, true> : (Fn)emu_solve<GenericCfg<H, DD>, false>;
+    if (upd) return wc ? (Fn)emu_update<GenericCfg<H, DD>, 1> : (Fn)emu_update<GenericCfg<H, DD>, 0>; \
+    return wc ? (Fn)emu_solve<GenericCfg<H, DD>, 3> : (Fn)emu_solve<GenericCfg<H, DD>, 0>;
   switch (d) { CASE(1) CASE(2) CASE(3) CASE(4) }
 #undef CASE
   return nullptr;
@@ -62,9 +62,9 @@ Fn pick(int h, int d, bool wc, bool upd) {
   return nullptr;
 }
 
-struct StaticEntry { int h, d, k, ms, mi, me; Fn fn[2]; };
-#define MTG_STATIC(H, D, K, MS, MI, ME) \
-  {H, D, K, MS, MI, ME, {(Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME>, false>, (Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME>, true>}},
+struct StaticEntry { int h, d, k, ms, mi, me, dv; Fn fn[2]; };
+#define MTG_STATIC(H, D, K, MS, MI, ME, DV) \
+  {H, D, K, MS, MI, ME, DV, {(Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>, (Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>}},
 const StaticEntry kStatic[] = {
 #include "../mav_trajectory_generation_amd/csrc/mtg_variants.inc"
 };
@@ -98,10 +98,10 @@ extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long
   P.ainvoff = kAinvLoOff[H];
   P.h1off = kH1Off[H][deriv];
   if (cost) for (long long b = 0; b < B; ++b) cost[b] = 0.0;
-  const bool wc = cost != nullptr;
+  const bool wc = cost != nullptr || (mode != 2 && n_free > 0 && dfree != nullptr);
   if (mode == 1) {
     for (const StaticEntry& e : kStatic) {
-      if (e.h != H || e.d != D || e.k != K) continue;
+      if (e.h != H || e.d != D || e.k != K || e.dv != deriv) continue;
       bool ok = mask[0] == e.ms && mask[K] == e.me;
       for (int v = 1; v < K && ok; ++v) ok = mask[v] == e.mi;
       if (!ok) continue;
