@@ -5,7 +5,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmtg_hip.so")
+# MTG_HIP_LIB selects an alternative build of the same HIP library (A/B kernel experiments); still HIP-only.
+LIB_PATH = os.environ.get("MTG_HIP_LIB") or os.path.join(_HERE, "csrc", "libmtg_hip.so")
 
 c_double_p = ctypes.c_void_p  # raw device or host addresses
 

@@ -21,48 +21,9 @@
 #include <vector>
 
 #include "../../include/mtg_hip.h"
-#include "mtg_lane.h"
+#include "mtg_kernels.h"
 
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: direction B
-
-template <class C, int OUT>
-__global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntiles) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int dir = threadIdx.x >> 6;  // wave-uniform
-  const int K = mtg_nseg<C>(P);
-  const int vm = (K + 1) / 2;
-  const int mm = mtg_mask<C>(P, vm);
-  const int nslots = mtg_mid_slots<C>(mm);
-  double* mine = lds + (size_t)dir * nslots * kWave + lane;
-  const double* other = lds + (size_t)(1 - dir) * nslots * kWave + lane;
-  double* wsl = P.ws ? P.ws + ((long long)blockIdx.x * kBlock + threadIdx.x) : nullptr;
-  MtgLane<C> ln;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b = (long long)tile * kWave + lane;
-    const bool active = b < P.B;
-    if (active) {
-      if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl);
-      else mtg_lane_forward<C, -1>(P, b, ln, wsl);
-      mtg_pack_mid<C>(ln, mm, mine, kWave);
-    }
-    __syncthreads();
-    if (active) {
-      if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave);
-      else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave);
-    }
-    __syncthreads();
-  }
-}
-
-template <class C, int OUT>
-__global__ __launch_bounds__(256) void mtg_update_kernel(MtgParams P) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < P.B) mtg_lane_update<C, OUT>(P, b);
-}
 
 __global__ void mtg_rcp_selftest_kernel(int n, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,92 +50,35 @@ __global__ void mtg_rcp_selftest_kernel(int n, double* out) {
   if (threadIdx.x == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(sm[0]));
 }
 
-// ---------------------------------------------------------------------------------------------
-using SolveFn = void (*)(MtgParams, int);
-using UpdateFn = void (*)(MtgParams);
-
-template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
-
-template <int H, int D>
-SolveFn generic_solve(bool with_cost) {
-  // generic kernels: OUT=3 handles cost / d_free behind run-time null checks
-  return with_cost ? (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, 3>
-                   : (SolveFn)mtg_solve_kernel<GenericCfg<H, D>, 0>;
-}
-template <int H, int D>
-UpdateFn generic_update(bool with_cost) {
-  return with_cost ? (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, 1>
-                   : (UpdateFn)mtg_update_kernel<GenericCfg<H, D>, 0>;
-}
-
-template <int H>
-SolveFn generic_solve_h(int d, bool wc) {
-  switch (d) {
-    case 1: return generic_solve<H, 1>(wc);
-    case 2: return generic_solve<H, 2>(wc);
-    case 3: return generic_solve<H, 3>(wc);
-    case 4: return generic_solve<H, 4>(wc);
-  }
-  return nullptr;
-}
-template <int H>
-UpdateFn generic_update_h(int d, bool wc) {
-  switch (d) {
-    case 1: return generic_update<H, 1>(wc);
-    case 2: return generic_update<H, 2>(wc);
-    case 3: return generic_update<H, 3>(wc);
-    case 4: return generic_update<H, 4>(wc);
-  }
-  return nullptr;
-}
-SolveFn pick_generic_solve(int h, int d, bool wc) {
-  switch (h) {
-    case 1: return generic_solve_h<1>(d, wc);
-    case 2: return generic_solve_h<2>(d, wc);
-    case 3: return generic_solve_h<3>(d, wc);
-    case 4: return generic_solve_h<4>(d, wc);
-    case 5: return generic_solve_h<5>(d, wc);
-    case 6: return generic_solve_h<6>(d, wc);
-  }
-  return nullptr;
-}
-UpdateFn pick_generic_update(int h, int d, bool wc) {
-  switch (h) {
-    case 1: return generic_update_h<1>(d, wc);
-    case 2: return generic_update_h<2>(d, wc);
-    case 3: return generic_update_h<3>(d, wc);
-    case 4: return generic_update_h<4>(d, wc);
-    case 5: return generic_update_h<5>(d, wc);
-    case 6: return generic_update_h<6>(d, wc);
-  }
-  return nullptr;
-}
-
-// Specialised register-resident variants: (H, D, K, start mask, interior mask, end mask).
-struct StaticEntry {
-  int h, d, k, ms, mi, me, dv;
-  SolveFn fn[2];
-};
-#define MTG_STATIC(H, D, K, MS, MI, ME, DV)                                                     \
-  {H, D, K, MS, MI, ME, DV,                                                                     \
-   {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,                              \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>}},
-const StaticEntry kStaticTable[] = {
-#include "mtg_variants.inc"
-};
-#undef MTG_STATIC
-
-const StaticEntry* find_static(int h, int d, int k, int deriv, const std::vector<int>& mask) {
-  for (const StaticEntry& e : kStaticTable) {
-    if (e.h != h || e.d != d || e.k != k || e.dv != deriv) continue;
-    bool ok = mask[0] == e.ms && mask[k] == e.me;
-    for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
-    if (ok) return &e;
-  }
-  return nullptr;
-}
 
 }  // namespace
+
+#define MTG_DECL(H) SolveFn mtg_pick_generic_solve_h##H(int, bool); UpdateFn mtg_pick_generic_update_h##H(int, bool);
+MTG_DECL(1) MTG_DECL(2) MTG_DECL(3) MTG_DECL(4) MTG_DECL(5) MTG_DECL(6)
+#undef MTG_DECL
+
+SolveFn mtg_pick_generic_solve(int h, int d, bool extra) {
+  switch (h) {
+    case 1: return mtg_pick_generic_solve_h1(d, extra);
+    case 2: return mtg_pick_generic_solve_h2(d, extra);
+    case 3: return mtg_pick_generic_solve_h3(d, extra);
+    case 4: return mtg_pick_generic_solve_h4(d, extra);
+    case 5: return mtg_pick_generic_solve_h5(d, extra);
+    case 6: return mtg_pick_generic_solve_h6(d, extra);
+  }
+  return nullptr;
+}
+UpdateFn mtg_pick_generic_update(int h, int d, bool wc) {
+  switch (h) {
+    case 1: return mtg_pick_generic_update_h1(d, wc);
+    case 2: return mtg_pick_generic_update_h2(d, wc);
+    case 3: return mtg_pick_generic_update_h3(d, wc);
+    case 4: return mtg_pick_generic_update_h4(d, wc);
+    case 5: return mtg_pick_generic_update_h5(d, wc);
+    case 6: return mtg_pick_generic_update_h6(d, wc);
+  }
+  return nullptr;
+}
 
 // ---------------------------------------------------------------------------------------------
 struct mtg_context {
@@ -203,7 +107,7 @@ struct mtg_plan {
   std::vector<int> offF, offP;      // [K+2]
   int n_fixed = 0, n_free = 0;
   int* d_tables = nullptr;          // vmask | offF | offP
-  const StaticEntry* fast = nullptr;
+  const MtgStaticEntry* fast = nullptr;
   double* ws = nullptr;
   size_t ws_bytes = 0;
   // staging for MTG_FLAG_HOST_POINTERS
@@ -349,7 +253,7 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   }
   p->n_fixed = p->offF[K + 1];
   p->n_free = p->offP[K + 1];
-  p->fast = find_static(p->H, D, K, d, p->mask);
+  p->fast = mtg_find_static(p->H, D, K, d, p->mask.data());
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
   tab.insert(tab.end(), p->offF.begin(), p->offF.end());
@@ -405,6 +309,8 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only) {
   if (!p || !L || !times || !coeffs || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = p->ctx;
+  if (!(flags & MTG_FLAG_HOST_POINTERS) && (reinterpret_cast<uintptr_t>(coeffs) & 15))
+    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");
   if (p->n_fixed > 0 && !d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_fixed is null");
   if (update_only && p->n_free > 0 && !d_free) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_free is null");
   if (batch == 0) return MTG_OK;
@@ -448,7 +354,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   if (update_only) {
     for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
       const int dc = std::min(4, p->D - dim0);
-      UpdateFn fn = pick_generic_update(p->H, dc, wc);
+      UpdateFn fn = mtg_pick_generic_update(p->H, dc, wc);
       if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no update kernel");
       MtgParams Q = P;
       Q.dim0 = dim0;
@@ -469,7 +375,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         fn = p->fast->fn[wc ? 1 : 0];
         grid = std::min(ntiles, ctx->n_cu * 8);
       } else {
-        fn = pick_generic_solve(p->H, dc, wc);
+        fn = mtg_pick_generic_solve(p->H, dc, wc);
         if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
         grid = std::min(ntiles, ctx->n_cu * 4);
         const int kc = (p->K + 1) / 2;
@@ -480,7 +386,9 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         Q.ws = p->ws;
         Q.ws_stride = (long long)grid * kBlock;
       }
-      const size_t lds = (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
+      // LDS: two coefficient staging buffers (64 rows x odd number of 16-byte chunks) + two exchange buffers
+      const size_t stage = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+      const size_t lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, st, Q, ntiles);
       LaunchRecord r;
       r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.lds = lds;

@@ -95,6 +95,17 @@ MTG_HD int mtg_launder(int off) {
   return off;
 }
 
+// 16-byte store of two doubles (ds_write_b128 / global_store_dwordx4 on the device)
+MTG_HD void mtg_store2(double* p, double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double mtg_d2 __attribute__((ext_vector_type(2)));
+  mtg_d2 v; v.x = a; v.y = b;
+  *reinterpret_cast<mtg_d2*>(p) = v;
+#else
+  p[0] = a; p[1] = b;
+#endif
+}
+
 MTG_HD int mtg_popc(int x) {
 #if defined(__HIPCC__)
   return __builtin_popcount(x);
@@ -464,9 +475,25 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
 // Coefficient recovery for one segment (impl/polynomial_optimization_linear_impl.h:274-280):
 // xS / xE = all h derivatives at the segment's start / end vertex.  Table entries are the outer
 // loops and the D dimensions the inner one, so each scalar constant is consumed immediately.
-template <class C, int OUT>
+// Output policy that stores one lane's D*N coefficients of a segment straight to global memory
+// (host emulation, and the one-lane-per-trajectory update kernel).  The solve kernels use the
+// LDS-staged, coalesced policy MtgLdsOut in mtg_kernels.h instead.
+template <class C>
+struct MtgDirectOut {
+  double buf[C::D * C::N];
+  long long b;
+  MTG_HD double* row() { return buf; }
+  MTG_HD void flush(const MtgParams& P, int seg) {
+    const int K = mtg_nseg<C>(P);
+    double* out = P.coeffs + (((long long)b * K + seg) * P.Dtot + P.dim0) * C::N;
+#pragma unroll
+    for (int i = 0; i < C::D * C::N; ++i) out[i] = buf[i];
+  }
+};
+
+template <class C, int OUT, class IO>
 MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
-                          const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H]) {
+                          const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H], IO& io) {
   constexpr int H = C::H, D = C::D, N = C::N;
   int dummy = 0;
   double s[H], bs[H], tinv;
@@ -489,19 +516,28 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
       invfact[p] = 1.0 / f;   // compile-time constant after unrolling
     }
   }
-  double dl[D][N], c[D][N], qs[D][N];
+  double dl[D][N], qs[D][N];
+  double* row = io.row();
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
+    double clo[H + 1];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
       dl[dm][p] = s[p] * xS[dm][p];
       dl[dm][H + p] = s[p] * xE[dm][p];
-      c[dm][p] = xS[dm][p] * invfact[p];
+      clo[p] = xS[dm][p] * invfact[p];
       qs[dm][p] = dl[dm][p] * invfact[p];
     }
+    // low half of the coefficients: c_p = d_p / p!  (pairs that lie entirely in the low half)
+#pragma unroll
+    for (int p = 0; p + 1 < H; p += 2) mtg_store2(row + dm * N + p, clo[p], clo[p + 1]);
+    if (H & 1) qs[dm][N - 1] = clo[H - 1];   // odd h: c_(h-1) pairs with c_h below (parked in an unused slot)
   }
   {
     const double* ai = mtg_ainv<C>(P);   // [H][N]
+    double prev[D];
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) prev[dm] = (H & 1) ? qs[dm][N - 1] : 0.0;
 #pragma unroll
     for (int jj = 0; jj < H; ++jj) {
       double acc[D];
@@ -516,18 +552,14 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
         qs[dm][H + jj] = acc[dm];
-        c[dm][H + jj] = acc[dm] * tp[jj];
+        const double cj = acc[dm] * tp[jj];
+        // coefficient index H + jj; store in aligned pairs (even index first)
+        if (((H + jj) & 1) != 0) mtg_store2(row + dm * N + H + jj - 1, prev[dm], cj);
+        else prev[dm] = cj;
       }
     }
   }
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-    double* out;
-    if constexpr (C::kStatic) out = P.coeffs + (((long long)b * C::KT + seg) * D + dm) * N;
-    else out = P.coeffs + (((long long)b * P.K + seg) * P.Dtot + (P.dim0 + dm)) * N;
-#pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = c[dm][k];
-  }
+  io.flush(P, seg);
   double cost = 0.0;
   if constexpr ((OUT & 1) != 0) {
     // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140).
@@ -653,10 +685,10 @@ MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, con
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
-template <class C, int DIR, int OUT>
+template <class C, int DIR, int OUT, class IO>
 MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane<C>& ln,
                            const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
-                           double (&xr)[C::D][C::H]) {
+                           double (&xr)[C::D][C::H], IO& io, bool active) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
@@ -676,13 +708,13 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane
       xl[dm][p] = acc;
     }
   }
-  mtg_store_free<C, OUT>(P, b, vl, ml, xl);
+  if (active) mtg_store_free<C, OUT>(P, b, vl, ml, xl);
   double T;
   if constexpr (C::kStatic) T = ln.T[j];
   else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   double cost;
-  if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr);
-  else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl);
+  if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr, io);
+  else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl, io);
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
@@ -734,21 +766,23 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
   }
 }
 
-template <class C, int DIR, int OUT>
+// `active` = this lane owns a real trajectory (tail tiles run clamped duplicates whose outputs
+// are suppressed; every lane still takes part in the cooperative coefficient flush).
+template <class C, int DIR, int OUT, class IO>
 MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
-                            const double* other, int stride) {
+                            const double* other, int stride, IO& io, bool active) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
   const int mm = mtg_mask<C>(P, vm);
   double xr[D][H];
   mtg_solve_mid<C, DIR>(P, b, ln, vm, mm, other, stride, xr);
-  if (DIR > 0) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
+  if (DIR > 0 && active) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
-    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr);
+    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr, io, active);
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
     constexpr int E = H * H + D * H;
@@ -765,11 +799,11 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 #pragma unroll
         for (int p = 0; p < H; ++p) g[dm][p] = w[(long long)(H * H + dm * H + p) * P.ws_stride];
       }
-      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, G, g, xr);
+      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, G, g, xr, io, active);
     }
   }
   if constexpr ((OUT & 1) != 0) {
-    if (P.cost != nullptr) {
+    if (P.cost != nullptr && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(P.cost + b, cost);
 #else
@@ -777,7 +811,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 #endif
     }
   }
-  if (ln.flags) {
+  if (ln.flags && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(P.status, ln.flags);
 #else
@@ -796,6 +830,8 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
   int flags = 0;
   static_assert(!C::kStatic, "update path is generic only");
   MtgLane<C> dummy_lane;
+  MtgDirectOut<C> io;
+  io.b = b;
   auto load_vertex = [&](int v, double (&x)[D][H]) {
     const int m = mtg_mask<C>(P, v);
     mtg_load_vals<C, 1>(P, b, v, m, dummy_lane, x);
@@ -815,7 +851,7 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
     load_vertex(i + 1, xb);
     const double T = P.times[b * P.ts_b + (long long)i * P.ts_k];
     if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
-    cost += mtg_recover<C, OUT>(P, b, i, T, xa, xb);
+    cost += mtg_recover<C, OUT>(P, b, i, T, xa, xb, io);
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
 #pragma unroll

@@ -27,8 +27,10 @@ void emu_solve(MtgParams P) {
     mtg_lane_forward<C, -1>(P, b, lb, wsb.data());
     mtg_pack_mid<C>(la, mm, bufa.data(), 1);
     mtg_pack_mid<C>(lb, mm, bufb.data(), 1);
-    mtg_lane_finish<C, 1, WC>(P, b, la, wsa.data(), bufb.data(), 1);
-    mtg_lane_finish<C, -1, WC>(P, b, lb, wsb.data(), bufa.data(), 1);
+    MtgDirectOut<C> io;
+    io.b = b;
+    mtg_lane_finish<C, 1, WC>(P, b, la, wsa.data(), bufb.data(), 1, io, true);
+    mtg_lane_finish<C, -1, WC>(P, b, lb, wsb.data(), bufa.data(), 1, io, true);
   }
 }
 
