@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=10_000, help="trajectories per step per GPU (BASELINE configs[1])")
     ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
+    ap.add_argument("--dims", default="auto", choices=["auto", "fused", "split"], help="kernel launch geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time the 125k / 1M per-launch batches")
     args = ap.parse_args()
@@ -85,11 +86,11 @@ def main():
         t, f = m.random_waypoint_batch(B, K, D, N, masks, seed=1234 + rank, device=dev, layout=args.layout)
         coeffs = torch.empty((B, K, D, N), dtype=torch.float64, device=dev)
         for _ in range(args.warmup):
-            plan.solve(t, f, layout=args.layout, coeffs=coeffs)
+            plan.solve(t, f, layout=args.layout, coeffs=coeffs, dims=args.dims)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            plan.solve(t, f, layout=args.layout, coeffs=coeffs)
+            plan.solve(t, f, layout=args.layout, coeffs=coeffs, dims=args.dims)
         barrier()
         dt = time.perf_counter() - t0
         ctx.sync()  # raises if any trajectory flagged bad time / singular
@@ -102,7 +103,7 @@ def main():
             for big in (125_000, 1_000_000):
                 tb, fb = m.random_waypoint_batch(big, K, D, N, masks, seed=99, device=dev, layout=args.layout)
                 cb = torch.empty((big, K, D, N), dtype=torch.float64, device=dev)
-                plan.solve(tb, fb, layout=args.layout, coeffs=cb)
+                plan.solve(tb, fb, layout=args.layout, coeffs=cb, dims=args.dims)
                 torch.cuda.synchronize()
                 us = plan.time_last_solve(20)
                 extra[f"batch_{big}"] = {"kernel_us": us, "traj_per_s": big / us * 1e6,

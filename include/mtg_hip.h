@@ -79,7 +79,10 @@ typedef struct mtg_layout {
 
 enum {
   MTG_FLAG_HOST_POINTERS = 1u << 0, /* all buffers are host memory: the library stages them  */
-  MTG_FLAG_GENERIC_KERNEL = 1u << 1 /* force the generic kernel (tests / A-B measurements)   */
+  MTG_FLAG_GENERIC_KERNEL = 1u << 1, /* force the generic kernel (tests / A-B measurements)  */
+  MTG_FLAG_FUSED_DIMS = 1u << 2,     /* all D dimensions in one workgroup (large batches)     */
+  MTG_FLAG_SPLIT_DIMS = 1u << 3      /* one dimension group per workgroup (small batches);    */
+                                     /* default: chosen from the batch size                   */
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -98,6 +101,10 @@ int mtg_plan_destroy(mtg_plan* plan);
 int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
 void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);
+
+/* Optional: caller-owned scratch for the generic kernels' back-substitution workspace (no allocation inside
+ * mtg_solve_linear then, e.g. for graph capture).  bytes == 0 restores library-managed scratch.               */
+int mtg_plan_set_workspace(mtg_plan* plan, void* device_ptr, size_t bytes);
 
 /* ---- the hot path -------------------------------------------------------------------- */
 /* Replaces updateSegmentTimes() + solveLinear() (LINH:101,108; LIN:286-305, :339-379,

@@ -38,6 +38,7 @@ EXPORTS = {
     "mtg_plan_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]),
     "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_layout_soa": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
+    "mtg_plan_set_workspace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mtg_solve_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
@@ -48,6 +49,8 @@ EXPORTS = {
 
 FLAG_HOST_POINTERS = 1
 FLAG_GENERIC_KERNEL = 2
+FLAG_FUSED_DIMS = 4
+FLAG_SPLIT_DIMS = 8
 
 _lib = None
 

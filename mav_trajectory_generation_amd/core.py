@@ -118,7 +118,7 @@ class Plan:
         return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
-              coeffs=None, d_free=None, cost=None, generic: bool = False):
+              coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto"):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost)."""
         import torch
@@ -135,6 +135,7 @@ class Plan:
             cost = torch.empty((batch,), dtype=torch.float64, device=dev)
         lay = self.layout(batch, layout)
         flags = L.FLAG_GENERIC_KERNEL if generic else 0
+        flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS}[dims]
         cur = self.ctx._enter()
         rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), self._ptr(times), self._ptr(d_fixed),
                                        self._ptr(coeffs), self._ptr(d_free), self._ptr(cost), flags)

@@ -96,7 +96,7 @@ struct LaunchRecord {
   bool valid = false;
   SolveFn fn = nullptr;
   MtgParams params;
-  int ntiles = 0, grid = 0;
+  int ntiles = 0, grid = 0, gridy = 1;
   size_t lds = 0;
 };
 
@@ -107,9 +107,12 @@ struct mtg_plan {
   std::vector<int> offF, offP;      // [K+2]
   int n_fixed = 0, n_free = 0;
   int* d_tables = nullptr;          // vmask | offF | offP
-  const MtgStaticEntry* fast = nullptr;
+  const MtgStaticEntry* fast = nullptr;        // all dimensions in one workgroup
+  const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   double* ws = nullptr;
   size_t ws_bytes = 0;
+  double* user_ws = nullptr;       // caller-owned workspace (mtg_plan_set_workspace)
+  size_t user_ws_bytes = 0;
   // staging for MTG_FLAG_HOST_POINTERS
   double* stage = nullptr;
   size_t stage_bytes = 0;
@@ -254,6 +257,9 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   p->n_fixed = p->offF[K + 1];
   p->n_free = p->offP[K + 1];
   p->fast = mtg_find_static(p->H, D, K, d, p->mask.data());
+  for (int dg = 1; dg < D && !p->fast_split; ++dg) {
+    if (D % dg == 0) p->fast_split = mtg_find_static(p->H, dg, K, d, p->mask.data());
+  }
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
   tab.insert(tab.end(), p->offF.begin(), p->offF.end());
@@ -283,7 +289,7 @@ int mtg_plan_get_info(const mtg_plan* p, mtg_plan_info* out) {
   out->n_all = p->N * p->K;
   out->n_fixed = p->n_fixed;
   out->n_free = p->n_free;
-  out->kernel_variant = p->fast ? 1 : 0;
+  out->kernel_variant = p->fast ? 1 : (p->fast_split ? 2 : 0);
   out->algorithmic_bytes_per_trajectory = 8ll * (p->K + (int64_t)p->D * p->n_fixed + (int64_t)p->K * p->D * p->N);
   return MTG_OK;
 }
@@ -362,18 +368,27 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, Q);
     }
   } else {
-    const bool use_fast = p->fast && !(flags & MTG_FLAG_GENERIC_KERNEL);
+    // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
+    // dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.
+    const MtgStaticEntry* var = nullptr;
+    if (!(flags & MTG_FLAG_GENERIC_KERNEL)) {
+      const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) ||
+                              (!(flags & MTG_FLAG_FUSED_DIMS) && ntiles < 4 * ctx->n_cu);
+      var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
+    }
     const int vm = (p->K + 1) / 2;
     const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
     for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
-      const int dc = use_fast ? p->D : std::min(4, p->D - dim0);
+      const int dc = var ? var->d : std::min(4, p->D - dim0);
+      const int ngroups = var ? p->D / var->d : 1;
       MtgParams Q = P;
       Q.dim0 = dim0;
       SolveFn fn;
       int grid;
-      if (use_fast) {
-        fn = p->fast->fn[wc ? 1 : 0];
-        grid = std::min(ntiles, ctx->n_cu * 8);
+      if (var) {
+        Q.ws = p->user_ws;   // unused by the specialised kernels (measurement builds park timestamps here)
+        fn = var->fn[wc ? 1 : 0];
+        grid = std::min(ntiles, std::max(1, ctx->n_cu * 8 / ngroups));
       } else {
         fn = mtg_pick_generic_solve(p->H, dc, wc);
         if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
@@ -381,19 +396,24 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         const int kc = (p->K + 1) / 2;
         const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
         const size_t need = (size_t)kc * E * (size_t)grid * kBlock * sizeof(double);
-        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
-        if (rc != MTG_OK) return rc;
-        Q.ws = p->ws;
+        if (p->user_ws) {
+          if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
+          Q.ws = p->user_ws;
+        } else {
+          int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+          if (rc != MTG_OK) return rc;
+          Q.ws = p->ws;
+        }
         Q.ws_stride = (long long)grid * kBlock;
       }
       // LDS: two coefficient staging buffers (64 rows x odd number of 16-byte chunks) + two exchange buffers
       const size_t stage = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
       const size_t lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, st, Q, ntiles);
+      hipLaunchKernelGGL(fn, dim3(grid, ngroups), dim3(kBlock), lds, st, Q, ntiles);
       LaunchRecord r;
-      r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.lds = lds;
+      r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.gridy = ngroups; r.lds = lds;
       p->last.push_back(r);
-      if (use_fast) break;
+      if (var) break;
     }
   }
   MTG_HIP_TRY(ctx, hipGetLastError());
@@ -404,6 +424,14 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
     MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
   }
+  return MTG_OK;
+}
+
+int mtg_plan_set_workspace(mtg_plan* p, void* device_ptr, size_t bytes) {
+  if (!p) return MTG_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(p->ctx->mu);
+  p->user_ws = bytes ? static_cast<double*>(device_ptr) : nullptr;
+  p->user_ws_bytes = bytes;
   return MTG_OK;
 }
 
@@ -431,7 +459,7 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   for (int i = 0; i < iters; ++i) {
     for (const LaunchRecord& r : p->last) {
       if (r.params.cost) hipMemsetAsync(r.params.cost, 0, r.params.B * sizeof(double), ctx->stream);
-      hipLaunchKernelGGL(r.fn, dim3(r.grid), dim3(kBlock), r.lds, ctx->stream, r.params, r.ntiles);
+      hipLaunchKernelGGL(r.fn, dim3(r.grid, r.gridy), dim3(kBlock), r.lds, ctx->stream, r.params, r.ntiles);
     }
   }
   MTG_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));

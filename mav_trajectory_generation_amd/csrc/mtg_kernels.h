@@ -13,52 +13,81 @@ constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: dir
 // of 16-byte units => conflict-free), then the whole wave streams the buffer out: chunk o of 16 bytes
 // belongs to trajectory t = o / Q at offset r = o % Q of that trajectory's contiguous D*N*8-byte piece
 // coeffs[b0 + t][seg][dim0 .. dim0+D)[0..N), so a store instruction covers 64 consecutive chunks
-// (~9 cache lines for the 240-byte pieces of N=10, D=3) instead of 64 lines with row-per-lane stores.
-// Measured on MI355X at B = 1M: 869 us -> see profiles/.
+// (~9 cache lines for the 240-byte pieces of N=10, D=3) instead of 64 lines with row-per-lane stores
+// (measured on MI355X, B = 1M: 869 us -> 612 us; profiles/).
+//
+// The rows of a segment are written (commit) one back-substitution step before they are streamed out
+// (drain), so the LDS write -> read latency overlaps the next step's arithmetic.  The stores are
+// buffer_store_dwordx4 through a per-drain descriptor whose base is the tile's first piece and whose
+// size ends at the last existing trajectory: per-lane byte offsets are computed once per kernel, and the
+// hardware range check drops the chunks of the tail tile's non-existent trajectories (no predication).
 template <class C>
 struct MtgLdsOut {
   static constexpr int Q = C::D * C::N / 2;   // 16-byte chunks per lane per segment
   static constexpr int QP = Q | 1;            // padded row stride (odd)
   typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   double* stage;        // this wave's staging buffer in LDS: 64 rows x QP chunks
   int lane;
   long long b0;         // first trajectory of the tile
-  __device__ __forceinline__ double* row() { return stage + (size_t)lane * QP * 2; }
-  __device__ __forceinline__ void flush(const MtgParams& P, int seg) {
-    const int K = mtg_nseg<C>(P);
-    long long piece, segoff;
-    if constexpr (C::kStatic) {
-      piece = (long long)C::KT * C::D * C::N;
-      segoff = (long long)seg * C::D * C::N;
-    } else {
-      piece = (long long)K * P.Dtot * C::N;
-      segoff = ((long long)seg * P.Dtot + P.dim0) * C::N;
+  int pending;          // segment whose rows sit in the staging buffer (-1: none)
+  unsigned goff[Q];     // byte offset of chunk i*64+lane inside the tile's output: t*piece_bytes + r*16
+  unsigned loff[Q];     // byte offset of the same chunk inside the staging buffer
+  unsigned piece_bytes; // K*Dtot*N*8: one trajectory's coefficients
+
+  __device__ __forceinline__ void init(const MtgParams& P, double* stage_, int lane_) {
+    stage = stage_;
+    lane = lane_;
+    pending = -1;
+    piece_bytes = (unsigned)(mtg_nseg<C>(P) * P.Dtot * C::N) * 8u;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const unsigned o = (unsigned)i * 64u + (unsigned)lane;
+      const unsigned t = o / (unsigned)Q, r = o - t * (unsigned)Q;
+      goff[i] = t * piece_bytes + r * 16u;
+      loff[i] = (t * (unsigned)QP + r) * 16u;
     }
-    char* gbase = reinterpret_cast<char*>(P.coeffs + b0 * piece + segoff);   // wave-uniform
-    const unsigned piece_bytes = (unsigned)piece * 8u;    // one tile spans < 4 GiB
-    const long long nvalid = P.B - b0;                    // trajectories of this tile that exist
-    // The per-chunk offsets depend only on the lane; recompute them per flush (a few integer ops)
-    // instead of letting LICM park 2*Q of them in registers across the whole tile loop.
-    unsigned l = (unsigned)lane;
-    asm volatile("" : "+v"(l));
+  }
+  __device__ __forceinline__ double* row() { return stage + (size_t)lane * QP * 2; }
+  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
+    pending = seg;
     __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void drain(const MtgParams& P) {
+    if (pending < 0) return;
+    const int seg = pending;
+    pending = -1;
+    const long long segoff = ((long long)seg * P.Dtot + P.dim0) * C::N;          // doubles
+    char* gbase = reinterpret_cast<char*>(P.coeffs + segoff) + b0 * (long long)piece_bytes;   // wave-uniform
+    long long nvalid = P.B - b0;                                                 // trajectories of this tile that exist
+    if (nvalid > 64) nvalid = 64;
+    int nbytes = (int)(nvalid - 1) * (int)piece_bytes + Q * 16;
+    // The descriptor must be provably wave-uniform or hipcc wraps every store in a waterfall loop
+    // (cdna_hip_programming.md T20): pin its inputs to SGPRs explicitly.
+    {
+      const unsigned long long g = reinterpret_cast<unsigned long long>(gbase);
+      const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)g);
+      const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+      gbase = reinterpret_cast<char*>(((unsigned long long)ghi << 32) | glo);
+      nbytes = __builtin_amdgcn_readfirstlane(nbytes);
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
     const char* sbase = reinterpret_cast<const char*>(stage);
-    if (nvalid >= 64) {
+    // LDS reads in groups of G ahead of their stores (one lgkmcnt wait per group instead of per chunk)
+    constexpr int G = 5;
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const unsigned o = (unsigned)i * 64u + l;
-        const unsigned t = o / (unsigned)Q, r = o - t * (unsigned)Q;
-        const d2 v = *reinterpret_cast<const d2*>(sbase + (size_t)(t * (unsigned)QP + r) * 16u);
-        *reinterpret_cast<d2*>(gbase + (size_t)(t * piece_bytes + r * 16u)) = v;
-      }
-    } else {
+    for (int i0 = 0; i0 < Q; i0 += G) {
+      u4 v[G];
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const unsigned o = (unsigned)i * 64u + l;
-        const unsigned t = o / (unsigned)Q, r = o - t * (unsigned)Q;
-        const d2 v = *reinterpret_cast<const d2*>(sbase + (size_t)(t * (unsigned)QP + r) * 16u);
-        if ((long long)t < nvalid) *reinterpret_cast<d2*>(gbase + (size_t)(t * piece_bytes + r * 16u)) = v;
+      for (int i = 0; i < G; ++i) {
+        if (i0 + i < Q) v[i] = *reinterpret_cast<const u4*>(sbase + loff[i0 + i]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        if (i0 + i < Q) __builtin_amdgcn_raw_buffer_store_b128(v[i], rsrc, (int)goff[i0 + i], 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -67,9 +96,23 @@ struct MtgLdsOut {
 template <class C>
 __host__ __device__ constexpr size_t mtg_stage_doubles() { return (size_t)64 * (C::D * C::N / 2 | 1) * 2; }
 
+// Occupancy target (2nd launch-bound = waves per SIMD): the light variants (static, D <= 2 dimensions per
+// workgroup) are held to 256 registers so two waves share a SIMD and hide each other's issue gaps.
+template <class C>
+constexpr int mtg_waves_per_simd() { return (C::kStatic && C::D <= 2) ? 2 : 1; }
+
+#if defined(MTG_TIMING)   // measurement-only build: per-wave phase timestamps (shader cycles) into P.ws
+#define MTG_TSTAMP(slot) do { if (tdo && lane == 0 && tile == (int)blockIdx.x) tdbg[slot] = clock64(); } while (0)
+#else
+#define MTG_TSTAMP(slot) do { } while (0)
+#endif
+
 template <class C, int OUT>
-__global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntiles) {
+__global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_kernel(MtgParams P, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // grid.y = dimension groups: workgroup (x, y) solves dimensions [dim0 + y*D, dim0 + (y+1)*D) of its tiles
+  // (the factorisation is repeated per group; groups are independent).
+  P.dim0 += (int)blockIdx.y * C::D;
   const int lane = threadIdx.x & (kWave - 1);
   const int dir = threadIdx.x >> 6;  // wave-uniform
   const int K = mtg_nseg<C>(P);
@@ -78,24 +121,60 @@ __global__ __launch_bounds__(kBlock) void mtg_solve_kernel(MtgParams P, int ntil
   const int nslots = mtg_mid_slots<C>(mm);
   // LDS: [staging A][staging B][exchange A][exchange B]
   MtgLdsOut<C> io;
-  io.stage = lds + (size_t)dir * mtg_stage_doubles<C>();
-  io.lane = lane;
+  io.init(P, lds + (size_t)dir * mtg_stage_doubles<C>(), lane);
   double* xch = lds + 2 * mtg_stage_doubles<C>();
   double* mine = xch + (size_t)dir * nslots * kWave + lane;
   const double* other = xch + (size_t)(1 - dir) * nslots * kWave + lane;
-  double* wsl = P.ws ? P.ws + ((long long)blockIdx.x * kBlock + threadIdx.x) : nullptr;
+  double* wsl = (P.ws && !C::kStatic)
+                    ? P.ws + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x) : nullptr;
   MtgLane<C> ln;
+#if defined(MTG_TIMING)
+  long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + dir) * 16;
+  const bool tdo = C::kStatic && P.ws != nullptr;
+  if (tdo && lane == 0) tdbg[0] = clock64();
+#endif
+  // Software prefetch (register-rich static variants): the inputs of this workgroup's NEXT tile are requested
+  // before the current tile is solved and land while it computes (measured: the exposed input latency was
+  // ~10k of ~40k cycles per tile at B = 1M).  The light 2-waves-per-SIMD variants have no registers to spare
+  // and rely on the co-resident wave instead.
+  constexpr bool kPrefetch = C::kStatic && mtg_waves_per_simd<C>() == 1;
+  double nT[C::KCS], nfx[C::D][C::NC];
+  auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
+    long long bb = (long long)tile_ * kWave + lane;
+    if (bb >= P.B) bb = P.B - 1;
+    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
+    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
+  };
+  if (kPrefetch && (int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     io.b0 = (long long)tile * kWave;
     const long long bl = io.b0 + lane;
     const bool active = bl < P.B;
     const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl);
-    else mtg_lane_forward<C, -1>(P, b, ln, wsl);
+    const bool has_next = kPrefetch && tile + (int)gridDim.x < ntiles;
+    if (has_next) fetch(tile + gridDim.x, nT, nfx);
+    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, !kPrefetch);
+    else mtg_lane_forward<C, -1>(P, b, ln, wsl, !kPrefetch);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
+    MTG_TSTAMP(1);
     __syncthreads();
+    MTG_TSTAMP(2);
     if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, io, active);
     else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+    MTG_TSTAMP(3);
+#if defined(MTG_TIMING)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MTG_TSTAMP(4);
+    if (has_next) {
+#pragma unroll
+      for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];
+#pragma unroll
+      for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) ln.fx[dm][c] = nfx[dm][c];
+      }
+    }
     __syncthreads();
   }
 }

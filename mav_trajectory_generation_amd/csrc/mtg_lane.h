@@ -184,7 +184,15 @@ struct MtgLane {
 // Static mode: issue every input load of this lane's half-chain up front with incrementally
 // advanced per-lane pointers (one v_lshl_add_u64 per load, no hoistable 64-bit stride products).
 template <class C, int DIR>
+MTG_HD void mtg_preload_into(const MtgParams& P, long long b, double (&T)[C::KCS], double (&fx)[C::D][C::NC]);
+
+template <class C, int DIR>
 MTG_HD void mtg_preload(const MtgParams& P, long long b, MtgLane<C>& ln) {
+  mtg_preload_into<C, DIR>(P, b, ln.T, ln.fx);
+}
+
+template <class C, int DIR>
+MTG_HD void mtg_preload_into(const MtgParams& P, long long b, double (&T)[C::KCS], double (&fx)[C::D][C::NC]) {
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
     constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
@@ -193,7 +201,7 @@ MTG_HD void mtg_preload(const MtgParams& P, long long b, MtgLane<C>& ln) {
     const long long tstep = DIR > 0 ? P.ts_k : -P.ts_k;
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
-      ln.T[j] = *pt;
+      T[j] = *pt;
       pt += tstep;
     }
     const double* pd = P.dfix + b * P.fs_b + (long long)P.dim0 * P.fs_d + (long long)c0 * P.fs_c;
@@ -202,7 +210,7 @@ MTG_HD void mtg_preload(const MtgParams& P, long long b, MtgLane<C>& ln) {
       const double* pc = pd;
 #pragma unroll
       for (int c = 0; c < nc; ++c) {
-        ln.fx[dm][c] = *pc;
+        fx[dm][c] = *pc;
         pc += P.fs_c;
       }
       pd += P.fs_d;
@@ -267,22 +275,32 @@ MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, int& flags)
   }
 }
 
-// x <- (L D L^T)^-1 x on the free index set
-template <int H>
-MTG_HD void mtg_ldl_solve(const double (&L)[H][H], const double (&dinv)[H], int fixed, double (&x)[H]) {
+// X <- (L D L^T)^-1 X for NR right-hand sides at once, X[i][c] (row i, column c).  The column loop
+// is innermost so that consecutive instructions are independent (ILP = number of columns in use).
+template <int H, int NR>
+MTG_HD void mtg_ldl_solve_multi(const double (&L)[H][H], const double (&dinv)[H], int fixed, double (&x)[H][NR],
+                                int colskip) {
 #pragma unroll
   for (int i = 0; i < H; ++i) {
     if ((fixed >> i) & 1) continue;
 #pragma unroll
     for (int k = 0; k < i; ++k) {
       if ((fixed >> k) & 1) continue;
-      x[i] = mtg_fma(-L[i][k], x[k], x[i]);
+#pragma unroll
+      for (int c = 0; c < NR; ++c) {
+        if ((colskip >> c) & 1) continue;
+        x[i][c] = mtg_fma(-L[i][k], x[k][c], x[i][c]);
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < H; ++i) {
     if ((fixed >> i) & 1) continue;
-    x[i] *= dinv[i];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+      if ((colskip >> c) & 1) continue;
+      x[i][c] *= dinv[i];
+    }
   }
 #pragma unroll
   for (int i = H - 1; i >= 0; --i) {
@@ -290,9 +308,26 @@ MTG_HD void mtg_ldl_solve(const double (&L)[H][H], const double (&dinv)[H], int 
 #pragma unroll
     for (int k = i + 1; k < H; ++k) {
       if ((fixed >> k) & 1) continue;
-      x[i] = mtg_fma(-L[k][i], x[k], x[i]);
+#pragma unroll
+      for (int c = 0; c < NR; ++c) {
+        if ((colskip >> c) & 1) continue;
+        x[i][c] = mtg_fma(-L[k][i], x[k][c], x[i][c]);
+      }
     }
   }
+}
+
+// x^e for a small compile-time-bounded exponent by squaring (dependency depth ~log2 e; the
+// wave runs alone on its SIMD, so chain depth -- 8 cycles per dependent FP64 op -- is what costs).
+template <int EMAX>
+MTG_HD double mtg_powi(double x, int e) {
+  double r = 1.0, p = x;
+#pragma unroll
+  for (int bit = 0; (1 << bit) <= EMAX; ++bit) {
+    if ((e >> bit) & 1) r *= p;
+    p *= p;
+  }
+  return r;
 }
 
 // per-segment scale vectors: s[p] = (DIR*T)^p, bs[p] = T^(1-2d) * s[p]
@@ -300,24 +335,14 @@ template <int H, int DIR>
 MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], double& tinv, int& flags) {
   if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
   tinv = mtg_rcp(T);
-  double base;
-  if (deriv == 0) {
-    base = T;
-  } else {
-    base = tinv;
-#pragma unroll
-    for (int i = 1; i < 2 * H - 1; ++i) {
-      if (i < 2 * deriv - 1) base *= tinv;
-    }
-  }
+  const double base = deriv == 0 ? T : mtg_powi<2 * H - 1>(tinv, 2 * deriv - 1);
   const double ts = DIR > 0 ? T : -T;
   s[0] = 1.0;
-  bs[0] = base;
+  if (H > 1) s[1] = ts;
 #pragma unroll
-  for (int p = 1; p < H; ++p) {
-    s[p] = s[p - 1] * ts;
-    bs[p] = base * s[p];
-  }
+  for (int p = 2; p < H; ++p) s[p] = s[p / 2] * s[p - p / 2];   // depth log2(p)
+#pragma unroll
+  for (int p = 0; p < H; ++p) bs[p] = base * s[p];
 }
 
 // One forward elimination step (chain step j): completes the left vertex, produces
@@ -414,67 +439,58 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
   }
   mtg_ldl<H>(A, dinv, ml, ln.flags);
 
-  // G = Dtilde^-1 U (column by column), g = Dtilde^-1 rv
+  // [G | g] = Dtilde^-1 [U | rv]: H + D right-hand sides solved together
+  {
+    double X[H][H + D];
 #pragma unroll
-  for (int q = 0; q < H; ++q) {
-    if ((mr >> q) & 1) {
+    for (int p = 0; p < H; ++p) {
 #pragma unroll
-      for (int p = 0; p < H; ++p) G[p][q] = 0.0;
-      continue;
+      for (int q = 0; q < H; ++q) X[p][q] = U[p][q];
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) X[p][H + dm] = rv[dm][p];
     }
-    double col[H];
+    mtg_ldl_solve_multi<H, H + D>(A, dinv, ml, X, mr);   // columns of fixed right-vertex slots are zero: skip
 #pragma unroll
-    for (int p = 0; p < H; ++p) col[p] = U[p][q];
-    mtg_ldl_solve<H>(A, dinv, ml, col);
+    for (int p = 0; p < H; ++p) {
 #pragma unroll
-    for (int p = 0; p < H; ++p) G[p][q] = ((ml >> p) & 1) ? 0.0 : col[p];
-  }
+      for (int q = 0; q < H; ++q) G[p][q] = (((ml >> p) & 1) || ((mr >> q) & 1)) ? 0.0 : X[p][q];
 #pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-    double col[H];
-#pragma unroll
-    for (int p = 0; p < H; ++p) col[p] = rv[dm][p];
-    mtg_ldl_solve<H>(A, dinv, ml, col);
-#pragma unroll
-    for (int p = 0; p < H; ++p) g[dm][p] = ((ml >> p) & 1) ? 0.0 : col[p];
+      for (int dm = 0; dm < D; ++dm) g[dm][p] = ((ml >> p) & 1) ? 0.0 : X[p][H + dm];
+    }
   }
 
-  // carried onto the right vertex: Sc' = a_rr - U^T G,  rc' = rnext - U^T g
+  // carried onto the right vertex: Sc' = a_rr - U^T G,  rc' = rnext - U^T g   (m outermost => independent FMAs adjacent)
   const double* hrr = mtg_h1<C>(P);
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       ln.Sc[p][q] = 0.0;
-      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) {
-        double acc = bs[p] * s[q] * hrr[(H + p) * N + H + q];
-#pragma unroll
-        for (int m = 0; m < H; ++m) {
-          if (!((ml >> m) & 1)) acc = mtg_fma(-U[m][p], G[m][q], acc);
-        }
-        ln.Sc[p][q] = acc;
-      }
+      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = bs[p] * s[q] * hrr[(H + p) * N + H + q];
     }
   }
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
-    for (int p = 0; p < H; ++p) {
-      double acc = rnext[dm][p];
-      if (!((mr >> p) & 1)) {
+    for (int p = 0; p < H; ++p) ln.rc[dm][p] = rnext[dm][p];
+  }
 #pragma unroll
-        for (int m = 0; m < H; ++m) {
-          if (!((ml >> m) & 1)) acc = mtg_fma(-U[m][p], g[dm][m], acc);
-        }
+  for (int m = 0; m < H; ++m) {
+    if ((ml >> m) & 1) continue;
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if ((mr >> p) & 1) continue;
+#pragma unroll
+      for (int q = 0; q <= p; ++q) {
+        if ((mr >> q) & 1) continue;
+        ln.Sc[p][q] = mtg_fma(-U[m][p], G[m][q], ln.Sc[p][q]);
       }
-      ln.rc[dm][p] = acc;
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-U[m][p], g[dm][m], ln.rc[dm][p]);
     }
   }
 }
 
-// Coefficient recovery for one segment (impl/polynomial_optimization_linear_impl.h:274-280):
-// xS / xE = all h derivatives at the segment's start / end vertex.  Table entries are the outer
-// loops and the D dimensions the inner one, so each scalar constant is consumed immediately.
 // Output policy that stores one lane's D*N coefficients of a segment straight to global memory
 // (host emulation, and the one-lane-per-trajectory update kernel).  The solve kernels use the
 // LDS-staged, coalesced policy MtgLdsOut in mtg_kernels.h instead.
@@ -483,7 +499,8 @@ struct MtgDirectOut {
   double buf[C::D * C::N];
   long long b;
   MTG_HD double* row() { return buf; }
-  MTG_HD void flush(const MtgParams& P, int seg) {
+  MTG_HD void drain(const MtgParams&) {}
+  MTG_HD void commit(const MtgParams& P, int seg) {
     const int K = mtg_nseg<C>(P);
     double* out = P.coeffs + (((long long)b * K + seg) * P.Dtot + P.dim0) * C::N;
 #pragma unroll
@@ -500,12 +517,14 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
   mtg_scales<H, 1>(T, mtg_deriv<C>(P), s, bs, tinv, dummy);
   double tp[H];                    // T^-(H+j)
   {
-    double t = tinv;
+    double ti[H];                  // tinv^j, depth log2(j)
+    ti[0] = 1.0;
+    if (H > 1) ti[1] = tinv;
 #pragma unroll
-    for (int p = 1; p < H; ++p) t *= tinv;
-    tp[0] = t;
+    for (int p = 2; p < H; ++p) ti[p] = ti[p / 2] * ti[p - p / 2];
+    const double th = H > 1 ? ti[H / 2] * ti[H - H / 2] : tinv;   // tinv^H
 #pragma unroll
-    for (int p = 1; p < H; ++p) tp[p] = tp[p - 1] * tinv;
+    for (int p = 0; p < H; ++p) tp[p] = th * ti[p];
   }
   double invfact[H];
   {
@@ -517,6 +536,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     }
   }
   double dl[D][N], qs[D][N];
+  io.drain(P);                 // stream out the previously committed segment before reusing the staging row
   double* row = io.row();
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
@@ -559,7 +579,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
       }
     }
   }
-  io.flush(P, seg);
+  io.commit(P, seg);
   double cost = 0.0;
   if constexpr ((OUT & 1) != 0) {
     // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140).
@@ -657,12 +677,20 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
     }
   }
   mtg_ldl<H>(A, dinv, mm, ln.flags);
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-    mtg_ldl_solve<H>(A, dinv, mm, r[dm]);
+  {
+    double X[H][D];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      if (!((mm >> p) & 1)) xm[dm][p] = r[dm][p];
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) X[p][dm] = r[dm][p];
+    }
+    mtg_ldl_solve_multi<H, D>(A, dinv, mm, X, 0);
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+        if (!((mm >> p) & 1)) xm[dm][p] = X[p][dm];
+      }
     }
   }
 }
@@ -699,13 +727,17 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      if ((ml >> p) & 1) continue;
-      double acc = g[dm][p];
+      if (!((ml >> p) & 1)) xl[dm][p] = g[dm][p];
+    }
+  }
 #pragma unroll
-      for (int q = 0; q < H; ++q) {
-        if (!((mr >> q) & 1)) acc = mtg_fma(-G[p][q], xr[dm][q], acc);
-      }
-      xl[dm][p] = acc;
+  for (int q = 0; q < H; ++q) {
+    if ((mr >> q) & 1) continue;
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if ((ml >> p) & 1) continue;
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) xl[dm][p] = mtg_fma(-G[p][q], xr[dm][q], xl[dm][p]);
     }
   }
   if (active) mtg_store_free<C, OUT>(P, b, vl, ml, xl);
@@ -725,11 +757,20 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane
 
 // ---- whole-lane phases -----------------------------------------------------------------
 // wsl: this lane's slab of the generic-mode workspace (element stride P.ws_stride)
+// do_preload = false: the caller already filled ln.T / ln.fx (the kernel prefetches the next tile's inputs
+// while the current tile is being solved).
 template <class C, int DIR>
-MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, double* wsl) {
+MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, double* wsl, bool do_preload = true) {
   constexpr int H = C::H, D = C::D;
   ln.flags = 0;
-  mtg_preload<C, DIR>(P, b, ln);
+  if (do_preload) mtg_preload<C, DIR>(P, b, ln);
+#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (DIR > 0 ? 0 : 1)) * 16;
+    if (C::kStatic && P.ws != nullptr && (threadIdx.x & 63) == 0 && b < 64 * (long long)gridDim.x) tdbg[5] = clock64();
+  }
+#endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
@@ -777,12 +818,22 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   const int mm = mtg_mask<C>(P, vm);
   double xr[D][H];
   mtg_solve_mid<C, DIR>(P, b, ln, vm, mm, other, stride, xr);
+#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (DIR > 0 ? 0 : 1)) * 16;
+  const bool tdo = C::kStatic && P.ws != nullptr && (threadIdx.x & 63) == 0 && b < 64 * (long long)gridDim.x;
+  if (tdo) tdbg[6] = clock64();
+#endif
   if (DIR > 0 && active) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
-    for (int j = KC - 1; j >= 0; --j) cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr, io, active);
+    for (int j = KC - 1; j >= 0; --j) {
+      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr, io, active);
+#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+      if (tdo && j < 8) tdbg[7 + j] = clock64();
+#endif
+    }
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
     constexpr int E = H * H + D * H;
@@ -802,6 +853,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, G, g, xr, io, active);
     }
   }
+  io.drain(P);
   if constexpr ((OUT & 1) != 0) {
     if (P.cost != nullptr && active) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -39,7 +39,7 @@ def ctx():
     c.close()
 
 
-def gpu_solve(ctx, n, d, masks, times, d_fixed, layout="aos", generic=False, want=True):
+def gpu_solve(ctx, n, d, masks, times, d_fixed, layout="aos", generic=False, want=True, dims="auto"):
     import torch
     import mav_trajectory_generation_amd as m
     dim, k = d_fixed.shape[1], times.shape[1]
@@ -49,7 +49,7 @@ def gpu_solve(ctx, n, d, masks, times, d_fixed, layout="aos", generic=False, wan
     if layout == "soa":
         t = t.t().contiguous()
         f = f.permute(1, 2, 0).contiguous()
-    co, fr, cost = plan.solve(t, f, layout=layout, want_free=want, want_cost=want, generic=generic)
+    co, fr, cost = plan.solve(t, f, layout=layout, want_free=want, want_cost=want, generic=generic, dims=dims)
     ctx.sync()
     if fr is not None and layout == "soa":
         fr = fr.permute(2, 0, 1)
@@ -87,6 +87,24 @@ def test_golden_fixtures(ctx, name, generic, layout):
     assert helpers.check_path(masks, c["times"], c["d_fixed"], co) < 1e-6
     if name == "two_vertices":
         assert np.abs(co[0, 0, 0] - c["matlab_coeffs"]).max() < 1e-12   # TOPT:777-780
+
+
+@pytest.mark.parametrize("name", ["config2", "config5", "readme"])
+@pytest.mark.parametrize("dims", ["fused", "split"])
+@pytest.mark.parametrize("want", [True, False])
+def test_dimension_split_and_fused_variants(ctx, name, dims, want):
+    """Both launch geometries of the specialised kernels (all dimensions per workgroup / one dimension group
+    per workgroup) against the oracle; cost is accumulated atomically across groups."""
+    c = case(name)
+    n, d = int(c["n"]), int(c["d"])
+    masks = [int(m) for m in c["masks"]]
+    co, fr, cost, variant = gpu_solve(ctx, n, d, masks, c["times"], c["d_fixed"], dims=dims, want=want)
+    assert variant in (1, 2)
+    assert helpers.poly_relerr(co, c["coeffs_lit"]) < tol_for(n, d)
+    assert helpers.poly_relerr(co, c["coeffs_mp"]) < 1e-11
+    if want:
+        assert np.abs(fr - c["d_free_mp"]).max() <= 1e-9 * max(1.0, np.abs(c["d_free_mp"]).max())
+        assert np.allclose(cost, c["cost_mp"], rtol=1e-9)
 
 
 def test_specialised_variant_is_selected_for_baseline_config(ctx):
@@ -183,10 +201,13 @@ def test_full_size_properties(ctx, bsz):
     co, fr, cost = plan.solve(t, f, want_free=True, want_cost=True)
     co_g, _, _ = plan.solve(t, f, generic=True)
     co_2, _, _ = plan.solve(t, f * 2.0)
+    co_s, _, _ = plan.solve(t, f, dims="split")
+    co_f, _, _ = plan.solve(t, f, dims="fused")
     ctx.sync()
     assert torch.isfinite(co).all()
     den = co.abs().amax(dim=-1).clamp_min(1e-300)
     assert float(((co - co_g).abs().amax(dim=-1) / den).max()) < 1e-11
+    assert float(((co_s - co_f).abs().amax(dim=-1) / den).max()) < 1e-11
     assert float(((co_2 - 2 * co).abs().amax(dim=-1) / den).max()) < 1e-13
     tn, fn, cn = t.cpu().numpy(), f.cpu().numpy(), co.cpu().numpy()
     assert helpers.check_path(masks, tn, fn, cn) < 1e-6

@@ -89,6 +89,29 @@ __global__ void k_fma_sgpr(double* out, long long* cyc, int iters, double a, dou
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// half of the lanes masked off: does a wave64 FP64 op with EXEC = low 32 lanes take half the passes?
+template <int CHAINS>
+__global__ void k_fma_half(double* out, long long* cyc, int iters, double a, double b) {
+  if (threadIdx.x >= 32) return;
+  double x[CHAINS];
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) x[i] = threadIdx.x * 1e-3 + i;
+  long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int i = 0; i < CHAINS; ++i) x[i] = __builtin_fma(x[i], a, b);
+    }
+  }
+  long long t1 = clock64();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) s += x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <class K, class... A>
 double run(const char* name, K kern, int blocks, int threads, int per_iter, int iters, A... args) {
   double* out; long long* cyc;
@@ -122,6 +145,8 @@ int main() {
   run("fma x8 indep (4 waves/SIMD)", k_fma<8>, 4096, 64, 8 * 8, iters, 1.0000001, 1e-9);
   run("fma x1 dep (4 waves/SIMD)", k_fma<1>, 4096, 64, 8 * 1, iters, 1.0000001, 1e-9);
   run("fma x1 dep (8 waves/SIMD)", k_fma<1>, 8192, 64, 8 * 1, iters, 1.0000001, 1e-9);
+  run("fma x8 indep, EXEC = low 32 lanes", k_fma_half<8>, 1024, 64, 8 * 8, iters, 1.0000001, 1e-9);
+  run("fma x8, EXEC low32, 2 waves/SIMD", k_fma_half<8>, 2048, 64, 8 * 8, iters, 1.0000001, 1e-9);
   run("mul dep x1", k_mul<1>, 1024, 64, 8 * 1, iters, 1.0000001);
   run("mul x8 indep", k_mul<8>, 1024, 64, 8 * 8, iters, 1.0000001);
   run("fma vvs x8 (sgpr addend)", k_fma_sgpr<8>, 1024, 64, 8 * 8, iters, 1e-9, 0.0);
