@@ -23,25 +23,27 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def cpu_baseline(n_sample, seed):
-    """oracle (reference-algorithm port) timed on host cores over a bounded sample of the same workload."""
-    import numpy as np
-    import torch
+    """Reference-algorithm CPU restatement (oracle/cpu_ref.cpp, the checker -- never the product path) timed on
+    this box's host cores over a bounded sample of the same workload (~10-15 s of CPU work)."""
     import mav_trajectory_generation_amd as m
+    from oracle import cpu_ref
     masks = m.ends_full_masks(10, 8)
     t, f = m.random_waypoint_batch(n_sample, 8, 3, 10, masks, seed=seed, device="cpu")
-    t, f = t.numpy(), f.numpy()
-    try:
-        from oracle import cpu_ref  # C++ restatement (oracle/cpu_ref.cpp) if built
-        return cpu_ref.timed_baseline(10, 4, masks, t, f)
-    except Exception:
-        from oracle import oracle_np
-        n = min(n_sample, 3000)
-        t0 = time.perf_counter()
-        oracle_np.solve_batch(10, 4, masks, t[:n], f[:n])
-        dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-                "sample": f"{n} trajectories of the bench workload, numpy restatement of the reference algorithm "
-                          f"(setup+solve), {dt:.1f} s"}
+    return cpu_ref.timed_baseline(10, 4, masks, t.numpy(), f.numpy(), target_seconds=12.0)
+
+
+def measured_traffic(batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
+    tools/gpu_profile.sh on the same command); None if no measurement for this batch size is on file."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("batch") == batch:
+            return d.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -110,6 +112,14 @@ def main():
                                          "GBps": big * plan.bytes_per_trajectory / us * 1e-3,
                                          "frac_of_8TBps": big * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
                 del tb, fb, cb
+            # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value
+            th, fh = t.t().contiguous().cpu().numpy() if args.layout == "soa" else t.cpu().numpy(), None
+            fh = (f.permute(2, 0, 1).contiguous() if args.layout == "soa" else f).cpu().numpy()
+            plan.solve_host(th, fh, want_free=False, want_cost=False)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                plan.solve_host(th, fh, want_free=False, want_cost=False)
+            extra["host_pointers_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -132,13 +142,14 @@ def main():
                                    f"coeffs [B][K][D][N]",
                        "kernel_variant": plan.kernel_variant, "bytes_per_trajectory": plan.bytes_per_trajectory},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
                          "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch},
         }
         if extra:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(20_000, 4321)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
