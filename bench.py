@@ -148,7 +148,7 @@ def main():
         if extra:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(20_000, 4321)
+            out["cpu_baseline"] = cpu_baseline(200_000, 4321)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

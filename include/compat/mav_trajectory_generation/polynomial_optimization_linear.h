@@ -1,0 +1,383 @@
+// Compat veneer: PolynomialOptimization<N> with the reference's public hot-path API
+// (reference: polynomial_optimization_linear.h:45-284) whose solveLinear() / setFreeConstraints() forward to the
+// MI355X library through the C ABI (include/mtg_hip.h).  Host code only: no HIP headers, Eigen optional.
+//
+// Kept: constructor, setupFromVertices, updateSegmentTimes, solveLinear, getSegments, getVertices,
+// getSegmentTimes, get/setFreeConstraints, getFixedConstraints, computeCost, the static matrix helpers, the
+// counters and the dense accessors getA / getAInverse / getM / getR / getMpinv.  Not provided (post-solve
+// analysis, out of scope per SURVEY.md section 2): getTrajectory, computeSegmentMaximumMagnitudeCandidates*,
+// computeMaximumOfMagnitude.  New: PolynomialOptimizationBatch<N>, the batched (accelerated) entry.
+//
+// Value semantics are preserved (the optimiser is copy-assigned in the wild, time_evaluation_node.cpp:357): the
+// object owns only host data plus a shared, immutable plan handle; device scratch lives in a per-thread context.
+#ifndef MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
+#define MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "../../mtg_hip.h"
+#include "motion_defines.h"
+#include "polynomial.h"
+#include "segment.h"
+#include "vertex.h"
+
+namespace mav_trajectory_generation {
+
+namespace mtg_compat_detail {
+struct ThreadContext {
+  mtg_context* ctx = nullptr;
+  ~ThreadContext() { if (ctx) mtg_context_destroy(ctx); }
+};
+inline mtg_context* context() {
+  static thread_local ThreadContext tc;
+  if (!tc.ctx) {
+    const int rc = mtg_context_create(0, nullptr, &tc.ctx);
+    CHECK(rc == MTG_OK) << "mtg_context_create: " << mtg_status_string(rc) << " (the solver has no CPU fallback)";
+  }
+  return tc.ctx;
+}
+inline std::shared_ptr<mtg_plan> make_plan(int N, int D, int K, int derivative, const std::vector<uint32_t>& mask) {
+  mtg_plan_desc desc{N, D, K, derivative, mask.data()};
+  mtg_plan* p = nullptr;
+  const int rc = mtg_plan_create(context(), &desc, &p);
+  CHECK(rc == MTG_OK) << "mtg_plan_create: " << mtg_status_string(rc) << " " << mtg_last_error_string(context());
+  return std::shared_ptr<mtg_plan>(p, [](mtg_plan* q) { mtg_plan_destroy(q); });
+}
+inline void check_sync() {
+  const int rc = mtg_context_sync(context());
+  // LIN:297 CHECK_GT(segment_time, 0) and friends surface here
+  CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(context());
+}
+}  // namespace mtg_compat_detail
+
+template <int _N = 10>
+class PolynomialOptimization {
+  static_assert(_N % 2 == 0, "The number of coefficients has to be even.");
+
+ public:
+  enum { N = _N };
+  static constexpr int kHighestDerivativeToOptimize = N / 2 - 1;
+  typedef Eigen::Matrix<double, N, N> SquareMatrix;
+  typedef std::vector<SquareMatrix, Eigen::aligned_allocator<SquareMatrix>> SquareMatrixVector;
+
+  explicit PolynomialOptimization(size_t dimension)
+      : dimension_(dimension), derivative_to_optimize_(derivative_order::INVALID), n_vertices_(0), n_segments_(0),
+        n_all_constraints_(0), n_fixed_constraints_(0), n_free_constraints_(0) {
+    fixed_constraints_compact_.resize(dimension_);
+    free_constraints_compact_.resize(dimension_);
+  }
+
+  bool setupFromVertices(const Vertex::Vector& vertices, const std::vector<double>& segment_times,
+                         int derivative_to_optimize = kHighestDerivativeToOptimize) {
+    CHECK(derivative_to_optimize >= 0 && derivative_to_optimize <= kHighestDerivativeToOptimize)
+        << "You tried to optimize the " << derivative_to_optimize << "th derivative on a " << N << " coefficient polynomial.";
+    CHECK(vertices.size() == segment_times.size() + 1) << "Size of times must be one less than positions.";
+    derivative_to_optimize_ = derivative_to_optimize;
+    vertices_ = vertices;
+    n_vertices_ = vertices.size();
+    n_segments_ = n_vertices_ - 1;
+    segments_.assign(n_segments_, Segment(N, (int)dimension_));
+    // constraints of order > N/2-1 are dropped (the reference warns and ignores them)
+    for (Vertex& v : vertices_) {
+      for (int k = N / 2; k <= 2 * Polynomial::kMaxN; ++k) v.removeConstraint(k);
+    }
+    // constraint structure: per-vertex masks, fixed values in (vertex, derivative) order
+    mask_.assign(n_vertices_, 0u);
+    n_fixed_constraints_ = 0;
+    for (size_t v = 0; v < n_vertices_; ++v) {
+      for (int p = 0; p < N / 2; ++p) {
+        if (vertices_[v].hasConstraint(p)) { mask_[v] |= 1u << p; ++n_fixed_constraints_; }
+      }
+    }
+    n_all_constraints_ = (size_t)N * n_segments_;
+    n_free_constraints_ = n_vertices_ * (N / 2) - n_fixed_constraints_;
+    for (size_t d = 0; d < dimension_; ++d) {
+      fixed_constraints_compact_[d] = Eigen::VectorXd::Zero(n_fixed_constraints_);
+      free_constraints_compact_[d] = Eigen::VectorXd::Zero(n_free_constraints_);
+    }
+    size_t col = 0;
+    for (size_t v = 0; v < n_vertices_; ++v) {
+      for (int p = 0; p < N / 2; ++p) {
+        Eigen::VectorXd value;
+        if (!vertices_[v].getConstraint(p, &value)) continue;
+        for (size_t d = 0; d < dimension_; ++d) fixed_constraints_compact_[d][col] = value[d];
+        ++col;
+      }
+    }
+    plan_ = mtg_compat_detail::make_plan(N, (int)dimension_, (int)n_segments_, derivative_to_optimize_, mask_);
+    updateSegmentTimes(segment_times);
+    return true;
+  }
+
+  void updateSegmentTimes(const std::vector<double>& segment_times) {
+    CHECK(segment_times.size() == n_segments_) << "Number of segment times does not match number of segments";
+    for (double t : segment_times) CHECK_GT(t, 0) << "Segment times need to be greater than zero";
+    segment_times_ = segment_times;
+  }
+
+  bool solveLinear() {
+    CHECK(derivative_to_optimize_ >= 0 && derivative_to_optimize_ <= kHighestDerivativeToOptimize);
+    run(/*solve=*/true);
+    return true;
+  }
+
+  void setFreeConstraints(const std::vector<Eigen::VectorXd>& free_constraints) {
+    CHECK(free_constraints.size() == dimension_);
+    for (const Eigen::VectorXd& v : free_constraints) CHECK(static_cast<size_t>(v.size()) == n_free_constraints_);
+    free_constraints_compact_ = free_constraints;
+    run(/*solve=*/false);
+  }
+
+  double computeCost() const {   // 0.5 * sum c^T Q c over segments and dimensions
+    double cost = 0.0;
+    for (size_t i = 0; i < n_segments_; ++i) {
+      SquareMatrix Q;
+      computeQuadraticCostJacobian(derivative_to_optimize_, segment_times_[i], &Q);
+      for (size_t d = 0; d < dimension_; ++d) {
+        const Eigen::VectorXd c = segments_[i][d].getCoefficients(0);
+        for (int r = 0; r < N; ++r) for (int q = 0; q < N; ++q) cost += c[r] * Q(r, q) * c[q];
+      }
+    }
+    return 0.5 * cost;
+  }
+
+  void getVertices(Vertex::Vector* vertices) const { CHECK_NOTNULL(vertices); *vertices = vertices_; }
+  void getSegments(Segment::Vector* segments) const { CHECK_NOTNULL(segments); *segments = segments_; }
+  void getSegmentTimes(std::vector<double>* t) const { CHECK(t != nullptr); *t = segment_times_; }
+  void getFreeConstraints(std::vector<Eigen::VectorXd>* f) const { CHECK(f != nullptr); *f = free_constraints_compact_; }
+  void getFixedConstraints(std::vector<Eigen::VectorXd>* f) const { CHECK(f != nullptr); *f = fixed_constraints_compact_; }
+
+  size_t getDimension() const { return dimension_; }
+  size_t getNumberSegments() const { return n_segments_; }
+  size_t getNumberAllConstraints() const { return n_all_constraints_; }
+  size_t getNumberFixedConstraints() const { return n_fixed_constraints_; }
+  size_t getNumberFreeConstraints() const { return n_free_constraints_; }
+  int getDerivativeToOptimize() const { return derivative_to_optimize_; }
+
+  // ---- static matrix helpers (host; not on the GPU path, kept for API compatibility) ----------------------
+  static void setupMappingMatrix(double segment_time, SquareMatrix* A) {   // A = [A(0); A(T)]
+    for (int i = 0; i < N / 2; ++i) {
+      const Eigen::VectorXd r0 = Polynomial::baseCoeffsWithTime(N, i, 0.0);
+      const Eigen::VectorXd r1 = Polynomial::baseCoeffsWithTime(N, i, segment_time);
+      for (int j = 0; j < N; ++j) { (*A)(i, j) = r0[j]; (*A)(i + N / 2, j) = r1[j]; }
+    }
+  }
+  // Inverse of the block matrix [[diag, 0], [C, D]]: [[diag^-1, 0], [-D^-1 C diag^-1, D^-1]].
+  static void invertMappingMatrix(const SquareMatrix& A, SquareMatrix* Ai) {
+    constexpr int h = N / 2;
+    double Dinv[h][h], W[h][2 * h];
+    for (int i = 0; i < h; ++i) for (int j = 0; j < h; ++j) { W[i][j] = A(h + i, h + j); W[i][h + j] = (i == j); }
+    for (int c = 0; c < h; ++c) {   // Gauss-Jordan with partial pivoting on the h x h block
+      int p = c;
+      for (int r = c + 1; r < h; ++r) if (std::abs(W[r][c]) > std::abs(W[p][c])) p = r;
+      if (p != c) for (int j = 0; j < 2 * h; ++j) std::swap(W[c][j], W[p][j]);
+      const double s = 1.0 / W[c][c];
+      for (int j = 0; j < 2 * h; ++j) W[c][j] *= s;
+      for (int r = 0; r < h; ++r) {
+        if (r == c) continue;
+        const double f = W[r][c];
+        for (int j = 0; j < 2 * h; ++j) W[r][j] -= f * W[c][j];
+      }
+    }
+    for (int i = 0; i < h; ++i) for (int j = 0; j < h; ++j) Dinv[i][j] = W[i][h + j];
+    Ai->setZero();
+    for (int i = 0; i < h; ++i) (*Ai)(i, i) = 1.0 / A(i, i);
+    for (int i = 0; i < h; ++i) {
+      for (int j = 0; j < h; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < h; ++k) acc += Dinv[i][k] * A(h + k, j);
+        (*Ai)(h + i, j) = -acc / A(j, j);
+        (*Ai)(h + i, h + j) = Dinv[i][j];
+      }
+    }
+  }
+  // Q(r, c) = base(d, r) base(d, c) t^(r+c-2d+1) * 2 / (r+c-2d+1) so that 0.5 c^T Q c = int_0^t (p^(d))^2
+  static void computeQuadraticCostJacobian(int derivative, double t, SquareMatrix* cost_jacobian) {
+    CHECK_LT(derivative, N);
+    cost_jacobian->setZero();
+    for (int r = derivative; r < N; ++r) {
+      for (int c = derivative; c < N; ++c) {
+        const double e = r + c - 2 * derivative + 1;
+        (*cost_jacobian)(r, c) = Polynomial::baseCoefficient(derivative, r) * Polynomial::baseCoefficient(derivative, c) *
+                                 std::pow(t, e) * 2.0 / e;
+      }
+    }
+  }
+
+  // ---- dense accessors ----------------------------------------------------------------------------------------
+  void getA(Eigen::MatrixXd* A) const {
+    CHECK_NOTNULL(A);
+    A->resize(N * n_segments_, N * n_segments_);
+    A->setZero();
+    for (size_t s = 0; s < n_segments_; ++s) {
+      SquareMatrix As;
+      setupMappingMatrix(segment_times_[s], &As);
+      for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) (*A)(N * s + i, N * s + j) = As(i, j);
+    }
+  }
+  void getAInverse(Eigen::MatrixXd* A_inv) const {
+    CHECK_NOTNULL(A_inv);
+    A_inv->resize(N * n_segments_, N * n_segments_);
+    A_inv->setZero();
+    for (size_t s = 0; s < n_segments_; ++s) {
+      SquareMatrix As, Ai;
+      setupMappingMatrix(segment_times_[s], &As);
+      invertMappingMatrix(As, &Ai);
+      for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) (*A_inv)(N * s + i, N * s + j) = Ai(i, j);
+    }
+  }
+  // M: row s*N + p <-> (vertex s, derivative p), row s*N + N/2 + p <-> (vertex s+1, p); columns = fixed slots in
+  // (vertex, derivative) order followed by free slots in the same order.
+  void getM(Eigen::MatrixXd* M) const {
+    CHECK_NOTNULL(M);
+    M->resize(n_all_constraints_, n_fixed_constraints_ + n_free_constraints_);
+    M->setZero();
+    const std::vector<int> col = columnOfSlot();
+    for (size_t s = 0; s < n_segments_; ++s) {
+      for (int p = 0; p < N / 2; ++p) {
+        (*M)(s * N + p, col[s * (N / 2) + p]) = 1.0;
+        (*M)(s * N + N / 2 + p, col[(s + 1) * (N / 2) + p]) = 1.0;
+      }
+    }
+  }
+  void getMpinv(Eigen::MatrixXd* M_pinv) const {   // M^T with every row normalised by its sum
+    CHECK_NOTNULL(M_pinv);
+    Eigen::MatrixXd M;
+    getM(&M);
+    M_pinv->resize(M.cols(), M.rows());
+    for (std::ptrdiff_t r = 0; r < M.cols(); ++r) {
+      double sum = 0.0;
+      for (std::ptrdiff_t c = 0; c < M.rows(); ++c) sum += M(c, r);
+      for (std::ptrdiff_t c = 0; c < M.rows(); ++c) (*M_pinv)(r, c) = M(c, r) / sum;
+    }
+  }
+  void getR(Eigen::MatrixXd* R) const {   // R = M^T blkdiag(A^-T Q A^-1) M
+    CHECK_NOTNULL(R);
+    const size_t na = n_fixed_constraints_ + n_free_constraints_;
+    R->resize(na, na);
+    R->setZero();
+    const std::vector<int> col = columnOfSlot();
+    for (size_t s = 0; s < n_segments_; ++s) {
+      SquareMatrix As, Ai, Q;
+      setupMappingMatrix(segment_times_[s], &As);
+      invertMappingMatrix(As, &Ai);
+      computeQuadraticCostJacobian(derivative_to_optimize_, segment_times_[s], &Q);
+      double QA[N][N];
+      for (int a = 0; a < N; ++a) for (int b = 0; b < N; ++b) { double acc = 0; for (int c = 0; c < N; ++c) acc += Q(a, c) * Ai(c, b); QA[a][b] = acc; }
+      for (int a = 0; a < N; ++a) {
+        const int ca = col[(a < N / 2 ? s : s + 1) * (N / 2) + a % (N / 2)];
+        for (int b = 0; b < N; ++b) {
+          const int cb = col[(b < N / 2 ? s : s + 1) * (N / 2) + b % (N / 2)];
+          double acc = 0;
+          for (int c = 0; c < N; ++c) acc += Ai(c, a) * QA[c][b];
+          (*R)(ca, cb) += acc;
+        }
+      }
+    }
+  }
+
+ private:
+  std::vector<int> columnOfSlot() const {
+    std::vector<int> col(n_vertices_ * (N / 2));
+    int nf = 0, np = 0;
+    for (size_t v = 0; v < n_vertices_; ++v) for (int p = 0; p < N / 2; ++p) if ((mask_[v] >> p) & 1u) col[v * (N / 2) + p] = nf++;
+    for (size_t v = 0; v < n_vertices_; ++v) for (int p = 0; p < N / 2; ++p) if (!((mask_[v] >> p) & 1u)) col[v * (N / 2) + p] = nf + np++;
+    return col;
+  }
+
+  void run(bool solve) {
+    CHECK(plan_ != nullptr) << "setupFromVertices() has to be called first";
+    const size_t D = dimension_, K = n_segments_, nf = n_fixed_constraints_, np = n_free_constraints_;
+    std::vector<double> d_fixed(D * nf), d_free(D * np + 1), coeffs(K * D * N);
+    for (size_t d = 0; d < D; ++d) {
+      for (size_t c = 0; c < nf; ++c) d_fixed[d * nf + c] = fixed_constraints_compact_[d][c];
+      if (!solve) for (size_t c = 0; c < np; ++c) d_free[d * np + c] = free_constraints_compact_[d][c];
+    }
+    mtg_layout lay;
+    mtg_layout_aos(plan_.get(), 1, &lay);
+    int rc;
+    if (solve) {
+      rc = mtg_solve_linear(plan_.get(), 1, &lay, segment_times_.data(), d_fixed.data(), coeffs.data(),
+                            np ? d_free.data() : nullptr, nullptr, MTG_FLAG_HOST_POINTERS);
+    } else {
+      rc = mtg_update_segments_from_free(plan_.get(), 1, &lay, segment_times_.data(), d_fixed.data(), d_free.data(),
+                                         coeffs.data(), nullptr, MTG_FLAG_HOST_POINTERS);
+    }
+    CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_compat_detail::context());
+    mtg_compat_detail::check_sync();
+    for (size_t d = 0; d < D; ++d) {
+      if (solve) for (size_t c = 0; c < np; ++c) free_constraints_compact_[d][c] = d_free[d * np + c];
+      for (size_t k = 0; k < K; ++k) {
+        Eigen::VectorXd c(N);
+        for (int j = 0; j < N; ++j) c[j] = coeffs[(k * D + d) * N + j];
+        segments_[k].setTime(segment_times_[k]);
+        segments_[k][d] = Polynomial(N, c);
+      }
+    }
+  }
+
+  Vertex::Vector vertices_;
+  Segment::Vector segments_;
+  std::vector<Eigen::VectorXd> fixed_constraints_compact_, free_constraints_compact_;
+  std::vector<double> segment_times_;
+  std::vector<uint32_t> mask_;
+  std::shared_ptr<mtg_plan> plan_;
+  size_t dimension_;
+  int derivative_to_optimize_;
+  size_t n_vertices_, n_segments_, n_all_constraints_, n_fixed_constraints_, n_free_constraints_;
+};
+
+// Batched entry: B trajectories sharing one constraint structure (masks).  Buffers are flat, AoS:
+// times [B][K], d_fixed [B][D][n_fixed], coeffs [B][K][D][N], d_free [B][D][n_free], cost [B]; host or device.
+template <int _N = 10>
+class PolynomialOptimizationBatch {
+ public:
+  enum { N = _N };
+  PolynomialOptimizationBatch(size_t dimension, const std::vector<uint32_t>& fixed_mask, int derivative_to_optimize = N / 2 - 1)
+      : dimension_(dimension), n_segments_(fixed_mask.size() - 1) {
+    plan_ = mtg_compat_detail::make_plan(N, (int)dimension, (int)n_segments_, derivative_to_optimize, fixed_mask);
+    mtg_plan_get_info(plan_.get(), &info_);
+  }
+  // structure taken from a prototype vertex list (values ignored)
+  static std::vector<uint32_t> masksFromVertices(const Vertex::Vector& vertices) {
+    std::vector<uint32_t> m(vertices.size(), 0u);
+    for (size_t v = 0; v < vertices.size(); ++v) for (int p = 0; p < N / 2; ++p) m[v] |= uint32_t(vertices[v].hasConstraint(p)) << p;
+    return m;
+  }
+  size_t getNumberFixedConstraints() const { return info_.n_fixed; }
+  size_t getNumberFreeConstraints() const { return info_.n_free; }
+
+  bool solveLinear(size_t batch, const double* times, const double* d_fixed, double* coeffs, double* d_free = nullptr,
+                   double* cost = nullptr, bool device_pointers = false) {
+    mtg_layout lay;
+    mtg_layout_aos(plan_.get(), (int64_t)batch, &lay);
+    const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
+                                    device_pointers ? 0u : (uint32_t)MTG_FLAG_HOST_POINTERS);
+    CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_compat_detail::context());
+    if (!device_pointers) mtg_compat_detail::check_sync();
+    return true;
+  }
+  void sync() { mtg_compat_detail::check_sync(); }
+
+  // Segment::Vector view of trajectory b of a host coefficient buffer
+  void getSegments(const double* coeffs, const double* times, size_t b, Segment::Vector* segments) const {
+    segments->assign(n_segments_, Segment(N, (int)dimension_));
+    for (size_t k = 0; k < n_segments_; ++k) {
+      (*segments)[k].setTime(times[b * n_segments_ + k]);
+      for (size_t d = 0; d < dimension_; ++d) {
+        Eigen::VectorXd c(N);
+        for (int j = 0; j < N; ++j) c[j] = coeffs[((b * n_segments_ + k) * dimension_ + d) * N + j];
+        (*segments)[k][d] = Polynomial(N, c);
+      }
+    }
+  }
+
+ private:
+  size_t dimension_, n_segments_;
+  std::shared_ptr<mtg_plan> plan_;
+  mtg_plan_info info_;
+};
+
+}  // namespace mav_trajectory_generation
+#endif

@@ -64,20 +64,20 @@ def timed_baseline(n, deriv, masks, times, d_fixed, target_seconds=12.0):
     """bench.py cpu_baseline: reference-algorithm restatement on all host cores over a bounded sample."""
     lib = load()
     cores = max(1, lib.cpu_ref_hardware_threads())
-    # calibrate on a small slice, then size the sample for ~target_seconds of CPU work
+    # calibrate single-threaded on a small slice (thread start-up would dominate a many-thread probe), then size
+    # the timed region for ~target_seconds of wall time assuming ideal scaling (it is re-measured, not assumed)
     probe = min(len(times), 2000)
-    _, _, _, s0 = solve_batch(n, deriv, masks, times[:probe], d_fixed[:probe], nthreads=cores, want_free=False,
+    _, _, _, s0 = solve_batch(n, deriv, masks, times[:probe], d_fixed[:probe], nthreads=1, want_free=False,
                               want_cost=False)
-    rate = probe / max(s0, 1e-9)
-    n_sample = int(min(len(times), max(probe, rate * target_seconds)))
+    rate = probe / max(s0, 1e-9) * cores
+    n_sample = len(times)
     reps = max(1, int(rate * target_seconds / n_sample))
-    best = None
+    solve_batch(n, deriv, masks, times, d_fixed, nthreads=cores, want_free=False, want_cost=False)   # warm-up
     total = 0.0
     for _ in range(reps):
         _, _, _, s = solve_batch(n, deriv, masks, times[:n_sample], d_fixed[:n_sample], nthreads=cores,
                                  want_free=False, want_cost=False)
         total += s
-        best = s if best is None else min(best, s)
     _, _, _, s1 = solve_batch(n, deriv, masks, times[:probe], d_fixed[:probe], nthreads=1, want_free=False,
                               want_cost=False)
     return {"value": n_sample * reps / total, "unit": "trajectories/s", "cores": cores, "kind": "port",

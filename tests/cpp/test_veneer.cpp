@@ -1,0 +1,206 @@
+// Compat-veneer test program (runs on the GPU box; built by __graft_entry__.build()).  Mirrors the reference's
+// own tests for the hot path through the reference's API:
+//   TwoVerticesSetup (test_polynomial_optimization.cpp:743-787, MATLAB vector), the README example
+//   (README.md:104-140), checkPath (:113-174) on random 3-D / 10-segment paths, ConstraintPacking (:505-564),
+//   setFreeConstraints round trip, copy-assignment (time_evaluation_node.cpp:357) and the batched entry.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include <mav_trajectory_generation/polynomial_optimization_linear.h>
+
+using namespace mav_trajectory_generation;
+
+static int g_fail = 0;
+#define EXPECT(cond, ...) do { if (!(cond)) { ++g_fail; std::printf("FAIL %s:%d %s  ", __FILE__, __LINE__, #cond); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+static double checkPath(const Vertex::Vector& vertices, const Segment::Vector& segments, int N) {
+  double worst = 0.0;
+  for (size_t i = 0; i < segments.size(); ++i) {
+    for (Vertex::Constraints::const_iterator it = vertices[i].cBegin(); it != vertices[i].cEnd(); ++it) {
+      const Eigen::VectorXd actual = segments[i].evaluate(0.0, it->first);
+      for (int d = 0; d < actual.size(); ++d) worst = std::max(worst, std::abs(actual[d] - it->second[d]));
+    }
+    for (Vertex::Constraints::const_iterator it = vertices[i + 1].cBegin(); it != vertices[i + 1].cEnd(); ++it) {
+      const Eigen::VectorXd actual = segments[i].evaluate(segments[i].getTime(), it->first);
+      for (int d = 0; d < actual.size(); ++d) worst = std::max(worst, std::abs(actual[d] - it->second[d]));
+    }
+    if (i > 0) {
+      for (int k = 0; k < N / 2; ++k) {
+        const Eigen::VectorXd a = segments[i - 1].evaluate(segments[i - 1].getTime(), k), b = segments[i].evaluate(0.0, k);
+        for (int d = 0; d < a.size(); ++d) worst = std::max(worst, std::abs(a[d] - b[d]));
+      }
+    }
+  }
+  return worst;
+}
+
+int main() {
+  // --- TwoVerticesSetup ------------------------------------------------------------------------------------
+  {
+    Vertex start(1);
+    for (int k = 0; k <= 4; ++k) start.addConstraint(k, 0.0);
+    Vertex goal = start;
+    goal.addConstraint(derivative_order::POSITION, 5.0);
+    PolynomialOptimization<10> opt(1);
+    Vertex::Vector vertices{start, goal};
+    opt.setupFromVertices(vertices, {5.0}, derivative_order::SNAP);
+    EXPECT(opt.getNumberFreeConstraints() == 0, "n_free=%zu", opt.getNumberFreeConstraints());
+    opt.solveLinear();
+    Segment::Vector segments;
+    opt.getSegments(&segments);
+    const double matlab[10] = {-0.000000000000004, 0.000000000000004, -0.000000000000006, 0.000000000000003,
+                               -0.000000000000001, 0.201600000000015, -0.134400000000012, 0.034560000000004,
+                               -0.004032000000000, 0.000179200000000};
+    const Eigen::VectorXd c = segments[0].getPolynomialsRef()[0].getCoefficients();
+    for (int i = 0; i < 10; ++i) EXPECT(std::abs(c[i] - matlab[i]) < 1e-12, "coeff %d: %.17g vs %.17g", i, c[i], matlab[i]);
+    EXPECT(checkPath(vertices, segments, 10) < 1e-6, "checkPath");
+  }
+  // --- README example ----------------------------------------------------------------------------------------
+  {
+    const int dimension = 3;
+    Vertex start(dimension), middle(dimension), end(dimension);
+    start.makeStartOrEnd(Eigen::VectorXd({0, 0, 1}), derivative_order::SNAP);
+    middle.addConstraint(derivative_order::POSITION, Eigen::VectorXd({1, 2, 3}));
+    end.makeStartOrEnd(Eigen::VectorXd({2, 1, 5}), derivative_order::SNAP);
+    Vertex::Vector vertices{start, middle, end};
+    std::vector<double> segment_times = estimateSegmentTimes(vertices, 2.0, 2.0);
+    EXPECT(std::abs(segment_times[0] - 3.970847833173347) < 1e-14 && std::abs(segment_times[1] - 3.8241301415334297) < 1e-14, "times");
+    PolynomialOptimization<10> opt(dimension);
+    opt.setupFromVertices(vertices, segment_times, derivative_order::SNAP);
+    opt.solveLinear();
+    Segment::Vector segments;
+    opt.getSegments(&segments);
+    // segment-0 x coefficients of the 50-digit solve (tests/golden)
+    const double want[10] = {0, 0, 0, 0, 0, 1.339252819662407e-02, -7.845546057749868e-03, 1.954568943684918e-03,
+                             -2.392908039915994e-04, 1.181394415296818e-05};
+    const Eigen::VectorXd c = segments[0][0].getCoefficients();
+    for (int i = 0; i < 10; ++i) EXPECT(std::abs(c[i] - want[i]) < 1e-13, "readme coeff %d: %.17g vs %.17g", i, c[i], want[i]);
+    EXPECT(checkPath(vertices, segments, 10) < 1e-6, "checkPath readme");
+  }
+  // --- random paths: checkPath, cost, constraint packing, free-constraint round trip, copy semantics ---------
+  for (int seed = 100; seed < 104; ++seed) {
+    const int D = 3, K = 10;
+    Vertex::Vector vertices = createRandomVertices(derivative_order::SNAP, K, Eigen::VectorXd::Constant(D, -10.0),
+                                                   Eigen::VectorXd::Constant(D, 10.0), seed);
+    std::vector<double> times = estimateSegmentTimes(vertices, 3.0, 5.0);
+    PolynomialOptimization<10> opt(D);
+    opt.setupFromVertices(vertices, times);
+    EXPECT(opt.getNumberFixedConstraints() == 10 + (K - 1) && opt.getNumberFreeConstraints() == 4 * (K - 1), "counts");
+    opt.solveLinear();
+    Segment::Vector segments;
+    opt.getSegments(&segments);
+    EXPECT(checkPath(vertices, segments, 10) < 1e-6, "checkPath seed %d: %g", seed, checkPath(vertices, segments, 10));
+    // cost vs numeric integral of squared snap (composite Simpson)
+    double numeric = 0.0;
+    for (int s = 0; s < K; ++s) {
+      const int n = 2000;
+      const double hstep = times[s] / n;
+      for (int i = 0; i <= n; ++i) {
+        const Eigen::VectorXd v = segments[s].evaluate(i * hstep, derivative_order::SNAP);
+        const double w = (i == 0 || i == n) ? 1.0 : (i % 2 ? 4.0 : 2.0);
+        numeric += w * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * hstep / 3.0;
+      }
+    }
+    EXPECT(std::abs(opt.computeCost() - numeric) < 1e-6 * numeric, "cost %g vs numeric %g", opt.computeCost(), numeric);
+    // ConstraintPacking: [d_F; d_P] -> p = A^-1 M d -> segment coefficients; A p -> M^+ -> d again
+    std::vector<Eigen::VectorXd> fixed, free_c;
+    opt.getFixedConstraints(&fixed);
+    opt.getFreeConstraints(&free_c);
+    Eigen::MatrixXd M, A_inv, A, M_pinv;
+    opt.getM(&M); opt.getAInverse(&A_inv); opt.getA(&A); opt.getMpinv(&M_pinv);
+    for (int d = 0; d < D; ++d) {
+      Eigen::VectorXd d_all(fixed[d].size() + free_c[d].size());
+      for (int i = 0; i < fixed[d].size(); ++i) d_all[i] = fixed[d][i];
+      for (int i = 0; i < free_c[d].size(); ++i) d_all[fixed[d].size() + i] = free_c[d][i];
+      const Eigen::VectorXd p = A_inv * (M * d_all);
+      const Eigen::VectorXd back = M_pinv * (A * p);
+      for (int i = 0; i < d_all.size(); ++i) EXPECT(std::abs(back[i] - d_all[i]) < 1e-6, "packing round trip");
+      for (int s = 0; s < K; ++s) {
+        const Eigen::VectorXd cs = segments[s][d].getCoefficients(0);
+        for (int j = 0; j < 10; ++j) EXPECT(std::abs(cs[j] - p[s * 10 + j]) < 1e-6 * (1.0 + std::abs(cs[j])), "packing coeffs");
+      }
+    }
+    // KKT: R_PP d_P + R_PF d_F = 0
+    Eigen::MatrixXd R;
+    opt.getR(&R);
+    const size_t nf = opt.getNumberFixedConstraints(), np = opt.getNumberFreeConstraints();
+    for (int d = 0; d < D; ++d) {
+      double worst = 0.0, scale = 0.0;
+      for (size_t a = 0; a < np; ++a) {
+        double acc = 0.0;
+        for (size_t c = 0; c < nf; ++c) { acc += R(nf + a, c) * fixed[d][c]; scale = std::max(scale, std::abs(R(nf + a, c) * fixed[d][c])); }
+        for (size_t c = 0; c < np; ++c) acc += R(nf + a, nf + c) * free_c[d][c];
+        worst = std::max(worst, std::abs(acc));
+      }
+      EXPECT(worst < 1e-7 * scale, "KKT residual %g (scale %g)", worst, scale);
+    }
+    // setFreeConstraints(getFreeConstraints()) reproduces the segments; a perturbed d_P costs more
+    PolynomialOptimization<10> copy(D);
+    copy = opt;   // copy-assignment as in time_evaluation_node.cpp:357
+    const double cost0 = opt.computeCost();
+    copy.setFreeConstraints(free_c);
+    Segment::Vector seg2;
+    copy.getSegments(&seg2);
+    for (int s = 0; s < K; ++s) for (int d = 0; d < D; ++d) {
+      const Eigen::VectorXd a = segments[s][d].getCoefficients(0), b = seg2[s][d].getCoefficients(0);
+      for (int j = 0; j < 10; ++j) EXPECT(std::abs(a[j] - b[j]) <= 1e-12 * (1.0 + std::abs(a[j])), "setFreeConstraints round trip");
+    }
+    free_c[0][3] *= 1.05;
+    copy.setFreeConstraints(free_c);
+    EXPECT(copy.computeCost() > cost0, "perturbed cost %g <= optimal %g", copy.computeCost(), cost0);
+    EXPECT(std::abs(opt.computeCost() - cost0) == 0.0, "original untouched by the copy");
+  }
+  // --- N = 12 with free end-vertex derivatives (test_feasibility.cpp:97-99) --------------------------------------
+  {
+    Vertex::Vector vertices = createRandomVertices(derivative_order::SNAP, 1, Eigen::VectorXd::Constant(3, -5.0),
+                                                   Eigen::VectorXd::Constant(3, 5.0), 7);
+    PolynomialOptimization<12> opt(3);
+    opt.setupFromVertices(vertices, {4.2}, derivative_order::SNAP);
+    EXPECT(opt.getNumberFreeConstraints() == 2, "N=12 n_free=%zu", opt.getNumberFreeConstraints());
+    opt.solveLinear();
+    Segment::Vector segments;
+    opt.getSegments(&segments);
+    EXPECT(checkPath(vertices, segments, 12) < 1e-6, "checkPath N=12");
+  }
+  // --- batched entry vs single solves ---------------------------------------------------------------------------
+  {
+    const int D = 3, K = 8, B = 257;
+    Vertex::Vector proto = createRandomVertices(derivative_order::SNAP, K, Eigen::VectorXd::Constant(D, -10.0),
+                                                Eigen::VectorXd::Constant(D, 10.0), 0);
+    PolynomialOptimizationBatch<10> batch(D, PolynomialOptimizationBatch<10>::masksFromVertices(proto));
+    const size_t nf = batch.getNumberFixedConstraints();
+    std::vector<double> times(B * K), d_fixed(B * D * nf), coeffs(B * K * D * 10), cost(B);
+    std::vector<Vertex::Vector> all;
+    for (int b = 0; b < B; ++b) {
+      Vertex::Vector v = createRandomVertices(derivative_order::SNAP, K, Eigen::VectorXd::Constant(D, -10.0),
+                                              Eigen::VectorXd::Constant(D, 10.0), 1000 + b);
+      std::vector<double> t = estimateSegmentTimes(v, 3.0, 5.0);
+      for (int k = 0; k < K; ++k) times[b * K + k] = t[k];
+      PolynomialOptimization<10> one(D);
+      one.setupFromVertices(v, t);
+      std::vector<Eigen::VectorXd> fixed;
+      one.getFixedConstraints(&fixed);
+      for (int d = 0; d < D; ++d) for (size_t c = 0; c < nf; ++c) d_fixed[(b * D + d) * nf + c] = fixed[d][c];
+      all.push_back(v);
+    }
+    batch.solveLinear(B, times.data(), d_fixed.data(), coeffs.data(), nullptr, cost.data());
+    for (int b = 0; b < B; b += 64) {
+      Segment::Vector segs;
+      batch.getSegments(coeffs.data(), times.data(), b, &segs);
+      EXPECT(checkPath(all[b], segs, 10) < 1e-6, "batch checkPath b=%d", b);
+      PolynomialOptimization<10> one(D);
+      std::vector<double> t(times.begin() + b * K, times.begin() + (b + 1) * K);
+      one.setupFromVertices(all[b], t);
+      one.solveLinear();
+      EXPECT(std::abs(one.computeCost() - cost[b]) < 1e-9 * cost[b], "batch cost %g vs single %g", cost[b], one.computeCost());
+      Segment::Vector s1;
+      one.getSegments(&s1);
+      EXPECT(s1[3][1] == segs[3][1] || true, "bitwise equality not required");
+      const Eigen::VectorXd a = s1[3][1].getCoefficients(0), c = segs[3][1].getCoefficients(0);
+      for (int j = 0; j < 10; ++j) EXPECT(std::abs(a[j] - c[j]) <= 1e-11 * (1e-30 + std::abs(a[j])) + 1e-300, "batch vs single coeff");
+    }
+  }
+  std::printf(g_fail ? "VENEER TESTS FAILED: %d\n" : "VENEER TESTS PASSED%.0d\n", g_fail);
+  return g_fail ? 1 : 0;
+}
