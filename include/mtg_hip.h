@@ -133,7 +133,8 @@ int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layou
  * kernel-side duration per launch in microseconds.                                        */
 int mtg_time_last_solve(mtg_plan* plan, int iters, double* mean_us);
 /* Accuracy self-test of the device reciprocal used by the LDL^T pivots: max relative error
- * of rcp(x) vs 1/x over n pseudo-random positive doubles.                                 */
+ * of rcp(x) vs 1/x over n pseudo-random positive doubles.  (n < 0: diagnostic -- |n| samples with
+ * (|n| & 3) Newton steps instead of the shipped two.)                                      */
 int mtg_selftest_rcp(mtg_context* ctx, int n, double* max_rel_err);
 
 #ifdef __cplusplus

@@ -5,6 +5,10 @@
 
 #include "mtg_lane.h"
 
+#ifndef MTG_STORE_AUX
+#define MTG_STORE_AUX 0   // cache-policy bits of the coefficient stores (16 = sc1 write-through; A/B knob)
+#endif
+
 constexpr int kWave = 64;
 constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: direction B
 
@@ -21,7 +25,10 @@ constexpr int kBlock = 2 * kWave;  // wave 0: direction A (forward), wave 1: dir
 // buffer_store_dwordx4 through a per-drain descriptor whose base is the tile's first piece and whose
 // size ends at the last existing trajectory: per-lane byte offsets are computed once per kernel, and the
 // hardware range check drops the chunks of the tail tile's non-existent trajectories (no predication).
-template <class C>
+// WRITE_THROUGH (kernel OUT bit 2): sc1 stores.  Small launches (one tile per workgroup) otherwise end with all
+// their output dirty in L2 and pay the write-back as a serial tail (B = 10k: 13.4 -> 12.0 us); large launches
+// are faster with write-back stores (B = 1M: 517 us vs 752 us), so the host picks by tile count.
+template <class C, bool WRITE_THROUGH = false>
 struct MtgLdsOut {
   static constexpr int Q = C::D * C::N / 2;   // 16-byte chunks per lane per segment
   static constexpr int QP = Q | 1;            // padded row stride (odd)
@@ -85,7 +92,7 @@ struct MtgLdsOut {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        if (i0 + i < Q) __builtin_amdgcn_raw_buffer_store_b128(v[i], rsrc, (int)goff[i0 + i], 0, 0);
+        if (i0 + i < Q) __builtin_amdgcn_raw_buffer_store_b128(v[i], rsrc, (int)goff[i0 + i], 0, WRITE_THROUGH ? 16 : MTG_STORE_AUX);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   const int mm = mtg_mask<C>(P, vm);
   const int nslots = mtg_mid_slots<C>(mm);
   // LDS: [staging A][staging B][exchange A][exchange B]
-  MtgLdsOut<C> io;
+  MtgLdsOut<C, (OUT & 4) != 0> io;
   io.init(P, lds + (size_t)dir * mtg_stage_doubles<C>(), lane);
   double* xch = lds + 2 * mtg_stage_doubles<C>();
   double* mine = xch + (size_t)dir * nslots * kWave + lane;
@@ -195,7 +202,7 @@ SolveFn mtg_pick_generic_solve(int h, int d, bool extra_outputs);
 UpdateFn mtg_pick_generic_update(int h, int d, bool with_cost);
 struct MtgStaticEntry {
   int h, d, k, ms, mi, me, dv;
-  SolveFn fn[2];
+  SolveFn fn[4];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask);
 

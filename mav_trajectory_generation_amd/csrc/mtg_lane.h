@@ -374,47 +374,54 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
     }
   }
 
-  // rhs of the left vertex and of the right vertex (fixed-value couplings).  Loop order: table
-  // entry outermost, dimensions innermost, so every scalar constant is consumed at once.
+  // rhs of the left vertex and of the right vertex (fixed-value couplings).  Loop order: source column q
+  // outermost, the independent accumulators (row p, dimension) innermost, so consecutive FMAs never depend
+  // on each other (a wave alone on its SIMD pays 8 cycles per dependent FP64 op, 4 per independent one).
   double rv[D][H], rnext[D][H];
   {
     const double* hc = mtg_h1<C>(P);
+    double accl[H][D], accr[H][D];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      double accl[D], accr[D];
 #pragma unroll
-      for (int dm = 0; dm < D; ++dm) { accl[dm] = 0.0; accr[dm] = 0.0; }
+      for (int dm = 0; dm < D; ++dm) { accl[p][dm] = 0.0; accr[p][dm] = 0.0; }
+    }
 #pragma unroll
-      for (int q = 0; q < H; ++q) {
+    for (int q = 0; q < H; ++q) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
         if (!((ml >> p) & 1)) {
           if ((ml >> q) & 1) {
             const double c = hc[p * N + q];
 #pragma unroll
-            for (int dm = 0; dm < D; ++dm) accl[dm] = mtg_fma(c, val_l[dm][q], accl[dm]);
+            for (int dm = 0; dm < D; ++dm) accl[p][dm] = mtg_fma(c, val_l[dm][q], accl[p][dm]);
           }
           if ((mr >> q) & 1) {
             const double c = hc[p * N + H + q];
 #pragma unroll
-            for (int dm = 0; dm < D; ++dm) accl[dm] = mtg_fma(c, val_r[dm][q], accl[dm]);
+            for (int dm = 0; dm < D; ++dm) accl[p][dm] = mtg_fma(c, val_r[dm][q], accl[p][dm]);
           }
         }
         if (!((mr >> p) & 1)) {
           if ((mr >> q) & 1) {
             const double c = hc[(H + p) * N + H + q];
 #pragma unroll
-            for (int dm = 0; dm < D; ++dm) accr[dm] = mtg_fma(c, val_r[dm][q], accr[dm]);
+            for (int dm = 0; dm < D; ++dm) accr[p][dm] = mtg_fma(c, val_r[dm][q], accr[p][dm]);
           }
           if ((ml >> q) & 1) {
             const double c = hc[q * N + H + p];
 #pragma unroll
-            for (int dm = 0; dm < D; ++dm) accr[dm] = mtg_fma(c, val_l[dm][q], accr[dm]);
+            for (int dm = 0; dm < D; ++dm) accr[p][dm] = mtg_fma(c, val_l[dm][q], accr[p][dm]);
           }
         }
       }
+    }
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
-        rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[dm], ln.rc[dm][p]);
-        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -bs[p] * accr[dm];
+        rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[p][dm], ln.rc[dm][p]);
+        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -bs[p] * accr[p][dm];
       }
     }
   }
@@ -555,24 +562,31 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
   }
   {
     const double* ai = mtg_ainv<C>(P);   // [H][N]
+    double acc[H][D];
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) acc[jj][dm] = 0.0;
+    }
+    // source index k outermost, the H*D independent accumulators innermost (no back-to-back dependent FMAs)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int jj = 0; jj < H; ++jj) {
+        const double a = ai[jj * N + k];
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) acc[jj][dm] = mtg_fma(a, dl[dm][k], acc[jj][dm]);
+      }
+    }
     double prev[D];
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) prev[dm] = (H & 1) ? qs[dm][N - 1] : 0.0;
 #pragma unroll
     for (int jj = 0; jj < H; ++jj) {
-      double acc[D];
-#pragma unroll
-      for (int dm = 0; dm < D; ++dm) acc[dm] = 0.0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const double a = ai[jj * N + k];
-#pragma unroll
-        for (int dm = 0; dm < D; ++dm) acc[dm] = mtg_fma(a, dl[dm][k], acc[dm]);
-      }
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
-        qs[dm][H + jj] = acc[dm];
-        const double cj = acc[dm] * tp[jj];
+        qs[dm][H + jj] = acc[jj][dm];
+        const double cj = acc[jj][dm] * tp[jj];
         // coefficient index H + jj; store in aligned pairs (even index first)
         if (((H + jj) & 1) != 0) mtg_store2(row + dm * N + H + jj - 1, prev[dm], cj);
         else prev[dm] = cj;

@@ -4,7 +4,9 @@
 #define MTG_STATIC(H, D, K, MS, MI, ME, DV)                                 \
   {H, D, K, MS, MI, ME, DV,                                                 \
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,          \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>}},
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>,          \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 4>,          \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>}},
 static const MtgStaticEntry kStaticTable[] = {
 #include "mtg_variants.inc"
 };
