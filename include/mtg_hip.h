@@ -67,7 +67,7 @@ typedef struct mtg_plan_info {
   int32_t n_all;          /* getNumberAllConstraints()   LINH:218 = N*K                     */
   int32_t n_fixed;        /* getNumberFixedConstraints() LINH:219                           */
   int32_t n_free;         /* getNumberFreeConstraints()  LINH:220                           */
-  int32_t kernel_variant; /* 0 = generic (runtime K/masks), 1 = specialised register kernel */
+  int32_t kernel_variant; /* 0 generic (run-time K/masks), 1 static, 2 static dim-split only, 3 rolled */
   int64_t algorithmic_bytes_per_trajectory; /* 8*(K + D*n_fixed + K*D*N), SURVEY 8(d)       */
 } mtg_plan_info;
 

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -295,7 +296,7 @@ int mtg_plan_get_info(const mtg_plan* p, mtg_plan_info* out) {
   out->n_all = p->N * p->K;
   out->n_fixed = p->n_fixed;
   out->n_free = p->n_free;
-  out->kernel_variant = p->fast ? 1 : (p->fast_split ? 2 : 0);
+  out->kernel_variant = p->fast ? (p->fast->k < 0 ? 3 : 1) : (p->fast_split ? 2 : 0);
   out->algorithmic_bytes_per_trajectory = 8ll * (p->K + (int64_t)p->D * p->n_fixed + (int64_t)p->K * p->D * p->N);
   return MTG_OK;
 }
@@ -381,6 +382,13 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) ||
                               (!(flags & MTG_FLAG_FUSED_DIMS) && ntiles < 4 * ctx->n_cu);
       var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
+      if (const char* e = getenv("MTG_FORCE_DG")) {   // measurement knob: force the dimension-group size
+        const int dg = atoi(e);
+        if (dg > 0 && p->D % dg == 0) {
+          const MtgStaticEntry* v = mtg_find_static(p->H, dg, p->K, p->deriv, p->mask.data());
+          if (v) var = v;
+        }
+      }
     }
     const int vm = (p->K + 1) / 2;
     const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
@@ -391,8 +399,9 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       Q.dim0 = dim0;
       SolveFn fn;
       int grid;
+      const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
       if (var) {
-        Q.ws = p->user_ws;   // unused by the specialised kernels (measurement builds park timestamps here)
+        Q.ws = p->user_ws;   // unused by the static kernels (measurement builds park timestamps here)
         // few tiles => every workgroup finishes at about the same time: write-through stores avoid the serial
         // end-of-kernel L2 write-back; many tiles => plain write-back stores are faster
         const bool write_through = (long long)ntiles * ngroups <= 4ll * ctx->n_cu;
@@ -402,9 +411,12 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         fn = mtg_pick_generic_solve(p->H, dc, wc);
         if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
         grid = std::min(ntiles, ctx->n_cu * 4);
+      }
+      if (needs_ws) {
+        if (var) grid = std::min(ntiles, std::max(1, ctx->n_cu * 4 / ngroups));
         const int kc = (p->K + 1) / 2;
         const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
-        const size_t need = (size_t)kc * E * (size_t)grid * kBlock * sizeof(double);
+        const size_t need = (size_t)kc * E * (size_t)grid * ngroups * kBlock * sizeof(double);
         if (p->user_ws) {
           if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
           Q.ws = p->user_ws;
@@ -413,7 +425,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
           if (rc != MTG_OK) return rc;
           Q.ws = p->ws;
         }
-        Q.ws_stride = (long long)grid * kBlock;
+        Q.ws_stride = (long long)grid * ngroups * kBlock;
       }
       // LDS: two coefficient staging buffers (64 rows x odd number of 16-byte chunks) + two exchange buffers
       const size_t stage = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);

@@ -56,9 +56,17 @@ struct MtgLdsOut {
     }
   }
   __device__ __forceinline__ double* row() { return stage + (size_t)lane * QP * 2; }
+  // Cross-lane hand-off through LDS inside one wave: LDS operations of a wave execute in order, so no hardware
+  // barrier is needed, but the COMPILER must not move the staged writes / reads across each other (they use
+  // different lanes' addresses, which alias analysis cannot see): compiler-level memory fences on both sides.
+  __device__ __forceinline__ static void fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
   __device__ __forceinline__ void commit(const MtgParams&, int seg) {
     pending = seg;
-    __builtin_amdgcn_wave_barrier();
+    fence();
   }
   __device__ __forceinline__ void drain(const MtgParams& P) {
     if (pending < 0) return;
@@ -80,6 +88,7 @@ struct MtgLdsOut {
     }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
     const char* sbase = reinterpret_cast<const char*>(stage);
+    fence();
     // LDS reads in groups of G ahead of their stores (one lgkmcnt wait per group instead of per chunk)
     constexpr int G = 5;
 #pragma unroll
@@ -87,7 +96,7 @@ struct MtgLdsOut {
       u4 v[G];
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        if (i0 + i < Q) v[i] = *reinterpret_cast<const u4*>(sbase + loff[i0 + i]);
+        if (i0 + i < Q) v[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(sbase + loff[i0 + i]));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -96,7 +105,7 @@ struct MtgLdsOut {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_wave_barrier();
+    fence();
   }
 };
 
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   const int dir = threadIdx.x >> 6;  // wave-uniform
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
-  const int mm = mtg_mask<C>(P, vm);
+  const int mm = C::kRolled ? C::MI : mtg_mask<C>(P, vm);
   const int nslots = mtg_mid_slots<C>(mm);
   // LDS: [staging A][staging B][exchange A][exchange B]
   MtgLdsOut<C, (OUT & 4) != 0> io;

@@ -65,7 +65,13 @@ constexpr int mtg_ainv_offset(int n) {
 template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0>
 struct MtgCfg {
   static constexpr int H = H_, N = 2 * H_, D = D_, KT = KT_;
+  // KT_ > 0: "static"  -- compile-time K, masks, derivative; chain loops unrolled, back-substitution data in registers
+  // KT_ < 0: "rolled"  -- compile-time masks and derivative, run-time K >= 2 (uniform interior mask MI); the chain
+  //                       is a real loop (small code), back-substitution data in the coalesced global workspace
+  // KT_ == 0: "generic" -- everything at run time (per-vertex mask table)
   static constexpr bool kStatic = KT_ > 0;
+  static constexpr bool kRolled = KT_ < 0;
+  static constexpr bool kCT = KT_ != 0;   // compile-time masks / tables
   static constexpr int DV = DV_;   // static mode: derivative_to_optimize (table offsets fold to immediates)
   static constexpr int H1OFF = mtg_h1_offset(2 * H_, DV_), AINVOFF = mtg_ainv_offset(2 * H_);
   static constexpr int MS = MS_, MI = MI_, ME = ME_;
@@ -138,30 +144,30 @@ MTG_HD double mtg_rcp(double x) {
 // Table bases.  Static mode: compile-time offset => every entry folds to an immediate (no SGPR
 // pressure, trivially rematerialisable).  Generic mode: runtime offset, laundered (see above).
 template <class C> MTG_HD const double* mtg_h1(const MtgParams& P) {
-  if constexpr (C::kStatic) return kH1 + C::H1OFF; else return kH1 + mtg_launder(P.h1off);
+  if constexpr (C::kCT) return kH1 + C::H1OFF; else return kH1 + mtg_launder(P.h1off);
 }
 template <class C> MTG_HD const double* mtg_q1(const MtgParams& P) {
-  if constexpr (C::kStatic) return kQ1 + C::H1OFF; else return kQ1 + mtg_launder(P.h1off);
+  if constexpr (C::kCT) return kQ1 + C::H1OFF; else return kQ1 + mtg_launder(P.h1off);
 }
 template <class C> MTG_HD const double* mtg_ainv(const MtgParams& P) {
-  if constexpr (C::kStatic) return kAinvLo + C::AINVOFF; else return kAinvLo + mtg_launder(P.ainvoff);
+  if constexpr (C::kCT) return kAinvLo + C::AINVOFF; else return kAinvLo + mtg_launder(P.ainvoff);
 }
 template <class C> MTG_HD int mtg_deriv(const MtgParams& P) {
-  if constexpr (C::kStatic) return C::DV; else return P.deriv;
+  if constexpr (C::kCT) return C::DV; else return P.deriv;
 }
 
 template <class C> MTG_HD int mtg_nseg(const MtgParams& P) { if constexpr (C::kStatic) return C::KT; else return P.K; }
 
 template <class C> MTG_HD int mtg_mask(const MtgParams& P, int v) {
-  if constexpr (C::kStatic) return v == 0 ? C::MS : (v == C::KT ? C::ME : C::MI);
+  if constexpr (C::kCT) return v == 0 ? C::MS : (v == mtg_nseg<C>(P) ? C::ME : C::MI);
   else return P.vmask[v];
 }
 template <class C> MTG_HD int mtg_offF(const MtgParams& P, int v) {
-  if constexpr (C::kStatic) return v == 0 ? 0 : mtg_popc(C::MS) + (v - 1) * mtg_popc(C::MI);
+  if constexpr (C::kCT) return v == 0 ? 0 : mtg_popc(C::MS) + (v - 1) * mtg_popc(C::MI);
   else return P.offF[v];
 }
 template <class C> MTG_HD int mtg_offP(const MtgParams& P, int v) {
-  if constexpr (C::kStatic) return v == 0 ? 0 : (C::H - mtg_popc(C::MS)) + (v - 1) * (C::H - mtg_popc(C::MI));
+  if constexpr (C::kCT) return v == 0 ? 0 : (C::H - mtg_popc(C::MS)) + (v - 1) * (C::H - mtg_popc(C::MI));
   else return P.offP[v];
 }
 
@@ -338,7 +344,7 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
   const double base = deriv == 0 ? T : mtg_powi<2 * H - 1>(tinv, 2 * deriv - 1);
   const double ts = DIR > 0 ? T : -T;
   s[0] = 1.0;
-  if (H > 1) s[1] = ts;
+  if constexpr (H > 1) s[1] = ts;
 #pragma unroll
   for (int p = 2; p < H; ++p) s[p] = s[p / 2] * s[p - p / 2];   // depth log2(p)
 #pragma unroll
@@ -348,12 +354,11 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
 // One forward elimination step (chain step j): completes the left vertex, produces
 // (G, g) for back-substitution and the carried Schur complement for the right vertex.
 template <class C, int DIR>
-MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, MtgLane<C>& ln,
+MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, int ml, int mr, MtgLane<C>& ln,
                          double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D, N = C::N;
   const int K = mtg_nseg<C>(P);
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
-  const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
 
   double T;
   if constexpr (C::kStatic) T = ln.T[j];
@@ -526,10 +531,11 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
   {
     double ti[H];                  // tinv^j, depth log2(j)
     ti[0] = 1.0;
-    if (H > 1) ti[1] = tinv;
+    if constexpr (H > 1) ti[1] = tinv;
 #pragma unroll
     for (int p = 2; p < H; ++p) ti[p] = ti[p / 2] * ti[p - p / 2];
-    const double th = H > 1 ? ti[H / 2] * ti[H - H / 2] : tinv;   // tinv^H
+    double th = tinv;   // tinv^H
+    if constexpr (H > 1) th = ti[H / 2] * ti[H - H / 2];
 #pragma unroll
     for (int p = 0; p < H; ++p) tp[p] = th * ti[p];
   }
@@ -542,7 +548,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
       invfact[p] = 1.0 / f;   // compile-time constant after unrolling
     }
   }
-  double dl[D][N], qs[D][N];
+  double dl[D][N], qs[D][N], park[D];   // park: c_(h-1) when h is odd (pairs with c_h in the 16-byte store)
   io.drain(P);                 // stream out the previously committed segment before reusing the staging row
   double* row = io.row();
 #pragma unroll
@@ -558,7 +564,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     // low half of the coefficients: c_p = d_p / p!  (pairs that lie entirely in the low half)
 #pragma unroll
     for (int p = 0; p + 1 < H; p += 2) mtg_store2(row + dm * N + p, clo[p], clo[p + 1]);
-    if (H & 1) qs[dm][N - 1] = clo[H - 1];   // odd h: c_(h-1) pairs with c_h below (parked in an unused slot)
+    park[dm] = clo[H - 1];
   }
   {
     const double* ai = mtg_ainv<C>(P);   // [H][N]
@@ -580,7 +586,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     }
     double prev[D];
 #pragma unroll
-    for (int dm = 0; dm < D; ++dm) prev[dm] = (H & 1) ? qs[dm][N - 1] : 0.0;
+    for (int dm = 0; dm < D; ++dm) prev[dm] = park[dm];
 #pragma unroll
     for (int jj = 0; jj < H; ++jj) {
 #pragma unroll
@@ -709,9 +715,8 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
   }
 }
 
-template <class C, int OUT>
-MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, const double (&x)[C::D][C::H]) {
-  if constexpr ((OUT & 2) == 0) return;
+template <class C>
+MTG_HD void mtg_store_free_impl(const MtgParams& P, long long b, int v, int mask, const double (&x)[C::D][C::H]) {
   if (P.dfree == nullptr) return;
   const int off = mtg_offP<C>(P, v);
 #pragma unroll
@@ -724,17 +729,34 @@ MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, con
     }
   }
 }
+template <class C, int OUT>
+MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, const double (&x)[C::D][C::H]) {
+  if constexpr ((OUT & 2) == 0) return;
+  if constexpr (C::H == 1) {
+    // N = 2: a vertex has one slot.  Written without the generic slot loop: with that loop inlined hipcc
+    // (ROCm 7.2) generates wrong code for the <h = 1, D = 2> instantiation (fixed values read back as zero at
+    // -O1 and -O3; D = 1 / 3 / 4 unaffected; tools/debug_case3.py reproduces it).
+    if (P.dfree == nullptr || (mask & 1)) return;
+    double* dst = P.dfree + b * P.ps_b + (long long)P.dim0 * P.ps_d + (long long)mtg_offP<C>(P, v) * P.ps_c;
+#pragma unroll
+    for (int dm = 0; dm < C::D; ++dm) {
+      *dst = x[dm][0];
+      dst += P.ps_d;
+    }
+    return;
+  }
+  mtg_store_free_impl<C>(P, b, v, mask, x);
+}
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
 template <class C, int DIR, int OUT, class IO>
-MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane<C>& ln,
+MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int mr, const MtgLane<C>& ln,
                            const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
                            double (&xr)[C::D][C::H], IO& io, bool active) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
-  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
-  const int ml = mtg_mask<C>(P, vl), mr = mtg_mask<C>(P, vr);
+  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j);
   double xl[D][H];
   mtg_load_vals<C, DIR>(P, b, vl, ml, ln, xl);
 #pragma unroll
@@ -754,7 +776,10 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane
       for (int dm = 0; dm < D; ++dm) xl[dm][p] = mtg_fma(-G[p][q], xr[dm][q], xl[dm][p]);
     }
   }
-  if (active) mtg_store_free<C, OUT>(P, b, vl, ml, xl);
+  // No `active` guard here: tail lanes are clamped duplicates of the last trajectory and store identical values
+  // to identical addresses.  A per-lane condition inside this loop makes the compiler unswitch the loop on it,
+  // and the wave-cooperative coefficient drain (all 64 lanes must take part together) would run in two halves.
+  mtg_store_free<C, OUT>(P, b, vl, ml, xl);
   double T;
   if constexpr (C::kStatic) T = ln.T[j];
   else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
@@ -767,6 +792,36 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, const MtgLane
     for (int p = 0; p < H; ++p) xr[dm][p] = xl[dm][p];
   }
   return cost;
+}
+
+// Back-substitution data of one chain step in the lane-coalesced workspace (element stride = number of lanes):
+// only free x free entries of G and free entries of g exist.
+template <class C>
+MTG_HD void mtg_ws_store(double* w, long long stride, const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
+                         int ml, int mr) {
+  constexpr int H = C::H, D = C::D;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    if ((ml >> p) & 1) continue;
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      if (!((mr >> q) & 1)) w[(long long)(p * H + q) * stride] = G[p][q];
+    }
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) w[(long long)(H * H + dm * H + p) * stride] = g[dm][p];
+  }
+}
+template <class C>
+MTG_HD void mtg_ws_load(const double* w, long long stride, double (&G)[C::H][C::H], double (&g)[C::D][C::H], int ml,
+                        int mr) {
+  constexpr int H = C::H, D = C::D;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) G[p][q] = (((ml >> p) & 1) || ((mr >> q) & 1)) ? 0.0 : w[(long long)(p * H + q) * stride];
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) g[dm][p] = ((ml >> p) & 1) ? 0.0 : w[(long long)(H * H + dm * H + p) * stride];
+  }
 }
 
 // ---- whole-lane phases -----------------------------------------------------------------
@@ -798,25 +853,33 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
-    for (int j = 0; j < KC; ++j) mtg_fwd_step<C, DIR>(P, b, j, ln, ln.G[j], ln.g[j]);
+    for (int j = 0; j < KC; ++j) {
+      mtg_fwd_step<C, DIR>(P, b, j, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)), ln,
+                           ln.G[j], ln.g[j]);
+    }
   } else {
     const int K = P.K;
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
-    constexpr int E = H * H + D * H;
     for (int j = 0; j < kc; ++j) {
       double G[H][H], g[D][H];
-      mtg_fwd_step<C, DIR>(P, b, j, ln, G, g);
-      double* w = wsl + (long long)j * E * P.ws_stride;
-#pragma unroll
-      for (int p = 0; p < H; ++p) {
-#pragma unroll
-        for (int q = 0; q < H; ++q) w[(long long)(p * H + q) * P.ws_stride] = G[p][q];
+      int ml, mr;
+      if constexpr (C::kRolled) {
+        // K >= 2: step 0 starts at a trajectory end, every other vertex of the half-chain (incl. the middle
+        // one) carries the interior mask => the loop body is compiled once with constant masks
+        mr = C::MI;
+        if (j == 0) {
+          ml = DIR > 0 ? C::MS : C::ME;
+          mtg_fwd_step<C, DIR>(P, b, j, DIR > 0 ? C::MS : C::ME, C::MI, ln, G, g);
+        } else {
+          ml = C::MI;
+          mtg_fwd_step<C, DIR>(P, b, j, C::MI, C::MI, ln, G, g);
+        }
+      } else {
+        ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j));
+        mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
+        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
       }
-#pragma unroll
-      for (int dm = 0; dm < D; ++dm) {
-#pragma unroll
-        for (int p = 0; p < H; ++p) w[(long long)(H * H + dm * H + p) * P.ws_stride] = g[dm][p];
-      }
+      mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, ml, mr);
     }
   }
 }
@@ -829,7 +892,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
-  const int mm = mtg_mask<C>(P, vm);
+  const int mm = C::kRolled ? C::MI : mtg_mask<C>(P, vm);   // rolled: K >= 2, the middle vertex is interior
   double xr[D][H];
   mtg_solve_mid<C, DIR>(P, b, ln, vm, mm, other, stride, xr);
 #if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
@@ -837,34 +900,36 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   const bool tdo = C::kStatic && P.ws != nullptr && (threadIdx.x & 63) == 0 && b < 64 * (long long)gridDim.x;
   if (tdo) tdbg[6] = clock64();
 #endif
-  if (DIR > 0 && active) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
+  if (DIR > 0) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
     for (int j = KC - 1; j >= 0; --j) {
-      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, ln.G[j], ln.g[j], xr, io, active);
+      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)),
+                                        ln, ln.G[j], ln.g[j], xr, io, active);
 #if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
       if (tdo && j < 8) tdbg[7 + j] = clock64();
 #endif
     }
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
-    constexpr int E = H * H + D * H;
     for (int j = kc - 1; j >= 0; --j) {
       double G[H][H], g[D][H];
-      const double* w = wsl + (long long)j * E * P.ws_stride;
-#pragma unroll
-      for (int p = 0; p < H; ++p) {
-#pragma unroll
-        for (int q = 0; q < H; ++q) G[p][q] = w[(long long)(p * H + q) * P.ws_stride];
+      const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
+      if constexpr (C::kRolled) {
+        if (j == 0) {
+          mtg_ws_load<C>(w, P.ws_stride, G, g, DIR > 0 ? C::MS : C::ME, C::MI);
+          cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, DIR > 0 ? C::MS : C::ME, C::MI, ln, G, g, xr, io, active);
+        } else {
+          mtg_ws_load<C>(w, P.ws_stride, G, g, C::MI, C::MI);
+          cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, C::MI, C::MI, ln, G, g, xr, io, active);
+        }
+      } else {
+        const int ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
+        mtg_ws_load<C>(w, P.ws_stride, G, g, ml, mr);
+        cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, G, g, xr, io, active);
       }
-#pragma unroll
-      for (int dm = 0; dm < D; ++dm) {
-#pragma unroll
-        for (int p = 0; p < H; ++p) g[dm][p] = w[(long long)(H * H + dm * H + p) * P.ws_stride];
-      }
-      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ln, G, g, xr, io, active);
     }
   }
   io.drain(P);
@@ -894,7 +959,7 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
   double xa[D][H], xb[D][H];
   double cost = 0.0;
   int flags = 0;
-  static_assert(!C::kStatic, "update path is generic only");
+  static_assert(!C::kCT, "update path is generic only");
   MtgLane<C> dummy_lane;
   MtgDirectOut<C> io;
   io.b = b;

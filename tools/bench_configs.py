@@ -26,6 +26,17 @@ def run(name, N, K, D, d, interior, B, layout="soa", dims="auto", yaw=False):
     print(json.dumps(r))
     plan.close()
 
+if len(sys.argv) > 1 and sys.argv[1] == "config5":
+    for B in (12_500, 100_000):
+        run("config5-dg" + os.environ.get("MTG_FORCE_DG", "auto"), 10, 16, 4, 4, 7, B, yaw=True)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "split-ab":
+    for dims in ("fused", "split"):
+        run("config5-" + dims, 10, 16, 4, 4, 7, 100_000, yaw=True, dims=dims)
+        run("config4-N12K8-" + dims, 12, 8, 3, 5, 1, 100_000, dims=dims)
+        run("config4-N8K8-" + dims, 8, 8, 3, 3, 1, 100_000, dims=dims)
+        run("config4-N12K8-" + dims, 12, 8, 3, 5, 1, 2500, dims=dims)
+    sys.exit(0)
 for B in (10_000, 125_000):
     run("config2/3", 10, 8, 3, 4, 1, B)
 # config 4: 30k trajectories = 12 buckets x 2500
