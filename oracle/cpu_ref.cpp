@@ -247,12 +247,15 @@ extern "C" {
 
 // times [B][K], dfix [B][D][n_fixed] -> coeffs [B][K][D][N], dfree [B][D][n_free] (optional), cost [B] (optional).
 // Returns wall-clock seconds of the solve loop (threads = nthreads, contiguous batch split).
-double cpu_ref_solve_batch(int n, int deriv, int k, int dim, const int* mask, long long bsz, const double* times,
-                           const double* dfix, double* coeffs, double* dfree, double* cost, int nthreads) {
+// `repeat` > 1 re-solves each thread's slice that many times (timing runs: one thread spawn for the whole sample).
+double cpu_ref_solve_batch_repeat(int n, int deriv, int k, int dim, const int* mask, long long bsz, const double* times,
+                                  const double* dfix, double* coeffs, double* dfree, double* cost, int nthreads,
+                                  int repeat) {
   const Plan p = make_plan(n, deriv, k, dim, mask);
   if (nthreads < 1) nthreads = 1;
   const auto t0 = std::chrono::steady_clock::now();
   auto work = [&](long long lo, long long hi) {
+    for (int rep = 0; rep < repeat; ++rep)
     for (long long b = lo; b < hi; ++b) {
       solve_one(p, times + b * k, dfix + b * (long long)dim * p.n_fixed, coeffs + b * (long long)k * dim * n,
                 dfree ? dfree + b * (long long)dim * p.n_free : nullptr, cost ? cost + b : nullptr);
@@ -266,6 +269,11 @@ double cpu_ref_solve_batch(int n, int deriv, int k, int dim, const int* mask, lo
     for (auto& x : th) x.join();
   }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+double cpu_ref_solve_batch(int n, int deriv, int k, int dim, const int* mask, long long bsz, const double* times,
+                           const double* dfix, double* coeffs, double* dfree, double* cost, int nthreads) {
+  return cpu_ref_solve_batch_repeat(n, deriv, k, dim, mask, bsz, times, dfix, coeffs, dfree, cost, nthreads, 1);
 }
 
 // createRandomVertices (VERT:27-82, real std::mt19937 / std::uniform_real_distribution of this libstdc++) +

@@ -22,6 +22,9 @@ def load():
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         lib.cpu_ref_solve_batch.restype = ctypes.c_double
         lib.cpu_ref_solve_batch.argtypes = [ctypes.c_int] * 4 + [ip, ctypes.c_longlong, dp, dp, dp, dp, dp, ctypes.c_int]
+        lib.cpu_ref_solve_batch_repeat.restype = ctypes.c_double
+        lib.cpu_ref_solve_batch_repeat.argtypes = [ctypes.c_int] * 4 + [ip, ctypes.c_longlong, dp, dp, dp, dp, dp,
+                                                   ctypes.c_int, ctypes.c_int]
         lib.cpu_ref_generate.restype = None
         lib.cpu_ref_generate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_ulonglong] + \
             [ctypes.c_double] * 4 + [dp, dp]
@@ -61,27 +64,31 @@ def generate(bsz, k, dim, seed0, box=10.0, v_max=3.0, a_max=5.0, magic=6.5):
 
 
 def timed_baseline(n, deriv, masks, times, d_fixed, target_seconds=12.0):
-    """bench.py cpu_baseline: reference-algorithm restatement on all host cores over a bounded sample."""
+    """bench.py cpu_baseline: reference-algorithm restatement on all host cores over a bounded sample.
+    One calibration pass over the sample, then ONE timed call in which every thread re-solves its slice `repeat`
+    times (sized from the calibration for ~target_seconds; a single thread spawn, so start-up cost is amortised)."""
     lib = load()
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
     cores = max(1, lib.cpu_ref_hardware_threads())
-    # calibrate single-threaded on a small slice (thread start-up would dominate a many-thread probe), then size
-    # the timed region for ~target_seconds of wall time assuming ideal scaling (it is re-measured, not assumed)
-    probe = min(len(times), 2000)
-    _, _, _, s0 = solve_batch(n, deriv, masks, times[:probe], d_fixed[:probe], nthreads=1, want_free=False,
-                              want_cost=False)
-    rate = probe / max(s0, 1e-9) * cores
-    n_sample = len(times)
-    reps = max(1, int(rate * target_seconds / n_sample))
-    solve_batch(n, deriv, masks, times, d_fixed, nthreads=cores, want_free=False, want_cost=False)   # warm-up
-    total = 0.0
-    for _ in range(reps):
-        _, _, _, s = solve_batch(n, deriv, masks, times[:n_sample], d_fixed[:n_sample], nthreads=cores,
-                                 want_free=False, want_cost=False)
-        total += s
-    _, _, _, s1 = solve_batch(n, deriv, masks, times[:probe], d_fixed[:probe], nthreads=1, want_free=False,
-                              want_cost=False)
-    return {"value": n_sample * reps / total, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "single_thread_value": probe / s1,
-            "sample": f"{reps} x {n_sample} trajectories of the bench workload (setupFromVertices + solveLinear per "
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    d_fixed = np.ascontiguousarray(d_fixed, dtype=np.float64)
+    bsz, k = times.shape
+    dim = d_fixed.shape[1]
+    m = np.array(masks, dtype=np.int32)
+    co = np.empty((bsz, k, dim, n))
+
+    def run(nthreads, count, repeat):
+        return lib.cpu_ref_solve_batch_repeat(n, deriv, k, dim, m.ctypes.data_as(ip), count, times.ctypes.data_as(dp),
+                                              d_fixed.ctypes.data_as(dp), co.ctypes.data_as(dp), None, None, nthreads,
+                                              repeat)
+
+    s_cal = run(cores, bsz, 1)
+    repeat = int(max(1, min(10_000, target_seconds / max(s_cal, 1e-6))))
+    s_all = run(cores, bsz, repeat)
+    probe = min(bsz, 2000)
+    s_one = run(1, probe, 1)
+    return {"value": bsz * repeat / s_all, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "single_thread_value": probe / s_one,
+            "sample": f"{repeat} x {bsz} trajectories of the bench workload (setupFromVertices + solveLinear per "
                       f"trajectory), C++17 -O3 -march=native restatement of the reference algorithm (Eigen unavailable "
-                      f"offline), std::thread over {cores} host threads, {total:.1f} s"}
+                      f"offline), std::thread over {cores} host threads, {s_all:.1f} s"}

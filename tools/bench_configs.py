@@ -26,6 +26,11 @@ def run(name, N, K, D, d, interior, B, layout="soa", dims="auto", yaw=False):
     print(json.dumps(r))
     plan.close()
 
+if len(sys.argv) > 1 and sys.argv[1] == "long":
+    for (N, d) in ((8, 3), (10, 4), (12, 5)):
+        for K in (16, 32):
+            run("long-dg" + os.environ.get("MTG_FORCE_DG", "auto"), N, K, 3, d, 1, 100_000)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "config5":
     for B in (12_500, 100_000):
         run("config5-dg" + os.environ.get("MTG_FORCE_DG", "auto"), 10, 16, 4, 4, 7, B, yaw=True)
