@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
     ap.add_argument("--dims", default="auto", choices=["auto", "fused", "split"], help="kernel launch geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "exercise the multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--device", type=int, default=None, help="force the HIP device index (multi-process tests)")
     ap.add_argument("--extra", action="store_true", help="also time the 125k / 1M per-launch batches")
     args = ap.parse_args()
 
@@ -65,12 +68,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is not None:
+        local = args.device
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     else:
-        torch.cuda.set_device(0)
-        local = 0
+        torch.cuda.set_device(local if args.device is not None else 0)
+        local = local if args.device is not None else 0
     dev = torch.device("cuda", local)
 
     N, K, D, d = 10, 8, 3, 4
@@ -122,7 +130,7 @@ def main():
             extra["host_pointers_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

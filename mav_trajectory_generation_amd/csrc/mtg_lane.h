@@ -795,7 +795,9 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
 }
 
 // Back-substitution data of one chain step in the lane-coalesced workspace (element stride = number of lanes):
-// only free x free entries of G and free entries of g exist.
+// only free x free entries of G and free entries of g exist; they are packed in traversal order and addressed by
+// walking a pointer (one 64-bit add per element) -- indexed addressing made the compiler keep ~40 hoisted
+// 64-bit slot offsets live across the chain loop (450-900 SGPR spills in the rolled kernels).
 template <class C>
 MTG_HD void mtg_ws_store(double* w, long long stride, const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
                          int ml, int mr) {
@@ -805,10 +807,15 @@ MTG_HD void mtg_ws_store(double* w, long long stride, const double (&G)[C::H][C:
     if ((ml >> p) & 1) continue;
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-      if (!((mr >> q) & 1)) w[(long long)(p * H + q) * stride] = G[p][q];
+      if ((mr >> q) & 1) continue;
+      *w = G[p][q];
+      w += stride;
     }
 #pragma unroll
-    for (int dm = 0; dm < D; ++dm) w[(long long)(H * H + dm * H + p) * stride] = g[dm][p];
+    for (int dm = 0; dm < D; ++dm) {
+      *w = g[dm][p];
+      w += stride;
+    }
   }
 }
 template <class C>
@@ -818,9 +825,19 @@ MTG_HD void mtg_ws_load(const double* w, long long stride, double (&G)[C::H][C::
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
-    for (int q = 0; q < H; ++q) G[p][q] = (((ml >> p) & 1) || ((mr >> q) & 1)) ? 0.0 : w[(long long)(p * H + q) * stride];
+    for (int q = 0; q < H; ++q) {
+      G[p][q] = 0.0;
+      if (((ml >> p) & 1) || ((mr >> q) & 1)) continue;
+      G[p][q] = *w;
+      w += stride;
+    }
 #pragma unroll
-    for (int dm = 0; dm < D; ++dm) g[dm][p] = ((ml >> p) & 1) ? 0.0 : w[(long long)(H * H + dm * H + p) * stride];
+    for (int dm = 0; dm < D; ++dm) {
+      g[dm][p] = 0.0;
+      if ((ml >> p) & 1) continue;
+      g[dm][p] = *w;
+      w += stride;
+    }
   }
 }
 

@@ -216,3 +216,40 @@ def test_full_size_properties(ctx, bsz):
     assert helpers.poly_relerr(cn[idx], c_lit) < 1e-9
     assert np.allclose(cost.cpu().numpy()[idx], j_lit, rtol=1e-8)
     plan.close()
+
+
+def _run_bench(extra_args, nproc=1):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable]
+    if nproc > 1:
+        base += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                 "--master-port", str(29600 + os.getpid() % 300)]
+    cmd = base + [os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu():
+    """bench.py prints ONE JSON line with the driver's keys plus roofline (kernel time from hipEvents)."""
+    d = _run_bench([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 1e8 and "workload" in d["config"]   # the BASELINE target is 1e5 trajectories/s
+
+
+def test_bench_multi_process_path_on_one_gpu():
+    """The N > 1 code path of bench.py (one process per rank, barrier + max-reduce of the timing) with two ranks
+    sharing the only GPU of this box; gloo carries the two tiny collectives here, RCCL on a real multi-GPU node."""
+    d = _run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0"], nproc=2)
+    assert d["n_gpus"] == 2 and d["value"] > 1e8
