@@ -382,6 +382,14 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) ||
                               (!(flags & MTG_FLAG_FUSED_DIMS) && ntiles < 4 * ctx->n_cu);
       var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
+      if (var && var->heavy && !want_split) {   // large launch, spilling static kernel: the rolled form is faster
+        const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+        if (v) var = v;
+      }
+      if (getenv("MTG_PREFER_ROLLED")) {   // measurement knob: rolled variant even where a static one exists
+        const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+        if (v) var = v;
+      }
       if (const char* e = getenv("MTG_FORCE_DG")) {   // measurement knob: force the dimension-group size
         const int dg = atoi(e);
         if (dg > 0 && p->D % dg == 0) {

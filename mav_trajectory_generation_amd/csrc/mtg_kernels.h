@@ -211,8 +211,9 @@ SolveFn mtg_pick_generic_solve(int h, int d, bool extra_outputs);
 UpdateFn mtg_pick_generic_update(int h, int d, bool with_cost);
 struct MtgStaticEntry {
   int h, d, k, ms, mi, me, dv;
+  int heavy;       // static variant that spills: prefer a rolled variant for large launches
   SolveFn fn[4];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]
 };
-const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask);
+const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
 
 #endif  // MTG_KERNELS_H_

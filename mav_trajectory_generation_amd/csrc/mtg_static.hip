@@ -1,14 +1,16 @@
 // Specialised register-resident kernel variants (mtg_variants.inc).
 #include "mtg_kernels.h"
 
-#define MTG_STATIC(H, D, K, MS, MI, ME, DV)                                 \
-  {H, D, K, MS, MI, ME, DV,                                                 \
+#define MTG_STATIC_HEAVY(H, D, K, MS, MI, ME, DV) MTG_STATIC_(H, D, K, MS, MI, ME, DV, 1)
+#define MTG_STATIC(H, D, K, MS, MI, ME, DV) MTG_STATIC_(H, D, K, MS, MI, ME, DV, 0)
+#define MTG_STATIC_(H, D, K, MS, MI, ME, DV, HEAVY)                         \
+  {H, D, K, MS, MI, ME, DV, HEAVY,                                          \
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 4>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>}},
 #define MTG_ROLLED(H, D, MS, MI, ME, DV)                                    \
-  {H, D, -1, MS, MI, ME, DV,                                                \
+  {H, D, -1, MS, MI, ME, DV, 0,                                             \
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 4>,         \
@@ -17,11 +19,14 @@ static const MtgStaticEntry kStaticTable[] = {
 #include "mtg_variants.inc"
 };
 #undef MTG_STATIC
+#undef MTG_STATIC_
+#undef MTG_STATIC_HEAVY
 #undef MTG_ROLLED
 
-const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask) {
+const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only) {
   for (const MtgStaticEntry& e : kStaticTable) {
     if (e.h != h || e.d != d || e.dv != deriv) continue;
+    if (rolled_only && e.k >= 0) continue;
     if (e.k != k && !(e.k < 0 && k >= 2)) continue;   // k < 0: rolled variant, any K >= 2
     bool ok = mask[0] == e.ms && mask[k] == e.me;
     for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;

@@ -67,12 +67,14 @@ Fn pick(int h, int d, bool wc, bool upd) {
 struct StaticEntry { int h, d, k, ms, mi, me, dv; Fn fn[2]; };
 #define MTG_STATIC(H, D, K, MS, MI, ME, DV) \
   {H, D, K, MS, MI, ME, DV, {(Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>, (Fn)emu_solve<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>}},
+#define MTG_STATIC_HEAVY(H, D, K, MS, MI, ME, DV) MTG_STATIC(H, D, K, MS, MI, ME, DV)
 #define MTG_ROLLED(H, D, MS, MI, ME, DV) \
   {H, D, -1, MS, MI, ME, DV, {(Fn)emu_solve<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>, (Fn)emu_solve<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>}},
 const StaticEntry kStatic[] = {
 #include "../mav_trajectory_generation_amd/csrc/mtg_variants.inc"
 };
 #undef MTG_STATIC
+#undef MTG_STATIC_HEAVY
 #undef MTG_ROLLED
 
 }  // namespace

@@ -26,6 +26,13 @@ def run(name, N, K, D, d, interior, B, layout="soa", dims="auto", yaw=False):
     print(json.dumps(r))
     plan.close()
 
+if len(sys.argv) > 1 and sys.argv[1] == "heavy":
+    tag = "rolled" if os.environ.get("MTG_PREFER_ROLLED") else "static"
+    for B in (12_500, 100_000):
+        run("config5-" + tag, 10, 16, 4, 4, 7, B, yaw=True)
+        run("N12K8-" + tag, 12, 8, 3, 5, 1, B)
+        run("N10K8-" + tag, 10, 8, 3, 4, 1, B)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "long":
     for (N, d) in ((8, 3), (10, 4), (12, 5)):
         for K in (16, 32):
