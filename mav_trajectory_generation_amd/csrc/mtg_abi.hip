@@ -365,14 +365,19 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   p->last.clear();
 
   if (update_only) {
+    // compile-time-mask ("rolled") update kernel when the plan has one (all D dimensions in one launch), else generic
+    const MtgStaticEntry* uv = (flags & MTG_FLAG_GENERIC_KERNEL) ? nullptr
+                               : mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
     for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
-      const int dc = std::min(4, p->D - dim0);
-      UpdateFn fn = mtg_pick_generic_update(p->H, dc, wc);
+      const int dc = uv ? p->D : std::min(4, p->D - dim0);
+      UpdateFn fn = uv ? uv->upd[wc ? 1 : 0] : mtg_pick_generic_update(p->H, dc, wc);
       if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no update kernel");
       MtgParams Q = P;
       Q.dim0 = dim0;
-      const int grid = (int)((batch + 255) / 256);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, Q);
+      const int grid = std::min(ntiles, ctx->n_cu * 16);
+      const size_t lds = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, st, Q, ntiles);
+      if (uv) break;
     }
   } else {
     // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the

@@ -195,15 +195,26 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   }
 }
 
+// setFreeConstraints path: one wave = 64 trajectories, one lane per trajectory, recovery only; coefficients leave
+// through the same LDS-staged coalesced drain as the solve kernel.  Dynamic LDS = mtg_stage_doubles<C>() doubles.
 template <class C, int OUT>
-__global__ __launch_bounds__(256) void mtg_update_kernel(MtgParams P) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < P.B) mtg_lane_update<C, OUT>(P, b);
+__global__ __launch_bounds__(kWave) void mtg_update_kernel(MtgParams P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  P.dim0 += (int)blockIdx.y * C::D;
+  const int lane = threadIdx.x;
+  MtgLdsOut<C> io;
+  io.init(P, lds, lane);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    io.b0 = (long long)tile * kWave;
+    const long long bl = io.b0 + lane;
+    const bool active = bl < P.B;
+    mtg_lane_update<C, OUT>(P, active ? bl : P.B - 1, io, active);
+  }
 }
 
 
 using SolveFn = void (*)(MtgParams, int);
-using UpdateFn = void (*)(MtgParams);
+using UpdateFn = void (*)(MtgParams, int);
 template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
 
 // per-TU pickers (mtg_generic_hN.hip, mtg_static.hip)
@@ -213,6 +224,7 @@ struct MtgStaticEntry {
   int h, d, k, ms, mi, me, dv;
   int heavy;       // static variant that spills: prefer a rolled variant for large launches
   SolveFn fn[4];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]
+  void (*upd[2])(MtgParams, int);   // rolled entries: setFreeConstraints kernel [with cost]; static entries: null
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
 

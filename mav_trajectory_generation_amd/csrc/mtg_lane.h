@@ -969,17 +969,16 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 }
 
 // ---- setFreeConstraints path: coefficients from given d_free (no solve) ------------------
-template <class C, int OUT>
-MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
+// One lane per trajectory; `io` is the coefficient output policy (LDS-staged in the kernel, direct on the host).
+template <class C, int OUT, class IO>
+MTG_HD void mtg_lane_update(const MtgParams& P, long long b, IO& io, bool active) {
   constexpr int H = C::H, D = C::D;
   const int K = P.K;
   double xa[D][H], xb[D][H];
   double cost = 0.0;
   int flags = 0;
-  static_assert(!C::kCT, "update path is generic only");
+  static_assert(!C::kStatic, "update path: generic or rolled (compile-time masks) configurations");
   MtgLane<C> dummy_lane;
-  MtgDirectOut<C> io;
-  io.b = b;
   auto load_vertex = [&](int v, double (&x)[D][H]) {
     const int m = mtg_mask<C>(P, v);
     mtg_load_vals<C, 1>(P, b, v, m, dummy_lane, x);
@@ -1006,14 +1005,17 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b) {
       for (int p = 0; p < H; ++p) xa[dm][p] = xb[dm][p];
     }
   }
+  io.drain(P);
   if constexpr ((OUT & 1) != 0) {
+    if (active) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicAdd(P.cost + b, cost);
+      atomicAdd(P.cost + b, cost);
 #else
-    P.cost[b] += cost;
+      P.cost[b] += cost;
 #endif
+    }
   }
-  if (flags) {
+  if (flags && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(P.status, flags);
 #else

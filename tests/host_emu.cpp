@@ -36,7 +36,11 @@ void emu_solve(MtgParams P) {
 
 template <class C, int WC>
 void emu_update(MtgParams P) {
-  for (long long b = 0; b < P.B; ++b) mtg_lane_update<C, WC>(P, b);
+  for (long long b = 0; b < P.B; ++b) {
+    MtgDirectOut<C> io;
+    io.b = b;
+    mtg_lane_update<C, WC>(P, b, io, true);
+  }
 }
 
 using Fn = void (*)(MtgParams);

@@ -253,3 +253,72 @@ def test_bench_multi_process_path_on_one_gpu():
     sharing the only GPU of this box; gloo carries the two tiny collectives here, RCCL on a real multi-GPU node."""
     d = _run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0"], nproc=2)
     assert d["n_gpus"] == 2 and d["value"] > 1e8
+
+
+def test_mixed_batch_config4_buckets(ctx):
+    """BASELINE config 4: N in {8 (jerk), 10 (snap), 12}, K in {4, 8, 16, 32}, D = 3, mixed in one request list; every
+    trajectory is checked against the oracle (N <= 10: 1e-9) or the mpmath truth (N = 12: 1e-7)."""
+    import mav_trajectory_generation_amd as m
+    from oracle import oracle_mp as omp
+    rng = np.random.default_rng(4)
+    problems, meta = [], []
+    for (n, d) in ((8, 3), (10, 4), (12, 5)):
+        for k in (4, 8, 16, 32):
+            masks, times, d_fixed = helpers.reference_batch(3, k, n, 3, 7000 + n * 100 + k)
+            for b in range(3):
+                problems.append(dict(n_coeffs=n, derivative=d, masks=masks, times=times[b], d_fixed=d_fixed[b]))
+                meta.append((n, d, masks))
+    order = rng.permutation(len(problems))
+    solver = m.MixedBatchSolver(ctx)
+    coeffs, costs = solver.solve([problems[i] for i in order], want_cost=True)
+    assert len(solver.plans) == 12
+    for pos, i in enumerate(order):
+        n, d, masks = meta[i]
+        p = problems[i]
+        if n == 12:
+            ref, _, j = omp.solve(n, d, masks, p["times"], p["d_fixed"])
+            tol = 1e-7
+        else:
+            ref, _, j = onp.solve_batch(n, d, masks, p["times"][None], p["d_fixed"][None])
+            ref, j = ref[0], j[0]
+            tol = 1e-9
+        assert helpers.poly_relerr(coeffs[pos], ref) < tol, (n, len(p["times"]))
+        assert abs(costs[pos] - j) <= 1e-6 * abs(j)
+    solver.close()
+
+
+def test_config5_full_size_properties(ctx):
+    """BASELINE config 5 shape at its per-GPU share (100k / 8): K = 16, D = 4 (x, y, z, yaw), interior vertices fix
+    position, velocity and acceleration.  checkPath over the whole batch + oracle parity on a subset, for both the
+    small-launch (dimension-split static) and large-launch (rolled) kernel choices."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 16, 7)
+    plan = m.Plan(ctx, 10, 4, 16, 4, masks)
+    for bsz in (12_500, 70_000):
+        t, f = m.random_waypoint_batch(bsz, 16, 4, 10, masks, seed=3, device="cuda", yaw_dim=True)
+        co, _, cost = plan.solve(t, f, want_cost=True)
+        ctx.sync()
+        tn, fn, cn = t.cpu().numpy(), f.cpu().numpy(), co.cpu().numpy()
+        assert helpers.check_path(masks, tn, fn, cn) < 1e-6
+        idx = np.arange(0, bsz, bsz // 100)[:100]
+        c_lit, _, j_lit = onp.solve_batch(10, 4, masks, tn[idx], fn[idx])
+        assert helpers.poly_relerr(cn[idx], c_lit) < 1e-9
+        assert np.allclose(cost.cpu().numpy()[idx], j_lit, rtol=1e-8)
+    plan.close()
+
+
+def test_update_from_free_large_batch(ctx):
+    """setFreeConstraints path at size: coefficients rebuilt from the solver's own d_P equal the solve's."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(50_001, 8, 3, 10, masks, seed=8, device="cuda")
+    co, fr, cost = plan.solve(t, f, want_free=True, want_cost=True)
+    co2, cost2 = plan.update_from_free(t, f, fr, want_cost=True)
+    ctx.sync()
+    den = co.abs().amax(dim=-1).clamp_min(1e-300)
+    assert float(((co - co2).abs().amax(dim=-1) / den).max()) < 1e-12
+    assert torch.allclose(cost, cost2, rtol=1e-10)
+    plan.close()
