@@ -81,8 +81,12 @@ enum {
   MTG_FLAG_HOST_POINTERS = 1u << 0, /* all buffers are host memory: the library stages them  */
   MTG_FLAG_GENERIC_KERNEL = 1u << 1, /* force the generic kernel (tests / A-B measurements)  */
   MTG_FLAG_FUSED_DIMS = 1u << 2,     /* all D dimensions in one workgroup (large batches)     */
-  MTG_FLAG_SPLIT_DIMS = 1u << 3      /* one dimension group per workgroup (small batches);    */
+  MTG_FLAG_SPLIT_DIMS = 1u << 3,     /* one dimension group per workgroup (small batches);    */
                                      /* default: chosen from the batch size                   */
+  MTG_FLAG_COST_ONLY = 1u << 4       /* only cost[] is produced (coeffs may be NULL): the     */
+                                     /* objective evaluations of the time optimisers          */
+                                     /* (polynomial_optimization_nonlinear_impl.h:313-359,    */
+                                     /* :569-571) need J = computeCost(), not the segments    */
 };
 
 /* ---- context ------------------------------------------------------------------------- */

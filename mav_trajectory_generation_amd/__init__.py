@@ -7,3 +7,4 @@ solver entry points without the built library, or calling them without a GPU, ra
 from .core import Context, Plan, MtgError, solve_linear_batch, library_path  # noqa: F401
 from .workload import ends_full_masks, random_waypoint_batch  # noqa: F401
 from .buckets import MixedBatchSolver  # noqa: F401
+from .time_gradient import mellinger_cost_and_gradient  # noqa: F401

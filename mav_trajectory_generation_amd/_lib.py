@@ -51,6 +51,7 @@ FLAG_HOST_POINTERS = 1
 FLAG_GENERIC_KERNEL = 2
 FLAG_FUSED_DIMS = 4
 FLAG_SPLIT_DIMS = 8
+FLAG_COST_ONLY = 16
 
 _lib = None
 

@@ -143,6 +143,21 @@ class Plan:
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
 
+    def solve_cost_only(self, times, d_fixed, layout: str = "aos", cost=None):
+        """computeCost() of the optimum for every trajectory without materialising the segments
+        (MTG_FLAG_COST_ONLY): what the time optimisers' objective callbacks need.  Returns cost [B]."""
+        import torch
+        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        if cost is None:
+            cost = torch.empty((batch,), dtype=torch.float64, device=times.device)
+        lay = self.layout(batch, layout)
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), self._ptr(times), self._ptr(d_fixed),
+                                       None, None, self._ptr(cost), L.FLAG_COST_ONLY)
+        self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+        return cost
+
     def update_from_free(self, times, d_fixed, d_free, layout: str = "aos", want_cost: bool = False):
         """setFreeConstraints() path: coefficients from given free constraints, no solve."""
         import torch

@@ -60,11 +60,11 @@ __global__ void mtg_rcp_selftest_kernel(int n, double* out, int iters) {
 
 }  // namespace
 
-#define MTG_DECL(H) SolveFn mtg_pick_generic_solve_h##H(int, bool); UpdateFn mtg_pick_generic_update_h##H(int, bool);
+#define MTG_DECL(H) SolveFn mtg_pick_generic_solve_h##H(int, int); UpdateFn mtg_pick_generic_update_h##H(int, bool);
 MTG_DECL(1) MTG_DECL(2) MTG_DECL(3) MTG_DECL(4) MTG_DECL(5) MTG_DECL(6)
 #undef MTG_DECL
 
-SolveFn mtg_pick_generic_solve(int h, int d, bool extra) {
+SolveFn mtg_pick_generic_solve(int h, int d, int extra) {
   switch (h) {
     case 1: return mtg_pick_generic_solve_h1(d, extra);
     case 2: return mtg_pick_generic_solve_h2(d, extra);
@@ -320,9 +320,11 @@ static int64_t span(int64_t batch, int64_t sb, int64_t n1, int64_t s1, int64_t n
 
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only) {
-  if (!p || !L || !times || !coeffs || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
+  const bool cost_only = !update_only && (flags & MTG_FLAG_COST_ONLY) != 0;
+  if (!p || !L || !times || (!coeffs && !cost_only) || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
+  if (cost_only && (!cost || (flags & MTG_FLAG_HOST_POINTERS))) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = p->ctx;
-  if (!(flags & MTG_FLAG_HOST_POINTERS) && (reinterpret_cast<uintptr_t>(coeffs) & 15))
+  if (!cost_only && !(flags & MTG_FLAG_HOST_POINTERS) && (reinterpret_cast<uintptr_t>(coeffs) & 15))
     return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");
   if (p->n_fixed > 0 && !d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_fixed is null");
   if (update_only && p->n_free > 0 && !d_free) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_free is null");
@@ -418,10 +420,10 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         // few tiles => every workgroup finishes at about the same time: write-through stores avoid the serial
         // end-of-kernel L2 write-back; many tiles => plain write-back stores are faster
         const bool write_through = (long long)ntiles * ngroups <= 4ll * ctx->n_cu;
-        fn = var->fn[(wc ? 1 : 0) + (write_through ? 2 : 0)];
+        fn = cost_only ? var->fn[4] : var->fn[(wc ? 1 : 0) + (write_through ? 2 : 0)];
         grid = std::min(ntiles, std::max(1, ctx->n_cu * 8 / ngroups));
       } else {
-        fn = mtg_pick_generic_solve(p->H, dc, wc);
+        fn = mtg_pick_generic_solve(p->H, dc, cost_only ? 2 : (wc ? 1 : 0));
         if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
         grid = std::min(ntiles, ctx->n_cu * 4);
       }

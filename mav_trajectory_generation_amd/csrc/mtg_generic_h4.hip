@@ -1,13 +1,14 @@
 // Generic (runtime K / masks / derivative) kernels for N = 8: explicit instantiations for D = 1..4.
 #include "mtg_kernels.h"
 
-SolveFn mtg_pick_generic_solve_h4(int d, bool extra) {
-  switch (d) {
-    case 1: return extra ? (SolveFn)mtg_solve_kernel<GenericCfg<4, 1>, 3> : (SolveFn)mtg_solve_kernel<GenericCfg<4, 1>, 0>;
-    case 2: return extra ? (SolveFn)mtg_solve_kernel<GenericCfg<4, 2>, 3> : (SolveFn)mtg_solve_kernel<GenericCfg<4, 2>, 0>;
-    case 3: return extra ? (SolveFn)mtg_solve_kernel<GenericCfg<4, 3>, 3> : (SolveFn)mtg_solve_kernel<GenericCfg<4, 3>, 0>;
-    case 4: return extra ? (SolveFn)mtg_solve_kernel<GenericCfg<4, 4>, 3> : (SolveFn)mtg_solve_kernel<GenericCfg<4, 4>, 0>;
-  }
+SolveFn mtg_pick_generic_solve_h4(int d, int mode) {
+#define MTG_CASE(DD)                                                                                   \
+  case DD:                                                                                             \
+    return mode == 2 ? (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 9>                                 \
+                     : (mode == 1 ? (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 3>                    \
+                                  : (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 0>);
+  switch (d) { MTG_CASE(1) MTG_CASE(2) MTG_CASE(3) MTG_CASE(4) }
+#undef MTG_CASE
   return nullptr;
 }
 UpdateFn mtg_pick_generic_update_h4(int d, bool wc) {

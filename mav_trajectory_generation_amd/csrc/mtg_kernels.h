@@ -218,12 +218,12 @@ using UpdateFn = void (*)(MtgParams, int);
 template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
 
 // per-TU pickers (mtg_generic_hN.hip, mtg_static.hip)
-SolveFn mtg_pick_generic_solve(int h, int d, bool extra_outputs);
+SolveFn mtg_pick_generic_solve(int h, int d, int out_mode);   // out_mode: 0 plain, 1 extra outputs (OUT 3), 2 cost only (OUT 9)
 UpdateFn mtg_pick_generic_update(int h, int d, bool with_cost);
 struct MtgStaticEntry {
   int h, d, k, ms, mi, me, dv;
   int heavy;       // static variant that spills: prefer a rolled variant for large launches
-  SolveFn fn[4];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]
+  SolveFn fn[5];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]; [4] = cost only (OUT 9)
   void (*upd[2])(MtgParams, int);   // rolled entries: setFreeConstraints kernel [with cost]; static entries: null
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);

@@ -549,8 +549,13 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     }
   }
   double dl[D][N], qs[D][N], park[D];   // park: c_(h-1) when h is odd (pairs with c_h in the 16-byte store)
-  io.drain(P);                 // stream out the previously committed segment before reusing the staging row
-  double* row = io.row();
+  constexpr bool kStore = (OUT & 8) == 0;   // OUT bit 3: cost-only launch, no coefficient output at all
+  double dummy_row[2];
+  double* row = dummy_row;
+  if constexpr (kStore) {
+    io.drain(P);               // stream out the previously committed segment before reusing the staging row
+    row = io.row();
+  }
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
     double clo[H + 1];
@@ -562,8 +567,10 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
       qs[dm][p] = dl[dm][p] * invfact[p];
     }
     // low half of the coefficients: c_p = d_p / p!  (pairs that lie entirely in the low half)
+    if constexpr (kStore) {
 #pragma unroll
-    for (int p = 0; p + 1 < H; p += 2) mtg_store2(row + dm * N + p, clo[p], clo[p + 1]);
+      for (int p = 0; p + 1 < H; p += 2) mtg_store2(row + dm * N + p, clo[p], clo[p + 1]);
+    }
     park[dm] = clo[H - 1];
   }
   {
@@ -594,12 +601,14 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
         qs[dm][H + jj] = acc[jj][dm];
         const double cj = acc[jj][dm] * tp[jj];
         // coefficient index H + jj; store in aligned pairs (even index first)
-        if (((H + jj) & 1) != 0) mtg_store2(row + dm * N + H + jj - 1, prev[dm], cj);
-        else prev[dm] = cj;
+        if constexpr (kStore) {
+          if (((H + jj) & 1) != 0) mtg_store2(row + dm * N + H + jj - 1, prev[dm], cj);
+          else prev[dm] = cj;
+        }
       }
     }
   }
-  io.commit(P, seg);
+  if constexpr (kStore) io.commit(P, seg);
   double cost = 0.0;
   if constexpr ((OUT & 1) != 0) {
     // 0.5 c^T Q(T) c = 0.5 T^(1-2d) q^T Q(1) q with q_j = c_j T^j   (impl/...:124-140).

@@ -8,14 +8,16 @@
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 4>,          \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>},         \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>,          \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 9>},         \
    {nullptr, nullptr}},
 #define MTG_ROLLED(H, D, MS, MI, ME, DV)                                    \
   {H, D, -1, MS, MI, ME, DV, 0,                                             \
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 4>,         \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 7>},        \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 7>,         \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 9>},        \
    {(UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,       \
     (UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1>}},
 static const MtgStaticEntry kStaticTable[] = {

@@ -322,3 +322,37 @@ def test_update_from_free_large_batch(ctx):
     assert float(((co - co2).abs().amax(dim=-1) / den).max()) < 1e-12
     assert torch.allclose(cost, cost2, rtol=1e-10)
     plan.close()
+
+
+def test_cost_only_and_mellinger_gradient(ctx):
+    """MTG_FLAG_COST_ONLY and the batched Mellinger cost/gradient step (K+1 perturbed-time solves per trajectory in
+    one launch) against a literal restatement of getCostAndGradientMellinger
+    (polynomial_optimization_nonlinear_impl.h:287-364) on the oracle."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    bsz, k = 12, 8
+    masks, times, d_fixed = helpers.reference_batch(bsz, k, 10, 3, 60606)
+    plan = m.Plan(ctx, 10, 3, k, 4, masks)
+    t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
+    _, _, cost_full = plan.solve(t, f, want_cost=True)
+    cost_only = plan.solve_cost_only(t, f)
+    j0, grad = m.mellinger_cost_and_gradient(plan, t, f)
+    ctx.sync()
+    assert torch.allclose(cost_only, cost_full, rtol=1e-12)
+    assert torch.allclose(j0, cost_full, rtol=1e-12)
+    # oracle: the reference's loop, one trajectory at a time
+    want = np.zeros((bsz, k))
+    for b in range(bsz):
+        def cost_of(tt):
+            _, _, j = onp.solve_batch(10, 4, masks, tt[None], d_fixed[b][None])
+            return j[0]
+        jd = cost_of(times[b])
+        for n in range(k):
+            tb = times[b].copy()
+            for i in range(k):
+                tb[i] += 0.1 if i == n else -0.1 / (k - 1.0)
+            tb = np.maximum(0.1, tb)
+            want[b, n] = (cost_of(tb) - jd) / 0.1
+    got = grad.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    plan.close()
