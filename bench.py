@@ -108,6 +108,15 @@ def main():
 
         # kernel-only duration: hipEvents on the launch stream (inside the library)
         kern_us = plan.time_last_solve(max(50, args.steps))
+        # context for small launches: a write-only fill of the same coefficient buffer (zero compute, zero reads)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        coeffs.fill_(0.0)
+        e0.record(ctx.stream)
+        for _ in range(50):
+            coeffs.fill_(0.0)
+        e1.record(ctx.stream)
+        torch.cuda.synchronize()
+        fill_us = e0.elapsed_time(e1) * 1e3 / 50
         extra = {}
         if args.extra and rank == 0:
             for big in (125_000, 1_000_000):
@@ -151,7 +160,8 @@ def main():
                        "kernel_variant": plan.kernel_variant, "bytes_per_trajectory": plan.bytes_per_trajectory},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                         "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch},
+                         "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch,
+                         "output_fill_only_us": fill_us},
         }
         if extra:
             out["extra"] = extra

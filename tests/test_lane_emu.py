@@ -84,3 +84,45 @@ def test_emulated_kernel_edge_shapes(host_emu, n, d, k, dim, masks):
     assert rc == 0 and st == 0
     assert helpers.poly_relerr(co, c_lit) < tol_for(n, d)
     assert helpers.check_path(masks, times, d_fixed, co) < 1e-6
+
+
+def test_randomised_shapes_and_masks(host_emu):
+    """Seeded sweep over ragged per-vertex masks (position always fixed), K, D, N: the generic code path of the
+    kernel (run-time masks, dimension chunks, workspace) against the literal oracle + checkPath."""
+    rng = np.random.default_rng(20240924)
+    for trial in range(60):
+        n = int(rng.choice([4, 6, 8, 10, 10, 10, 12]))
+        h = n // 2
+        d = h - 1 if rng.random() < 0.8 else int(rng.integers(max(1, h - 2), h))
+        k = int(rng.integers(1, 10))
+        dim = int(rng.integers(1, 6))
+        masks = [int(1 | (rng.integers(0, 1 << h) if rng.random() < 0.6 else 0)) for _ in range(k + 1)]
+        if rng.random() < 0.5:
+            masks[0] = masks[-1] = (1 << h) - 1
+        m2, times, d_fixed = helpers.reference_batch(3, k, n, dim, 9000 + trial, masks)
+        c_lit, f_lit, j_lit = onp.solve_batch(n, d, masks, times, d_fixed)
+        rc, co, fr, cost, st = helpers.emu_run(host_emu, n, dim, k, d, masks, times, d_fixed, 0)
+        # rank-deficient free systems (too few constraints for the null space of the cost, e.g. one segment with
+        # only the two end positions fixed): the reference's rank-revealing QR returns *a* minimiser, the kernel
+        # reports MTG_FLAG_SINGULAR or solves a numerically singular system -- only well-posed cases are compared
+        opt = onp.PolynomialOptimization(n, dim)
+        verts = [onp.Vertex(dim) for _ in range(k + 1)]
+        col = 0
+        for v in range(k + 1):
+            for p in range(h):
+                if (masks[v] >> p) & 1:
+                    verts[v].add_constraint(p, d_fixed[0, :, col])
+                    col += 1
+        opt.setup_from_vertices(verts, times[0], d)
+        if opt.n_free:
+            nf = opt.n_fixed
+            ev = np.linalg.eigvalsh(opt.construct_r()[nf:, nf:])
+            if ev.min() < 1e-11 * ev.max():
+                assert rc == 0
+                continue
+        assert rc == 0 and st == 0, (trial, n, d, k, dim, masks)
+        tol = 1e-8 if (n <= 10 and d == h - 1) else 1e-4
+        assert helpers.poly_relerr(co, c_lit) < tol, (trial, n, d, k, dim, masks)
+        assert helpers.check_path(masks, times, d_fixed, co) < 1e-6, (trial, n, d, k, dim, masks)
+        if j_lit.min() > 1e-9:
+            assert np.allclose(cost, j_lit, rtol=1e-5), (trial, n, d, k, dim, masks)
