@@ -54,3 +54,16 @@ def test_product_package_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert "oracle/" not in txt or f.endswith(".py") and "lives in oracle/" in txt, f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/mtg_hip.h compiles as C99 and a C program links against libmtg_hip.so (argument-validation calls only)."""
+    import subprocess
+    exe = str(tmp_path / "abi_is_c")
+    csrc = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_is_c.c"), "-o", exe, "-L" + csrc, "-lmtg_hip",
+                           "-Wl,-rpath," + csrc])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "C ABI ok" in r.stdout
