@@ -2,11 +2,12 @@
 // (reference: polynomial_optimization_linear.h:45-284) whose solveLinear() / setFreeConstraints() forward to the
 // MI355X library through the C ABI (include/mtg_hip.h).  Host code only: no HIP headers, Eigen optional.
 //
-// Kept: constructor, setupFromVertices, updateSegmentTimes, solveLinear, getSegments, getVertices,
-// getSegmentTimes, get/setFreeConstraints, getFixedConstraints, computeCost, the static matrix helpers, the
-// counters and the dense accessors getA / getAInverse / getM / getR / getMpinv.  Not provided (post-solve
-// analysis, out of scope per SURVEY.md section 2): getTrajectory, computeSegmentMaximumMagnitudeCandidates*,
-// computeMaximumOfMagnitude.  New: PolynomialOptimizationBatch<N>, the batched (accelerated) entry.
+// Kept: every public member of the reference class -- constructor, setupFromVertices, updateSegmentTimes,
+// solveLinear, getTrajectory, getSegments, getVertices, getSegmentTimes, get/setFreeConstraints,
+// getFixedConstraints, computeCost, the static matrix helpers, the counters, the dense accessors getA /
+// getAInverse / getM / getR / getMpinv and the magnitude-extremum helpers (host code; real roots by derivative
+// recursion + bisection instead of the reference's Jenkins-Traub translation).  Only setupFromPositons, which the
+// reference declares but never defines (LINH:79), is absent.  New: PolynomialOptimizationBatch<N>, the batched entry.
 //
 // Value semantics are preserved (the optimiser is copy-assigned in the wild, time_evaluation_node.cpp:357): the
 // object owns only host data plus a shared, immutable plan handle; device scratch lives in a per-thread context.
@@ -14,12 +15,15 @@
 #define MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
 #include <cmath>
 #include <memory>
+#include <numeric>
 #include <vector>
 
 #include "../../mtg_hip.h"
 #include "motion_defines.h"
 #include "polynomial.h"
+#include "extremum.h"
 #include "segment.h"
+#include "trajectory.h"
 #include "vertex.h"
 
 namespace mav_trajectory_generation {
@@ -140,6 +144,64 @@ class PolynomialOptimization {
       }
     }
     return 0.5 * cost;
+  }
+
+  void getTrajectory(Trajectory* trajectory) const { CHECK_NOTNULL(trajectory); trajectory->setSegments(segments_); }
+
+  // ---- extrema of |p^(derivative)| (post-solve helpers of the reference API; host code) ---------------------
+  template <int Derivative>
+  static bool computeSegmentMaximumMagnitudeCandidates(const Segment& segment, double t_start, double t_stop,
+                                                       std::vector<double>* candidates) {
+    return computeSegmentMaximumMagnitudeCandidates(Derivative, segment, t_start, t_stop, candidates);
+  }
+  static bool computeSegmentMaximumMagnitudeCandidates(int derivative, const Segment& segment, double t_start,
+                                                       double t_stop, std::vector<double>* candidates) {
+    CHECK(candidates != nullptr);
+    CHECK(N - derivative - 1 > 0) << "N-Derivative-1 has to be greater 0";
+    std::vector<int> dimensions(segment.D());
+    std::iota(dimensions.begin(), dimensions.end(), 0);
+    return segment.computeMinMaxMagnitudeCandidateTimes(derivative, t_start, t_stop, dimensions, candidates);
+  }
+  // Sampling variant (debugging aid in the reference): sign changes of d|.|/dt on a dt grid, plus both ends.
+  template <int Derivative>
+  static void computeSegmentMaximumMagnitudeCandidatesBySampling(const Segment& segment, double t_start, double t_stop,
+                                                                 double sampling_interval, std::vector<double>* candidates) {
+    CHECK_NOTNULL(candidates);
+    candidates->push_back(t_start);
+    double t_prev = t_start + sampling_interval;
+    double n_prev = segment.evaluate(t_prev, Derivative).norm();
+    double direction = n_prev - segment.evaluate(t_start, Derivative).norm();
+    for (double t = t_start + 2 * sampling_interval; t <= t_stop; t += sampling_interval) {
+      const double n_new = segment.evaluate(t, Derivative).norm();
+      const double direction_new = n_new - n_prev;
+      if (std::signbit(direction) != std::signbit(direction_new) && segment.evaluate(t_prev, Derivative + 1).norm() < 1e-2)
+        candidates->push_back(t_prev);
+      direction = direction_new;
+      n_prev = n_new;
+      t_prev = t;
+    }
+    if (candidates->back() != t_stop) candidates->push_back(t_stop);
+  }
+  template <int Derivative>
+  Extremum computeMaximumOfMagnitude(std::vector<Extremum>* candidates) const {
+    return computeMaximumOfMagnitude(Derivative, candidates);
+  }
+  Extremum computeMaximumOfMagnitude(int derivative, std::vector<Extremum>* candidates) const {
+    if (candidates != nullptr) candidates->clear();
+    Extremum best;
+    int idx = 0;
+    for (const Segment& s : segments_) {
+      std::vector<double> times;
+      computeSegmentMaximumMagnitudeCandidates(derivative, s, 0.0, s.getTime(), &times);
+      times.push_back(0.0);
+      for (double t : times) {
+        const Extremum c(t, s.evaluate(t, derivative).norm(), idx);
+        if (best < c) best = c;
+        if (candidates != nullptr) candidates->push_back(c);
+      }
+      ++idx;
+    }
+    return best;
   }
 
   void getVertices(Vertex::Vector* vertices) const { CHECK_NOTNULL(vertices); *vertices = vertices_; }

@@ -1,10 +1,11 @@
 // Compat veneer: Segment = D polynomials + duration (reference: segment.h:43-128, src/segment.cpp:41-81).
-// Extremum / min-max helpers are post-solve analysis and out of scope.
+// plus the magnitude-extremum candidate helpers (src/segment.cpp:83-159) used by computeMaximumOfMagnitude.
 #ifndef MAV_TRAJECTORY_GENERATION_SEGMENT_H_
 #define MAV_TRAJECTORY_GENERATION_SEGMENT_H_
 #include <cstdint>
 #include <vector>
 
+#include "extremum.h"
 #include "motion_defines.h"
 #include "polynomial.h"
 
@@ -32,6 +33,42 @@ class Segment {
     Eigen::VectorXd result(D_);
     for (int d = 0; d < D_; ++d) result[d] = polynomials_[d].evaluate(t, derivative);
     return result;
+  }
+
+  // Times where |p^(derivative)(t)| over `dimensions` can be extremal on [t_start, t_end]: interval ends and the real
+  // roots of d/dt |.|^2 = 2 sum_i p_i^(d) p_i^(d+1) (a convolution per dimension); one dimension: roots of p^(d+1).
+  bool computeMinMaxMagnitudeCandidateTimes(int derivative, double t_start, double t_end, const std::vector<int>& dimensions,
+                                            std::vector<double>* candidate_times) const {
+    CHECK_NOTNULL(candidate_times);
+    candidate_times->clear();
+    if (dimensions.empty()) return false;
+    for (int dim : dimensions) if (dim < 0 || dim >= D_) return false;
+    if (dimensions.size() == 1) return polynomials_[dimensions[0]].computeMinMaxCandidates(t_start, t_end, derivative, candidate_times);
+    const int n_d = N_ - derivative, n_dd = n_d - 1;
+    Eigen::VectorXd conv = Eigen::VectorXd::Zero(Polynomial::getConvolutionLength(n_d, n_dd));
+    for (int dim : dimensions) {
+      const Eigen::VectorXd full_d = polynomials_[dim].getCoefficients(derivative);
+      const Eigen::VectorXd full_dd = polynomials_[dim].getCoefficients(derivative + 1);
+      Eigen::VectorXd d(n_d), dd(n_dd);
+      for (int i = 0; i < n_d; ++i) d[i] = full_d[i];
+      for (int i = 0; i < n_dd; ++i) dd[i] = full_dd[i];
+      const Eigen::VectorXd c = Polynomial::convolve(d, dd);
+      for (int i = 0; i < conv.size(); ++i) conv[i] += c[i];
+    }
+    return Polynomial(conv).computeMinMaxCandidates(t_start, t_end, -1, candidate_times);
+  }
+  bool computeMinMaxMagnitudeCandidates(int derivative, double t_start, double t_end, const std::vector<int>& dimensions,
+                                        std::vector<Extremum>* candidates) const {
+    CHECK_NOTNULL(candidates);
+    std::vector<double> times;
+    if (!computeMinMaxMagnitudeCandidateTimes(derivative, t_start, t_end, dimensions, &times)) return false;
+    candidates->clear();
+    for (double t : times) {
+      double m = 0.0;
+      for (int dim : dimensions) { const double v = polynomials_[dim].evaluate(t, derivative); m += v * v; }
+      candidates->push_back(Extremum(t, std::sqrt(m), 0));
+    }
+    return true;
   }
 
  protected:

@@ -5,6 +5,7 @@
 //   setFreeConstraints round trip, copy-assignment (time_evaluation_node.cpp:357) and the batched entry.
 #include <cmath>
 #include <cstdio>
+#include <numeric>
 #include <vector>
 
 #include <mav_trajectory_generation/polynomial_optimization_linear.h>
@@ -150,6 +151,29 @@ int main() {
     copy.setFreeConstraints(free_c);
     EXPECT(copy.computeCost() > cost0, "perturbed cost %g <= optimal %g", copy.computeCost(), cost0);
     EXPECT(std::abs(opt.computeCost() - cost0) == 0.0, "original untouched by the copy");
+  }
+  // --- extrema of magnitude (test_polynomial_optimization.cpp:308-400 ExtremaOfMagnitude): analytic candidates vs 1 ms
+  //     sampling, velocity and acceleration, 3-D and 1-D ---------------------------------------------------------------
+  for (int D : {3, 1}) {
+    Vertex::Vector vertices = createRandomVertices(derivative_order::SNAP, 6, Eigen::VectorXd::Constant(D, -10.0),
+                                                   Eigen::VectorXd::Constant(D, 10.0), 321 + D);
+    std::vector<double> times = estimateSegmentTimes(vertices, 3.0, 5.0);
+    PolynomialOptimization<10> opt(D);
+    opt.setupFromVertices(vertices, times);
+    opt.solveLinear();
+    Trajectory trajectory;
+    opt.getTrajectory(&trajectory);
+    EXPECT(trajectory.K() == 6 && std::abs(trajectory.getMaxTime() - std::accumulate(times.begin(), times.end(), 0.0)) < 1e-12, "trajectory");
+    for (int derivative : {derivative_order::VELOCITY, derivative_order::ACCELERATION}) {
+      std::vector<Extremum> candidates;
+      const Extremum best = opt.computeMaximumOfMagnitude(derivative, &candidates);
+      double sampled = 0.0;
+      Segment::Vector segs;
+      opt.getSegments(&segs);
+      for (const Segment& s : segs) for (double t = 0.0; t <= s.getTime(); t += 1e-3) sampled = std::max(sampled, s.evaluate(t, derivative).norm());
+      EXPECT(best.value >= sampled - 1e-9 && best.value <= sampled * (1.0 + 1e-3) + 1e-6, "max |d%d| analytic %.9g vs sampled %.9g (D=%d)", derivative, best.value, sampled, D);
+      EXPECT(!candidates.empty(), "candidates");
+    }
   }
   // --- N = 12 with free end-vertex derivatives (test_feasibility.cpp:97-99) --------------------------------------
   {
