@@ -126,3 +126,19 @@ def test_randomised_shapes_and_masks(host_emu):
         assert helpers.check_path(masks, times, d_fixed, co) < 1e-6, (trial, n, d, k, dim, masks)
         if j_lit.min() > 1e-9:
             assert np.allclose(cost, j_lit, rtol=1e-5), (trial, n, d, k, dim, masks)
+
+
+def test_extreme_time_ratios_stay_closer_to_truth_than_the_literal_route(host_emu):
+    """Segment times log-uniform over three decades (ratios up to 1e3 between neighbouring segments): the problem
+    itself becomes ill-conditioned; the kernel's formulation (no inversion of A(T), scaled constants) must stay
+    orders of magnitude closer to the 50-digit solution than the literal float64 evaluation of the reference."""
+    from oracle import oracle_mp as omp
+    rng = np.random.default_rng(5)
+    masks, times, d_fixed = helpers.reference_batch(6, 8, 10, 3, 77)
+    times = np.exp(rng.uniform(np.log(0.05), np.log(50.0), times.shape))
+    c_mp, _, _ = omp.solve_batch(10, 4, masks, times, d_fixed)
+    c_lit, _, _ = onp.solve_batch(10, 4, masks, times, d_fixed)
+    rc, co, _, _, st = helpers.emu_run(host_emu, 10, 3, 8, 4, masks, times, d_fixed, 1)
+    assert rc == 0 and st == 0
+    e_kernel, e_lit = helpers.poly_relerr(co, c_mp), helpers.poly_relerr(c_lit, c_mp)
+    assert e_kernel < 1e-5 and e_kernel < 1e-2 * e_lit
