@@ -95,6 +95,9 @@ struct mtg_context {
   int* d_status = nullptr;
   int* h_status = nullptr;  // pinned
   int n_cu = 256;
+  // measurement knobs, read once from the environment at context creation (A/B runs in tools/; 0 = off)
+  int knob_force_dg = 0;        // MTG_FORCE_DG: dimension-group size of the specialised kernels
+  bool knob_prefer_rolled = false;   // MTG_PREFER_ROLLED: rolled variant even where a static one exists
   std::string last_error;
   std::mutex mu;
 };
@@ -210,10 +213,15 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   if (hipMalloc((void**)&ctx->d_status, sizeof(int)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess ||
       hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream) != hipSuccess) {
+    if (ctx->d_status) hipFree(ctx->d_status);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MTG_ERR_DEVICE;
   }
   *ctx->h_status = 0;
+  if (const char* e = getenv("MTG_FORCE_DG")) ctx->knob_force_dg = atoi(e);
+  ctx->knob_prefer_rolled = getenv("MTG_PREFER_ROLLED") != nullptr;
   *out = ctx;
   return MTG_OK;
 }
@@ -393,13 +401,13 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
         if (v) var = v;
       }
-      if (getenv("MTG_PREFER_ROLLED")) {   // measurement knob: rolled variant even where a static one exists
+      if (ctx->knob_prefer_rolled) {
         const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
         if (v) var = v;
       }
-      if (const char* e = getenv("MTG_FORCE_DG")) {   // measurement knob: force the dimension-group size
-        const int dg = atoi(e);
-        if (dg > 0 && p->D % dg == 0) {
+      if (ctx->knob_force_dg > 0) {
+        const int dg = ctx->knob_force_dg;
+        if (p->D % dg == 0) {
           const MtgStaticEntry* v = mtg_find_static(p->H, dg, p->K, p->deriv, p->mask.data());
           if (v) var = v;
         }
@@ -490,7 +498,8 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   MTG_HIP_TRY(ctx, hipEventCreate(&e0));
-  MTG_HIP_TRY(ctx, hipEventCreate(&e1));
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return set_err(ctx, MTG_ERR_DEVICE, "hipEventCreate"); }
+  struct EventGuard { hipEvent_t a, b; ~EventGuard() { hipEventDestroy(a); hipEventDestroy(b); } } guard{e0, e1};
   MTG_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   for (int i = 0; i < iters; ++i) {
     for (const LaunchRecord& r : p->last) {
@@ -502,8 +511,6 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   MTG_HIP_TRY(ctx, hipEventSynchronize(e1));
   float ms = 0.f;
   MTG_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
   *mean_us = (double)ms * 1000.0 / iters;
   return MTG_OK;
 }
