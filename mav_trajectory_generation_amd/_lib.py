@@ -43,6 +43,9 @@ EXPORTS = {
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
+    "mtg_sample_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                        c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_double_p, ctypes.c_void_p]),
     "mtg_time_last_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mtg_selftest_rcp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }

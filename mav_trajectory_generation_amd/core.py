@@ -49,6 +49,8 @@ class Context:
         _check(self.lib, self.lib.mtg_context_create(self.device, ctypes.c_void_p(self.stream.cuda_stream),
                                                      ctypes.byref(h)))
         self.handle = h
+        import weakref
+        self._plans = weakref.WeakSet()   # plans must be destroyed before their context
 
     def _enter(self):
         """Order the library's stream after torch's current stream (no-op when they are the same)."""
@@ -72,6 +74,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for p in list(getattr(self, "_plans", ())):
+                p.close()
             self.lib.mtg_context_destroy(self.handle)
             self.handle = None
 
@@ -80,6 +84,26 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def sample_range(ctx: "Context", coeffs, times, t_start: float, dt: float, n_samples: int, n_derivatives: int = 5,
+                 times_layout: str = "aos", want_valid: bool = False):
+    """Batched Trajectory::evaluateRange / sampleTrajectoryInRange: coeffs [B][K][D][N] and times ([B][K] 'aos' or
+    [K][B] 'soa') CUDA tensors -> out [B][n_samples][n_derivatives][D] (and n_valid [B] int32)."""
+    import torch
+    bsz, k, dim, n = coeffs.shape
+    assert coeffs.is_cuda and coeffs.dtype == torch.float64 and coeffs.is_contiguous() and times.is_contiguous()
+    out = torch.empty((bsz, n_samples, n_derivatives, dim), dtype=torch.float64, device=coeffs.device)
+    valid = torch.empty((bsz,), dtype=torch.int32, device=coeffs.device) if want_valid else None
+    sb, sk = (k, 1) if times_layout == "aos" else (1, bsz)
+    cur = ctx._enter()
+    rc = ctx.lib.mtg_sample_range(ctx.handle, n, k, dim, bsz, ctypes.c_void_p(coeffs.data_ptr()),
+                                  ctypes.c_void_p(times.data_ptr()), sb, sk, float(t_start), float(dt), n_samples,
+                                  n_derivatives, ctypes.c_void_p(out.data_ptr()),
+                                  ctypes.c_void_p(valid.data_ptr()) if valid is not None else None)
+    ctx._leave(cur)
+    _check(ctx.lib, rc, ctx.handle)
+    return (out, valid) if want_valid else out
 
 
 class Plan:
@@ -97,6 +121,7 @@ class Plan:
         h = ctypes.c_void_p()
         _check(self.lib, self.lib.mtg_plan_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)), ctx.handle)
         self.handle = h
+        ctx._plans.add(self)
         info = L.PlanInfo()
         _check(self.lib, self.lib.mtg_plan_get_info(h, ctypes.byref(info)))
         self.n_all, self.n_fixed, self.n_free = info.n_all, info.n_fixed, info.n_free
@@ -198,7 +223,8 @@ class Plan:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.mtg_plan_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):   # a plan outliving its context is already gone on the C side
+                self.lib.mtg_plan_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -237,6 +237,14 @@ int mtg_context_destroy(mtg_context* ctx) {
   return MTG_OK;
 }
 
+// used by the other translation units of the library (mtg_sample.hip): the context's stream and device
+int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device) {
+  if (!ctx || !stream || !device) return MTG_ERR_INVALID_ARGUMENT;
+  *stream = (void*)ctx->stream;
+  *device = ctx->device;
+  return MTG_OK;
+}
+
 int mtg_context_sync(mtg_context* ctx) {
   if (!ctx) return MTG_ERR_INVALID_ARGUMENT;
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -442,3 +442,53 @@ def solve_batch(n_coeffs: int, derivative: int, fixed_mask: Sequence[int],
             d_free[b, d] = opt.free_constraints_compact[d]
         cost[b] = opt.compute_cost()
     return coeffs, d_free, cost
+
+
+# --------------------------------------------------------------------------- sampling (next-step row N3)
+def polynomial_evaluate(coeffs: np.ndarray, t: float, derivative: int) -> float:
+    """polynomial.h:137-149: Horner on base_coefficients_(derivative, j) * c_j, highest power first."""
+    n = len(coeffs)
+    if derivative >= n:
+        return 0.0
+    tmp = n - 1
+    acc = BASE_COEFFICIENTS[derivative, tmp] * coeffs[tmp]
+    for j in range(tmp - 1, derivative - 1, -1):
+        acc *= t
+        acc += BASE_COEFFICIENTS[derivative, j] * coeffs[j]
+    return acc
+
+
+def trajectory_evaluate(segments: np.ndarray, times: Sequence[float], t: float, derivative: int) -> np.ndarray:
+    """src/trajectory.cpp:48-79 Trajectory::evaluate for segments [K][D][N] (t beyond the end: last segment, as the
+    reference does for t == max time; the batched kernel clamps such t to the end time)."""
+    accumulated = 0.0
+    i = 0
+    for i in range(len(times)):
+        accumulated += times[i]
+        if accumulated > t:
+            break
+    else:
+        i = len(times) - 1
+    accumulated -= times[i]
+    local = min(t - accumulated, times[i])
+    return np.array([polynomial_evaluate(segments[i, d], local, derivative) for d in range(segments.shape[1])])
+
+
+def sample_batch(coeffs: np.ndarray, times: np.ndarray, t_start: float, dt: float, n_samples: int,
+                 n_derivatives: int = 5):
+    """Batched restatement of sampleTrajectoryInRange (src/trajectory_sampling.cpp:45-110) with closed-form sample
+    times t_i = t_start + i*dt: out [B][S][ND][D], n_valid [B]."""
+    bsz, k, dim, _ = coeffs.shape
+    out = np.zeros((bsz, n_samples, n_derivatives, dim))
+    n_valid = np.zeros(bsz, dtype=np.int32)
+    for b in range(bsz):
+        total = 0.0
+        for i in range(k):
+            total += times[b, i]
+        for s in range(n_samples):
+            t = t_start + dt * s
+            if t <= total:
+                n_valid[b] += 1
+            for der in range(n_derivatives):
+                out[b, s, der] = trajectory_evaluate(coeffs[b], times[b], t, der)
+    return out, n_valid

@@ -356,3 +356,26 @@ def test_cost_only_and_mellinger_gradient(ctx):
     got = grad.cpu().numpy()
     assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
     plan.close()
+
+
+def test_batched_sampling_vs_oracle(ctx):
+    """mtg_sample_range (row N3) against the oracle restatement of Trajectory::evaluate / Polynomial::evaluate, incl.
+    samples past the end (clamped, counted out by n_valid), SoA times, N = 12 and D = 4."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    for (n, d, k, dim, bsz, S, nd) in [(10, 4, 8, 3, 37, 101, 5), (12, 5, 3, 4, 5, 64, 5), (8, 3, 5, 1, 9, 33, 3)]:
+        masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 515 + n)
+        plan = m.Plan(ctx, n, dim, k, d, masks)
+        t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
+        co, _, _ = plan.solve(t, f)
+        dt = float(times.sum(axis=1).max()) / (S - 7)     # the longest trajectory also runs past its end
+        out, nv = m.sample_range(ctx, co, t, 0.0, dt, S, nd, want_valid=True)
+        out_soa = m.sample_range(ctx, co, t.t().contiguous(), 0.0, dt, S, nd, times_layout="soa")
+        ctx.sync()
+        want, want_nv = onp.sample_batch(co.cpu().numpy(), times, 0.0, dt, S, nd)
+        got = out.cpu().numpy()
+        scale = np.abs(want).max(axis=(1, 3), keepdims=True) + 1e-300
+        assert (np.abs(got - want) / scale).max() < 1e-11
+        assert np.array_equal(nv.cpu().numpy(), want_nv)
+        assert torch.equal(out, out_soa)
+        plan.close()

@@ -170,3 +170,21 @@ def test_mp_single_matches_batch():
     c = case("readme")
     co, _, _ = omp.solve(10, 4, list(c["masks"]), c["times"][0], c["d_fixed"][0])
     assert np.array_equal(co, c["coeffs_mp"][0])
+
+
+def test_sampling_restatement_vs_numpy_polynomials():
+    """oracle sample_batch (Trajectory::evaluate + Polynomial::evaluate restatement) vs numpy's own polynomial
+    derivative evaluation on the README example."""
+    c = case("readme")
+    coeffs, times = c["coeffs_mp"], c["times"]
+    out, nv = onp.sample_batch(coeffs, times, 0.0, 0.37, 25, 5)
+    total = times[0].sum()
+    assert nv[0] == int(total / 0.37) + 1
+    for s in range(25):
+        t = min(0.37 * s, total)
+        seg = 0 if t < times[0, 0] else 1
+        local = t - (times[0, 0] if seg else 0.0)
+        for der in range(5):
+            for d in range(3):
+                p = np.polynomial.Polynomial(coeffs[0, seg, d]).deriv(der) if der else np.polynomial.Polynomial(coeffs[0, seg, d])
+                assert abs(out[0, s, der, d] - p(local)) <= 1e-12 * (1 + abs(p(local)))
