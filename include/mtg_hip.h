@@ -143,6 +143,41 @@ int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments, int
                      double t_start, double dt, int32_t n_samples, int32_t n_derivatives, double* out,
                      int32_t* n_valid);
 
+/* ---- next step after the path: batched magnitude extrema and feasibility time scaling ---- */
+/* Replaces, for a batch, Trajectory::computeMinMaxMagnitude (src/trajectory.cpp:190-227) over
+ * Segment::computeMinMaxMagnitudeCandidates / selectMinMaxMagnitudeFromCandidates (src/segment.cpp:83-184):
+ * extrema over [0, T_k] of  sqrt(sum_{dim in mask} (p_dim^(derivative)(t))^2)  for every segment.
+ *   dimension_mask       bit d set = dimension d enters the magnitude (0 = all `dimension` of them); with exactly
+ *                        one bit the candidates are the critical points of that polynomial (segment.cpp:124-131)
+ *   segment_minmax   out [batch][K][4] = (t_min, v_min, t_max, v_max), times relative to the segment start
+ *                        (Extremum::time, extremum.h:40-41); required, 16-byte aligned
+ *   trajectory_minmax out optional [batch][4]: first segment with the strictly smallest / largest value
+ *   trajectory_segment_idx out optional [batch][2] = (Extremum::segment_idx of the minimum, of the maximum)
+ * The real roots of the magnitude derivative are isolated directly instead of running Jenkins-Traub
+ * (src/rpoly/rpoly_ak1.cpp) -- same extrema values; extremum TIMES agree only where the root is well conditioned.
+ * Needs n_coeffs - derivative - 1 >= 0 (polynomial.cpp:70-73).  Device pointers; asynchronous.               */
+int mtg_minmax_magnitude(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments, int32_t dimension, int64_t batch,
+                         const double* coeffs, const double* times, int64_t times_stride_b, int64_t times_stride_k,
+                         int32_t derivative, uint32_t dimension_mask, double* segment_minmax,
+                         double* trajectory_minmax, int32_t* trajectory_segment_idx);
+
+/* Replaces, for a batch, Trajectory::scaleSegmentTimesToMeetConstraints(v_max, a_max) (src/trajectory.cpp:385-429)
+ * on top of computeMaxVelocityAndAcceleration (:343-361): `max_iterations` rounds of { maximum |velocity| and
+ * |acceleration| over all dimensions; if either exceeds its bound by more than 1e-3 relative, stretch every
+ * segment time by s = max(1, v_act/v_max, sqrt(a_act/a_max)) and rescale the coefficients by (1/s)^n }.
+ * The reference allows up to 20 rounds but stretching by s meets both bounds exactly, so round 2 only verifies;
+ * pass 2 for the reference's result, 1 to skip the verification.  In place on coeffs [batch][K][D][N] and times.
+ *   workspace     [8 * batch * (K + 1)] doubles, 16-byte aligned; afterwards holds the last round's
+ *                 per-segment tables [2][batch][K][4] and per-trajectory extrema [2][batch][4] (0 = velocity,
+ *                 1 = acceleration), evaluated BEFORE that round's scaling
+ *   scaling   out optional [batch]: total factor applied to the segment times
+ *   within_range out optional [batch]: the reference's return value (1 = bounds met at the last check)       */
+int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments,
+                                                int32_t dimension, int64_t batch, double* coeffs, double* times,
+                                                int64_t times_stride_b, int64_t times_stride_k, double v_max,
+                                                double a_max, int32_t max_iterations, double* workspace,
+                                                double* scaling, int32_t* within_range);
+
 /* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
 /* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the
  * context's stream, bracketed by hipEvents recorded on that same stream; returns the mean

@@ -46,6 +46,13 @@ EXPORTS = {
     "mtg_sample_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                         c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_double_p, ctypes.c_void_p]),
+    "mtg_minmax_magnitude": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                            c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_uint32, c_double_p, c_double_p, ctypes.c_void_p]),
+    "mtg_scale_segment_times_to_meet_constraints": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_double_p, c_double_p,
+        ctypes.c_void_p]),
     "mtg_time_last_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mtg_selftest_rcp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }

@@ -106,6 +106,58 @@ def sample_range(ctx: "Context", coeffs, times, t_start: float, dt: float, n_sam
     return (out, valid) if want_valid else out
 
 
+def minmax_magnitude(ctx: "Context", coeffs, times, derivative: int, dimensions: Optional[Sequence[int]] = None,
+                     times_layout: str = "aos"):
+    """Batched Trajectory::computeMinMaxMagnitude: coeffs [B][K][D][N], times ([B][K] 'aos' / [K][B] 'soa') CUDA
+    tensors -> (segment_minmax [B][K][4], trajectory_minmax [B][4], trajectory_segment_idx [B][2] int32); the four
+    columns are (t_min, v_min, t_max, v_max) with segment-local times."""
+    import torch
+    bsz, k, dim, n = coeffs.shape
+    assert coeffs.is_cuda and coeffs.dtype == torch.float64 and coeffs.is_contiguous() and times.is_contiguous()
+    mask = 0
+    for d in (dimensions if dimensions is not None else range(dim)):
+        if d < 0 or d >= dim:
+            raise MtgError(-1, "dimension %d out of bounds [0..%d]" % (d, dim - 1))
+        mask |= 1 << d
+    seg = torch.empty((bsz, k, 4), dtype=torch.float64, device=coeffs.device)
+    traj = torch.empty((bsz, 4), dtype=torch.float64, device=coeffs.device)
+    idx = torch.empty((bsz, 2), dtype=torch.int32, device=coeffs.device)
+    sb, sk = (k, 1) if times_layout == "aos" else (1, bsz)
+    cur = ctx._enter()
+    rc = ctx.lib.mtg_minmax_magnitude(ctx.handle, n, k, dim, bsz, ctypes.c_void_p(coeffs.data_ptr()),
+                                      ctypes.c_void_p(times.data_ptr()), sb, sk, int(derivative), mask,
+                                      ctypes.c_void_p(seg.data_ptr()), ctypes.c_void_p(traj.data_ptr()),
+                                      ctypes.c_void_p(idx.data_ptr()))
+    ctx._leave(cur)
+    _check(ctx.lib, rc, ctx.handle)
+    return seg, traj, idx
+
+
+def scale_segment_times_to_meet_constraints(ctx: "Context", coeffs, times, v_max: float, a_max: float,
+                                            max_iterations: int = 2, times_layout: str = "aos", workspace=None):
+    """Batched Trajectory::scaleSegmentTimesToMeetConstraints, IN PLACE on coeffs [B][K][D][N] and times.
+    Returns (scaling [B], within_range [B] int32, workspace); workspace[2*B*K*4:].view(2, B, 4)[:, :, 3] are the
+    maximum |velocity| / |acceleration| seen by the last round's check."""
+    import torch
+    bsz, k, dim, n = coeffs.shape
+    assert coeffs.is_cuda and coeffs.dtype == torch.float64 and coeffs.is_contiguous() and times.is_contiguous()
+    need = 8 * bsz * (k + 1)
+    if workspace is None:
+        workspace = torch.empty((need,), dtype=torch.float64, device=coeffs.device)
+    assert workspace.numel() >= need and workspace.dtype == torch.float64
+    scaling = torch.empty((bsz,), dtype=torch.float64, device=coeffs.device)
+    within = torch.empty((bsz,), dtype=torch.int32, device=coeffs.device)
+    sb, sk = (k, 1) if times_layout == "aos" else (1, bsz)
+    cur = ctx._enter()
+    rc = ctx.lib.mtg_scale_segment_times_to_meet_constraints(
+        ctx.handle, n, k, dim, bsz, ctypes.c_void_p(coeffs.data_ptr()), ctypes.c_void_p(times.data_ptr()), sb, sk,
+        float(v_max), float(a_max), int(max_iterations), ctypes.c_void_p(workspace.data_ptr()),
+        ctypes.c_void_p(scaling.data_ptr()), ctypes.c_void_p(within.data_ptr()))
+    ctx._leave(cur)
+    _check(ctx.lib, rc, ctx.handle)
+    return scaling, within, workspace
+
+
 class Plan:
     def __init__(self, ctx: Context, n_coeffs: int, dimension: int, n_segments: int,
                  derivative_to_optimize: Optional[int], fixed_mask: Sequence[int]):

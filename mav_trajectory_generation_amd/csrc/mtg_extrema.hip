@@ -1,0 +1,220 @@
+// mtg_extrema.hip -- batched magnitude extrema + feasibility time scaling.
+//
+// Replaces, for a batch of solved trajectories (coeffs [B][K][D][N] as written by mtg_solve_linear):
+//   * Trajectory::computeMinMaxMagnitude (src/trajectory.cpp:190-227) over Segment::computeMinMaxMagnitude-
+//     Candidates / selectMinMaxMagnitudeFromCandidates (src/segment.cpp:83-184)            -> mtg_minmax_magnitude
+//   * Trajectory::computeMaxVelocityAndAcceleration (:343-361) + scaleSegmentTimesToMeetConstraints (:385-429)
+//                                                                          -> mtg_scale_segment_times_to_meet_constraints
+// The per-lane algorithm (real-root isolation by a compile-time derivative chain instead of the reference's
+// Jenkins-Traub) lives in mtg_extrema_lane.h.  Mapping: one lane per (trajectory, segment); blockIdx.y selects the
+// derivative (velocity / acceleration are searched in one launch for the scaling path).  The kernels are
+// FP64-latency bound, not HBM bound: ~10^4 dependent FMAs per lane against 240 B of coefficients read.  The root
+// list of each lane lives in LDS ([slot][lane] layout: lanes in lock-step hit distinct banks); everything else is
+// in registers with compile-time indices.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mtg_hip.h"
+#include "mtg_extrema_lane.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct ExtremaParams {
+  const double* coeffs;   // [B][K][D][N]
+  const double* times;    // times[b*ts_b + k*ts_k]
+  long long ts_b, ts_k;
+  double* seg_out;        // [n_slots][B][K][4]  (t_min, v_min, t_max, v_max), segment-local times
+  double* traj_out;       // [n_slots][B][4]
+  int* traj_seg;          // [n_slots][B][2] (segment of the minimum, of the maximum) or null
+  long long B;
+  int N, K, D;
+  unsigned mask;
+  int der[2];
+};
+
+struct LdsRoots {
+  double* p;   // lane's column: element i at p[i * kThreads]
+  __device__ double& operator[](int i) { return p[i * kThreads]; }
+};
+
+template <int NMAX>
+__global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
+  extern __shared__ double lds[];
+  const long long total = P.B * P.K;
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total) return;
+  const int slot = blockIdx.y;
+  const long long b = idx / P.K;
+  const int seg = (int)(idx - b * P.K);
+  const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
+  LdsRoots roots{lds + threadIdx.x};
+  const mtgx::MinMax mm =
+      mtgx::segment_minmax<NMAX>(P.coeffs + idx * (long long)(P.D * P.N), P.N, P.D, P.mask, P.der[slot], T, roots);
+  double* o = P.seg_out + ((long long)slot * total + idx) * 4;
+  reinterpret_cast<double2*>(o)[0] = make_double2(mm.t_min, mm.v_min);
+  reinterpret_cast<double2*>(o)[1] = make_double2(mm.t_max, mm.v_max);
+}
+
+// Trajectory::computeMinMaxMagnitude's outer loop (trajectory.cpp:199-225): first segment with a strictly
+// smaller / larger value wins.
+__global__ void mtg_minmax_traj_kernel(ExtremaParams P) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  const int slot = blockIdx.y;
+  const double* s = P.seg_out + ((long long)slot * P.B + b) * P.K * 4;
+  double t_min = 0.0, v_min = DBL_MAX, t_max = 0.0, v_max = -DBL_MAX;
+  int k_min = 0, k_max = 0;
+  for (int k = 0; k < P.K; ++k) {
+    const double2 lo = reinterpret_cast<const double2*>(s)[2 * k];
+    const double2 hi = reinterpret_cast<const double2*>(s)[2 * k + 1];
+    if (lo.y < v_min) { v_min = lo.y; t_min = lo.x; k_min = k; }
+    if (hi.y > v_max) { v_max = hi.y; t_max = hi.x; k_max = k; }
+  }
+  double* o = P.traj_out + ((long long)slot * P.B + b) * 4;
+  reinterpret_cast<double2*>(o)[0] = make_double2(t_min, v_min);
+  reinterpret_cast<double2*>(o)[1] = make_double2(t_max, v_max);
+  if (P.traj_seg) {
+    P.traj_seg[((long long)slot * P.B + b) * 2 + 0] = k_min;
+    P.traj_seg[((long long)slot * P.B + b) * 2 + 1] = k_max;
+  }
+}
+
+struct ScaleParams {
+  double* coeffs;
+  double* times;
+  long long ts_b, ts_k;
+  const double* traj_out;   // [2][B][4]: slot 0 velocity, slot 1 acceleration
+  double* scaling;          // [B] or null: product of the applied factors
+  int* within;              // [B] or null
+  long long B;
+  int N, K, D;
+  double v_max, a_max;
+  int first;
+};
+
+// One iteration body of scaleSegmentTimesToMeetConstraints (trajectory.cpp:398-425): lane per (b, segment, dim).
+__global__ void mtg_scale_kernel(ScaleParams P) {
+  const long long total = P.B * P.K * P.D;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long long bk = idx / P.D;
+  const int d = (int)(idx - bk * P.D);
+  const long long b = bk / P.K;
+  const int seg = (int)(bk - b * P.K);
+  const double v_act = P.traj_out[b * 4 + 3];
+  const double a_act = P.traj_out[(P.B + b) * 4 + 3];
+  bool within;
+  const double s = mtgx::violation_scaling(v_act, a_act, P.v_max, P.a_max, within);
+  if (seg == 0 && d == 0) {
+    if (P.within) P.within[b] = within ? 1 : 0;
+    if (P.scaling) P.scaling[b] = (P.first ? 1.0 : P.scaling[b]) * (within ? 1.0 : s);
+  }
+  if (within) return;   // the reference breaks out before scaling (:405-407)
+  const double inv = 1.0 / s;
+  double* c = P.coeffs + idx * (long long)P.N;
+  double scale = 1.0;
+  for (int n = 0; n < P.N; ++n) {   // Polynomial::scalePolynomialInTime (polynomial.cpp:199-205)
+    c[n] *= scale;
+    scale *= inv;
+  }
+  if (d == 0) P.times[b * P.ts_b + (long long)seg * P.ts_k] *= s;
+}
+
+template <int NMAX>
+void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
+  constexpr int L = 2 * NMAX - 2;
+  const long long total = P.B * P.K;
+  const size_t lds = (size_t)kThreads * (L - 1) * sizeof(double);
+  hipLaunchKernelGGL(mtg_minmax_seg_kernel<NMAX>, dim3((unsigned)((total + kThreads - 1) / kThreads), n_slots),
+                     dim3(kThreads), lds, stream, P);
+}
+
+int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream) {
+  int n_d = 0;
+  for (int s = 0; s < n_slots; ++s) {
+    const int nd = P.N - P.der[s];
+    if (nd > n_d) n_d = nd;
+  }
+  if (n_d <= 7) launch_seg<7>(P, n_slots, stream);
+  else if (n_d <= 9) launch_seg<9>(P, n_slots, stream);
+  else if (n_d <= 11) launch_seg<11>(P, n_slots, stream);
+  else launch_seg<12>(P, n_slots, stream);
+  if (P.traj_out)
+    hipLaunchKernelGGL(mtg_minmax_traj_kernel, dim3((unsigned)((P.B + 255) / 256), n_slots), dim3(256), 0, stream, P);
+  return hipGetLastError() == hipSuccess ? MTG_OK : MTG_ERR_DEVICE;
+}
+
+int check_common(mtg_context* ctx, int n_coeffs, int n_segments, int dimension, int64_t batch, const void* coeffs,
+                 const void* times) {
+  if (!ctx || !coeffs || !times || batch < 0 || n_coeffs < 2 || n_coeffs > MTG_MAX_N || n_segments < 1 ||
+      dimension < 1 || dimension > 32)
+    return MTG_ERR_INVALID_ARGUMENT;
+  return MTG_OK;
+}
+
+}  // namespace
+
+extern "C" int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device);
+
+extern "C" int mtg_minmax_magnitude(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments, int32_t dimension,
+                                    int64_t batch, const double* coeffs, const double* times, int64_t times_stride_b,
+                                    int64_t times_stride_k, int32_t derivative, uint32_t dimension_mask,
+                                    double* segment_minmax, double* trajectory_minmax, int32_t* trajectory_segment_idx) {
+  int rc = check_common(ctx, n_coeffs, n_segments, dimension, batch, coeffs, times);
+  if (rc != MTG_OK) return rc;
+  // N - derivative - 1 >= 0 (polynomial.cpp:70-73); a trajectory-level result needs the per-segment table
+  if (!segment_minmax || derivative < 0 || n_coeffs - derivative - 1 < 0) return MTG_ERR_INVALID_ARGUMENT;
+  const uint32_t all = dimension >= 32 ? 0xffffffffu : ((1u << dimension) - 1u);
+  if (dimension_mask == 0) dimension_mask = all;
+  if (dimension_mask & ~all) return MTG_ERR_INVALID_ARGUMENT;   // "dimensions out of bounds" (segment.cpp:102-107)
+  if (batch == 0) return MTG_OK;
+  void* stream = nullptr;
+  int device = 0;
+  rc = mtg_context_stream_device(ctx, &stream, &device);
+  if (rc != MTG_OK) return rc;
+  if (hipSetDevice(device) != hipSuccess) return MTG_ERR_DEVICE;
+  ExtremaParams P;
+  P.coeffs = coeffs; P.times = times; P.ts_b = times_stride_b; P.ts_k = times_stride_k;
+  P.seg_out = segment_minmax; P.traj_out = trajectory_minmax; P.traj_seg = trajectory_minmax ? trajectory_segment_idx : nullptr;
+  P.B = batch; P.N = n_coeffs; P.K = n_segments; P.D = dimension; P.mask = dimension_mask;
+  P.der[0] = derivative; P.der[1] = derivative;
+  return launch_minmax(P, 1, (hipStream_t)stream);
+}
+
+extern "C" int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments,
+                                                           int32_t dimension, int64_t batch, double* coeffs,
+                                                           double* times, int64_t times_stride_b, int64_t times_stride_k,
+                                                           double v_max, double a_max, int32_t max_iterations,
+                                                           double* workspace, double* scaling, int32_t* within_range) {
+  int rc = check_common(ctx, n_coeffs, n_segments, dimension, batch, coeffs, times);
+  if (rc != MTG_OK) return rc;
+  if (!workspace || max_iterations < 1 || !(v_max > 0.0) || !(a_max > 0.0) || n_coeffs < 3) return MTG_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return MTG_OK;
+  void* stream = nullptr;
+  int device = 0;
+  rc = mtg_context_stream_device(ctx, &stream, &device);
+  if (rc != MTG_OK) return rc;
+  if (hipSetDevice(device) != hipSuccess) return MTG_ERR_DEVICE;
+  ExtremaParams P;
+  P.coeffs = coeffs; P.times = times; P.ts_b = times_stride_b; P.ts_k = times_stride_k;
+  P.seg_out = workspace;
+  P.traj_out = workspace + (size_t)2 * batch * n_segments * 4;
+  P.traj_seg = nullptr;
+  P.B = batch; P.N = n_coeffs; P.K = n_segments; P.D = dimension;
+  P.mask = dimension >= 32 ? 0xffffffffu : ((1u << dimension) - 1u);   // "whatever dimensions we have" (trajectory.cpp:346-347)
+  P.der[0] = 1;   // derivative_order::VELOCITY
+  P.der[1] = 2;   // derivative_order::ACCELERATION
+  ScaleParams S;
+  S.coeffs = coeffs; S.times = times; S.ts_b = times_stride_b; S.ts_k = times_stride_k; S.traj_out = P.traj_out;
+  S.scaling = scaling; S.within = within_range; S.B = batch; S.N = n_coeffs; S.K = n_segments; S.D = dimension;
+  S.v_max = v_max; S.a_max = a_max;
+  const long long total = (long long)batch * n_segments * dimension;
+  for (int it = 0; it < max_iterations; ++it) {
+    rc = launch_minmax(P, 2, (hipStream_t)stream);
+    if (rc != MTG_OK) return rc;
+    S.first = it == 0;
+    hipLaunchKernelGGL(mtg_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S);
+  }
+  return hipGetLastError() == hipSuccess ? MTG_OK : MTG_ERR_DEVICE;
+}

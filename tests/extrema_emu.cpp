@@ -1,0 +1,43 @@
+// Host emulation of the device lane code of the extrema search (mtg_extrema_lane.h): the SAME header the HIP
+// kernel compiles, run lane-by-lane on the CPU so the algorithm can be checked against the oracle without a GPU.
+// Test infrastructure only.
+#include "../mav_trajectory_generation_amd/csrc/mtg_extrema_lane.h"
+
+namespace {
+struct LocalRoots {
+  double v[24];
+  double& operator[](int i) { return v[i]; }
+};
+
+template <int NMAX>
+void run(int N, int K, int D, long long B, const double* coeffs, const double* times, int der, unsigned mask, double* out) {
+  for (long long idx = 0; idx < B * K; ++idx) {
+    LocalRoots roots;
+    const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots);
+    out[idx * 4 + 0] = mm.t_min;
+    out[idx * 4 + 1] = mm.v_min;
+    out[idx * 4 + 2] = mm.t_max;
+    out[idx * 4 + 3] = mm.v_max;
+  }
+}
+}  // namespace
+
+// times = [B][K]; out = [B][K][4]
+extern "C" int extrema_emu_segments(int N, int K, int D, long long B, const double* coeffs, const double* times,
+                                    int der, unsigned mask, double* out) {
+  const int n_d = N - der;
+  if (n_d < 1 || N > 12) return -1;
+  if (n_d <= 7) run<7>(N, K, D, B, coeffs, times, der, mask, out);
+  else if (n_d <= 9) run<9>(N, K, D, B, coeffs, times, der, mask, out);
+  else if (n_d <= 11) run<11>(N, K, D, B, coeffs, times, der, mask, out);
+  else run<12>(N, K, D, B, coeffs, times, der, mask, out);
+  return 0;
+}
+
+// all real roots in [0, 1] of sum g[j] tau^j (j < 22), for direct root-finder tests
+extern "C" int extrema_emu_roots22(const double* g, double* roots_out) {
+  LocalRoots roots;
+  const int cnt = mtgx::real_roots_unit<22>(g, roots);
+  for (int i = 0; i < cnt; ++i) roots_out[i] = roots[i];
+  return cnt;
+}
