@@ -137,7 +137,7 @@ int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layou
  *   out[b][i][der][dim] = der-th derivative of dimension dim at t_i = t_start + i*dt,  i < n_samples,
  * der < n_derivatives (5 = position .. snap), from coeffs[batch][K][D][N] and times[b*stride_b + k*stride_k].
  * Samples beyond a trajectory's end are evaluated at its end; n_valid[b] (optional) = number of samples with
- * t_i <= total time.  Device pointers; asynchronous on the context's stream.                              */
+ * t_i <= total time.  Device pointers (out 16-byte aligned); asynchronous on the context's stream.          */
 int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments, int32_t dimension, int64_t batch,
                      const double* coeffs, const double* times, int64_t times_stride_b, int64_t times_stride_k,
                      double t_start, double dt, int32_t n_samples, int32_t n_derivatives, double* out,

@@ -137,7 +137,9 @@ int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream) {
     if (nd > n_d) n_d = nd;
   }
   if (n_d <= 7) launch_seg<7>(P, n_slots, stream);
+  else if (n_d <= 8) launch_seg<8>(P, n_slots, stream);
   else if (n_d <= 9) launch_seg<9>(P, n_slots, stream);
+  else if (n_d <= 10) launch_seg<10>(P, n_slots, stream);
   else if (n_d <= 11) launch_seg<11>(P, n_slots, stream);
   else launch_seg<12>(P, n_slots, stream);
   if (P.traj_out)

@@ -61,15 +61,18 @@ MTGX_HD void horner2(const double* a, double x, double& f, double& df) {   // va
   }
 }
 
-constexpr double kRootTol = 4e-15;   // absolute, in tau in [0, 1]
-constexpr int kRootMaxIter = 100;    // pure bisection needs ~48
+constexpr double kRootTol = 4e-15;        // absolute, in tau in [0, 1]: roots of g itself (the candidates)
+constexpr double kPartitionTol = 1e-7;    // roots of the derivative levels only partition [0, 1] for the next level
+constexpr int kRootMaxIter = 100;         // pure bisection needs ~48
 
 // One root of the degree-K polynomial a in [lo, hi], given f(lo), f(hi) of opposite sign and a monotone there.
 template <int K>
-MTGX_HD double bracketed_root(const double* a, double lo, double hi, double flo) {
+MTGX_HD double bracketed_root(const double* a, double lo, double hi, double flo, double fhi, double tol) {
   double xl = flo < 0.0 ? lo : hi;   // f(xl) < 0 <= f(xh)
   double xh = flo < 0.0 ? hi : lo;
-  double x = 0.5 * (lo + hi);
+  // start from the chord's zero (inside the bracket by construction), nudged off the end points
+  double x = lo - flo * (hi - lo) / (fhi - flo);
+  if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
   double dxold = fabs(hi - lo), dx = dxold;
   double f, df;
   horner2<K>(a, x, f, df);
@@ -84,7 +87,7 @@ MTGX_HD double bracketed_root(const double* a, double lo, double hi, double flo)
       dx = f / df;
       x -= dx;
     }
-    if (fabs(dx) < kRootTol) break;
+    if (fabs(dx) < tol) break;
     horner2<K>(a, x, f, df);
     if (f < 0.0) xl = x; else xh = x;
   }
@@ -102,7 +105,7 @@ struct Level {
       const double hi = i < cnt ? roots[i] : 1.0;
       const double fhi = horner<K>(a, hi);
       if ((flo < 0.0) != (fhi < 0.0)) {
-        const double r = bracketed_root<K>(a, lo, hi, flo);
+        const double r = bracketed_root<K>(a, lo, hi, flo, fhi, K < M ? kPartitionTol : kRootTol);
         roots[cnt_new] = r;   // cnt_new <= i and roots[i] was already read: in-place is safe
         ++cnt_new;
       }

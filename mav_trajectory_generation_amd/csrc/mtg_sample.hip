@@ -11,11 +11,14 @@
 // reported through n_valid[b] instead of being dropped.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "../../include/mtg_hip.h"
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kMaxN = MTG_MAX_N;
 
 struct SampleParams {
   const double* coeffs;   // [B][K][D][N]
@@ -33,39 +36,59 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, lo
   extern __shared__ double lds[];
   const int R = ND * P.D;          // results per lane
   const int RP = R | 1;            // odd row stride: conflict-free ds_write_b64
-  const int qstep = kThreads / R, rstep = kThreads - qstep * R;   // (owner, r) advance per 256 elements
-  for (long long base = (long long)blockIdx.x * kThreads; base < total; base += (long long)gridDim.x * kThreads) {
-    const long long idx = base + threadIdx.x;
-    if (idx < total) {
-      const long long b = idx / P.S;
-      const int s = (int)(idx - b * P.S);
+  // (trajectory, sample) of the block's first lane, advanced incrementally: one 64-bit division per thread per launch
+  const long long step = (long long)gridDim.x * kThreads;
+  const long long step_b = step / P.S;
+  const int step_s = (int)(step - step_b * P.S);
+  long long blk_b = ((long long)blockIdx.x * kThreads) / P.S;
+  int blk_s = (int)((long long)blockIdx.x * kThreads - blk_b * P.S);
+  for (long long base = (long long)blockIdx.x * kThreads; base < total; base += step) {
+    if (base + threadIdx.x < total) {
+      const unsigned off = (unsigned)blk_s + threadIdx.x;
+      const unsigned q = off / (unsigned)P.S;
+      const long long b = blk_b + q;
+      const int s = (int)(off - q * (unsigned)P.S);
       const double t = P.t_start + P.dt * s;
       // segment lookup: the first segment whose accumulated end time exceeds t (src/trajectory.cpp:52-66);
       // t at or beyond the last vertex -> last segment, clamped to its end
       const double* tt = P.times + b * P.ts_b;
+      // branch-free scan (no early exit: the loads of all K times are independent and stay in flight together)
       double acc = 0.0, seg_start = 0.0, seg_time = 0.0;
       int seg = 0;
+      bool found = false;
+#pragma unroll 4
       for (int i = 0; i < P.K; ++i) {
-        seg_time = tt[(long long)i * P.ts_k];
-        seg_start = acc;
-        seg = i;
-        acc += seg_time;
-        if (acc > t) break;
+        const double ti = tt[(long long)i * P.ts_k];
+        if (!found) { seg_time = ti; seg_start = acc; seg = i; }
+        acc += ti;
+        found = found || acc > t;
       }
       double local = t - seg_start;
       if (local > seg_time) local = seg_time;
       const double* c = P.coeffs + ((b * P.K + seg) * P.D) * (long long)P.N;
+      // coefficients of one dimension are loaded as a batch (static register indices, uniform j < N guards) and the
+      // next dimension's batch is issued before this one is consumed: one memory latency per lane, not N * D
+      double cur[kMaxN], nxt[kMaxN];
+#pragma unroll
+      for (int j = 0; j < kMaxN; ++j) cur[j] = j < P.N ? c[j] : 0.0;
       for (int d = 0; d < P.D; ++d) {
-        const double* cd = c + (long long)d * P.N;
+        if (d + 1 < P.D) {
+          const double* cn = c + (d + 1) * P.N;
+#pragma unroll
+          for (int j = 0; j < kMaxN; ++j) nxt[j] = j < P.N ? cn[j] : 0.0;
+        }
         // all derivatives in one pass: a[m] accumulates p^(m)(t) / m!  (Horner with derivatives; polynomial.h:137-149
         // evaluates each derivative with its own Horner loop -- same values to rounding)
         double a[ND];
 #pragma unroll
         for (int m = 0; m < ND; ++m) a[m] = 0.0;
-        for (int j = P.N - 1; j >= 0; --j) {
 #pragma unroll
-          for (int m = ND - 1; m >= 1; --m) a[m] = __builtin_fma(a[m], local, a[m - 1]);
-          a[0] = __builtin_fma(a[0], local, cd[j]);
+        for (int j = kMaxN - 1; j >= 0; --j) {
+          if (j < P.N) {
+#pragma unroll
+            for (int m = ND - 1; m >= 1; --m) a[m] = __builtin_fma(a[m], local, a[m - 1]);
+            a[0] = __builtin_fma(a[0], local, cur[j]);
+          }
         }
         double fact = 1.0;
 #pragma unroll
@@ -73,17 +96,32 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, lo
           if (m > 1) fact *= (double)m;
           lds[threadIdx.x * RP + m * P.D + d] = a[m] * fact;
         }
+#pragma unroll
+        for (int j = 0; j < kMaxN; ++j) cur[j] = nxt[j];
       }
     }
+    blk_b += step_b;
+    blk_s += step_s;
+    if (blk_s >= P.S) { blk_s -= P.S; ++blk_b; }
     __syncthreads();
-    // coalesced write-out of this block's contiguous [kThreads][R] slab (element e belongs to lane e / R)
+    // coalesced write-out of this block's contiguous [kThreads][R] slab, two doubles (16 B) per lane per store;
+    // element e belongs to lane e / R.  The slab starts 16-byte aligned (base is a multiple of kThreads).
     const long long slab = base * R;
     const int slab_len = (int)((total - base < kThreads ? total - base : kThreads) * R);
-    int owner = (int)threadIdx.x / R, r = (int)threadIdx.x - owner * R;
-    for (int e = threadIdx.x; e < slab_len; e += kThreads) {
-      P.out[slab + e] = lds[owner * RP + r];
-      owner += qstep;
-      r += rstep;
+    const int e0 = 2 * (int)threadIdx.x;
+    int owner = e0 / R, r = e0 - owner * R;
+    const int qstep2 = (2 * kThreads) / R, rstep2 = 2 * kThreads - qstep2 * R;
+    for (int e = e0; e < slab_len; e += 2 * kThreads) {
+      const double v0 = lds[owner * RP + r];
+      const int o1 = r + 1 == R ? owner + 1 : owner, r1 = r + 1 == R ? 0 : r + 1;
+      if (e + 1 < slab_len) {
+        const double v1 = lds[o1 * RP + r1];
+        *reinterpret_cast<double2*>(P.out + slab + e) = make_double2(v0, v1);
+      } else {
+        P.out[slab + e] = v0;
+      }
+      owner += qstep2;
+      r += rstep2;
       if (r >= R) { r -= R; ++owner; }
     }
     __syncthreads();
@@ -119,6 +157,7 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
   if (!ctx || !coeffs || !times || !out || batch < 0 || n_samples < 1 || n_derivatives < 1 || n_coeffs < 2 ||
       n_coeffs > MTG_MAX_N || n_segments < 1 || dimension < 1 || !(dt > 0.0))
     return MTG_ERR_INVALID_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(out) & 15u) return MTG_ERR_INVALID_ARGUMENT;   // 16-byte stores
   if (n_derivatives > 5 || n_derivatives * dimension > 64) return MTG_ERR_UNSUPPORTED;
   if (batch == 0) return MTG_OK;
   void* stream = nullptr;

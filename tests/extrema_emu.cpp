@@ -28,7 +28,9 @@ extern "C" int extrema_emu_segments(int N, int K, int D, long long B, const doub
   const int n_d = N - der;
   if (n_d < 1 || N > 12) return -1;
   if (n_d <= 7) run<7>(N, K, D, B, coeffs, times, der, mask, out);
+  else if (n_d <= 8) run<8>(N, K, D, B, coeffs, times, der, mask, out);
   else if (n_d <= 9) run<9>(N, K, D, B, coeffs, times, der, mask, out);
+  else if (n_d <= 10) run<10>(N, K, D, B, coeffs, times, der, mask, out);
   else if (n_d <= 11) run<11>(N, K, D, B, coeffs, times, der, mask, out);
   else run<12>(N, K, D, B, coeffs, times, der, mask, out);
   return 0;
