@@ -85,50 +85,73 @@ class Polynomial {
   }
   static inline int getConvolutionLength(int data_size, int kernel_size) { return data_size + kernel_size - 1; }
 
-  // All real roots of sum c[i] t^i inside [a, b]: the roots of the derivative (found recursively) split the
-  // interval into monotone pieces; each piece with a sign change is bisected.  Degenerate (identically zero)
-  // polynomials have no isolated roots.
+  // All real roots of sum c[i] t^i inside [a, b].  Same method as the device code (csrc/mtg_extrema_lane.h): map
+  // [a, b] to tau in [0, 1], then walk the derivative chain upwards -- between two consecutive roots of the
+  // (k+1)-th derivative the k-th derivative is monotone, so every sign change brackets exactly one root, found by
+  // bisection-safeguarded Newton.  Only exactly-zero leading coefficients are stripped (the reference strips
+  // |c| < DBL_MIN, rpoly_ak1.cpp:57-68); identically zero polynomials have no isolated roots.
   static void realRootsInInterval(std::vector<double> c, double a, double b, std::vector<double>* roots) {
     roots->clear();
-    double scale = 0.0;
-    for (double x : c) scale = std::max(scale, std::abs(x));
-    while (!c.empty() && std::abs(c.back()) <= 1e-14 * scale) c.pop_back();   // true degree
+    while (!c.empty() && c.back() == 0.0) c.pop_back();
     if (c.size() < 2 || !(a <= b)) return;
-    auto eval = [&](double t) { double v = 0.0; for (size_t i = c.size(); i-- > 0;) v = v * t + c[i]; return v; };
-    if (c.size() == 2) {
-      const double r = -c[0] / c[1];
-      if (r >= a && r <= b) roots->push_back(r);
-      return;
-    }
-    std::vector<double> dc(c.size() - 1), crit;
-    for (size_t i = 1; i < c.size(); ++i) dc[i - 1] = c[i] * (double)i;
-    realRootsInInterval(dc, a, b, &crit);
-    std::vector<double> knots;
-    knots.push_back(a);
-    for (double t : crit) if (t > knots.back()) knots.push_back(t);
-    if (b > knots.back()) knots.push_back(b);
-    const double ftol = 1e-13 * scale;
-    for (size_t i = 0; i + 1 < knots.size(); ++i) {
-      double lo = knots[i], hi = knots[i + 1];
-      double flo = eval(lo), fhi = eval(hi);
-      if (std::abs(flo) <= ftol * std::max(1.0, std::pow(std::max(std::abs(lo), 1.0), (double)c.size() - 1))) {
-        if (roots->empty() || lo > roots->back()) roots->push_back(lo);   // root at a knot (incl. double roots)
-        continue;
+    const int m = (int)c.size() - 1;
+    const double w = b - a;
+    if (w == 0.0) return;
+    // q(tau) = p(a + w tau): Taylor shift by a (repeated synthetic division), then scale coefficient j by w^j
+    std::vector<double> q(c);
+    if (a != 0.0)
+      for (int i = 0; i < m; ++i)
+        for (int j = m - 1; j >= i; --j) q[j] += a * q[j + 1];
+    double wp = 1.0;
+    for (int j = 0; j <= m; ++j) { q[j] *= wp; wp *= w; }
+    auto horner = [](const std::vector<double>& p, double x) {
+      double r = 0.0;
+      for (size_t i = p.size(); i-- > 0;) r = r * x + p[i];
+      return r;
+    };
+    auto bracketed = [](const std::vector<double>& p, double lo, double hi, double flo, double fhi) {
+      auto eval2 = [&p](double x, double* f, double* df) {
+        *f = 0.0; *df = 0.0;
+        for (size_t i = p.size(); i-- > 0;) { *df = *df * x + *f; *f = *f * x + p[i]; }
+      };
+      double xl = flo < 0.0 ? lo : hi, xh = flo < 0.0 ? hi : lo;
+      double x = lo - flo * (hi - lo) / (fhi - flo);
+      if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
+      double dxold = std::abs(hi - lo), dx = dxold, f, df;
+      eval2(x, &f, &df);
+      for (int it = 0; it < 200; ++it) {
+        const bool leaves = ((x - xh) * df - f) * ((x - xl) * df - f) > 0.0;
+        const bool slow = std::abs(2.0 * f) > std::abs(dxold * df);
+        dxold = dx;
+        if (leaves || slow || !(df != 0.0)) { dx = 0.5 * (xh - xl); x = xl + dx; } else { dx = f / df; x -= dx; }
+        if (std::abs(dx) < 4e-15) break;
+        eval2(x, &f, &df);
+        if (f < 0.0) xl = x; else xh = x;
       }
-      if ((flo < 0) == (fhi < 0) || fhi == 0.0) {
-        if (fhi == 0.0 && i + 2 == knots.size()) roots->push_back(hi);
-        continue;
+      return x;
+    };
+    std::vector<double> part, next, lvl;
+    for (int k = 1; k <= m; ++k) {
+      // (m-k)-th divided derivative: lvl[j] = q[j+s] * C(j+s, s), s = m - k
+      const int s = m - k;
+      lvl.assign(k + 1, 0.0);
+      double binom = 1.0;
+      for (int j = 0; j <= k; ++j) {
+        if (j > 0) binom = binom * (double)(j + s) / (double)j;
+        lvl[j] = q[j + s] * binom;
       }
-      for (int it = 0; it < 200 && hi - lo > 1e-15 * std::max(1.0, std::abs(lo)); ++it) {
-        const double mid = 0.5 * (lo + hi), fm = eval(mid);
-        if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+      next.clear();
+      double lo = 0.0, flo = lvl[0];
+      for (size_t i = 0; i <= part.size(); ++i) {
+        const double hi = i < part.size() ? part[i] : 1.0;
+        const double fhi = horner(lvl, hi);
+        if ((flo < 0.0) != (fhi < 0.0)) next.push_back(bracketed(lvl, lo, hi, flo, fhi));
+        lo = hi;
+        flo = fhi;
       }
-      roots->push_back(0.5 * (lo + hi));
+      part.swap(next);
     }
-    if (!knots.empty()) {
-      const double fb = eval(knots.back());
-      if (std::abs(fb) <= ftol && (roots->empty() || knots.back() > roots->back())) roots->push_back(knots.back());
-    }
+    for (double r : part) roots->push_back(a + w * r);
   }
 
   // Candidates for the extrema of the derivative-th derivative on [t_start, t_end]: both interval ends plus the real
@@ -165,6 +188,19 @@ class Polynomial {
     std::vector<double> candidates;
     if (!computeMinMaxCandidates(t_start, t_end, derivative, &candidates)) return false;
     return selectMinMaxFromCandidates(candidates, derivative, minimum, maximum);
+  }
+
+  // p_out(t) = p(scaling_factor * t): coefficient n scaled by scaling_factor^n (src/polynomial.cpp:199-205).
+  void scalePolynomialInTime(double scaling_factor) {
+    double scale = 1.0;
+    for (int n = 0; n < N_; ++n) {
+      coefficients_[n] *= scale;
+      scale *= scaling_factor;
+    }
+  }
+  void offsetPolynomial(const double offset) {   // src/polynomial.cpp:207-211
+    if (coefficients_.size() == 0) return;
+    coefficients_[0] += offset;
   }
 
  private:

@@ -3,6 +3,7 @@
 #ifndef MAV_TRAJECTORY_GENERATION_SEGMENT_H_
 #define MAV_TRAJECTORY_GENERATION_SEGMENT_H_
 #include <cstdint>
+#include <limits>
 #include <vector>
 
 #include "extremum.h"
@@ -67,6 +68,22 @@ class Segment {
       double m = 0.0;
       for (int dim : dimensions) { const double v = polynomials_[dim].evaluate(t, derivative); m += v * v; }
       candidates->push_back(Extremum(t, std::sqrt(m), 0));
+    }
+    return true;
+  }
+  // segment.cpp:146-184: strict </> over the candidates inside [t_start, t_end] (std::min/std::max on Extremum)
+  bool selectMinMaxMagnitudeFromCandidates(int /*derivative*/, double t_start, double t_end,
+                                           const std::vector<int>& /*dimensions*/, const std::vector<Extremum>& candidates,
+                                           Extremum* minimum, Extremum* maximum) const {
+    CHECK_NOTNULL(minimum);
+    CHECK_NOTNULL(maximum);
+    if (t_start > t_end) return false;
+    minimum->value = std::numeric_limits<double>::max();
+    maximum->value = std::numeric_limits<double>::lowest();
+    for (const Extremum& candidate : candidates) {
+      if (candidate.time < t_start || candidate.time > t_end) continue;
+      if (*maximum < candidate) *maximum = candidate;
+      if (candidate < *minimum) *minimum = candidate;
     }
     return true;
   }

@@ -110,6 +110,14 @@ void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);
  * mtg_solve_linear then, e.g. for graph capture).  bytes == 0 restores library-managed scratch.               */
 int mtg_plan_set_workspace(mtg_plan* plan, void* device_ptr, size_t bytes);
 
+/* ---- device memory for host code that must not see HIP headers --------------------------
+ * (the reference is host-only: its containers live in host memory, LINH:249-283.)  Allocation on
+ * the context's device; the copies are ordered on the context's stream and return when done.  */
+int mtg_device_malloc(mtg_context* ctx, size_t bytes, void** device_ptr);
+int mtg_device_free(mtg_context* ctx, void* device_ptr);
+int mtg_copy_to_device(mtg_context* ctx, void* dst_device, const void* src_host, size_t bytes);
+int mtg_copy_to_host(mtg_context* ctx, void* dst_host, const void* src_device, size_t bytes);
+
 /* ---- the hot path -------------------------------------------------------------------- */
 /* Replaces updateSegmentTimes() + solveLinear() (LINH:101,108; LIN:286-305, :339-379,
  * incl. constructR :308-336 and updateSegmentsFromCompactConstraints :263-283) for `batch`

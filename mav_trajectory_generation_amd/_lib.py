@@ -43,6 +43,10 @@ EXPORTS = {
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
+    "mtg_device_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_device_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mtg_copy_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "mtg_copy_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mtg_sample_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                         c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_double_p, ctypes.c_void_p]),

@@ -245,6 +245,47 @@ int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device) {
   return MTG_OK;
 }
 
+// ---- device memory helpers: host code above the C ABI never sees HIP headers ---------------------------------
+int mtg_device_malloc(mtg_context* ctx, size_t bytes, void** device_ptr) {
+  if (!ctx || !device_ptr) return MTG_ERR_INVALID_ARGUMENT;
+  *device_ptr = nullptr;
+  if (bytes == 0) return MTG_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MTG_HIP_TRY(ctx, hipMalloc(device_ptr, bytes));
+  return MTG_OK;
+}
+
+int mtg_device_free(mtg_context* ctx, void* device_ptr) {
+  if (!ctx) return MTG_ERR_INVALID_ARGUMENT;
+  if (!device_ptr) return MTG_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing queued on the context may still use it
+  MTG_HIP_TRY(ctx, hipFree(device_ptr));
+  return MTG_OK;
+}
+
+int mtg_copy_to_device(mtg_context* ctx, void* dst_device, const void* src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst_device || !src_host))) return MTG_ERR_INVALID_ARGUMENT;
+  if (bytes == 0) return MTG_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MTG_HIP_TRY(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host buffer may be reused on return
+  return MTG_OK;
+}
+
+int mtg_copy_to_host(mtg_context* ctx, void* dst_host, const void* src_device, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src_device))) return MTG_ERR_INVALID_ARGUMENT;
+  if (bytes == 0) return MTG_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MTG_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MTG_OK;
+}
+
 int mtg_context_sync(mtg_context* ctx) {
   if (!ctx) return MTG_ERR_INVALID_ARGUMENT;
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));

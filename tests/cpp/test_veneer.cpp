@@ -9,6 +9,7 @@
 #include <vector>
 
 #include <mav_trajectory_generation/polynomial_optimization_linear.h>
+#include <mav_trajectory_generation/trajectory_batch.h>
 
 using namespace mav_trajectory_generation;
 
@@ -224,6 +225,86 @@ int main() {
       const Eigen::VectorXd a = s1[3][1].getCoefficients(0), c = segs[3][1].getCoefficients(0);
       for (int j = 0; j < 10; ++j) EXPECT(std::abs(a[j] - c[j]) <= 1e-11 * (1e-30 + std::abs(a[j])) + 1e-300, "batch vs single coeff");
     }
+  }
+  // --- TrajectoryBatch (device) vs the host-side Trajectory helpers: two independent root finders ----------------
+  //     (test_polynomial_optimization.cpp:690-727 TimeScaling + :176-240 analytic maxima)
+  {
+    const int D = 3, K = 6, B = 130;
+    std::vector<Trajectory> trajs(B);
+    for (int b = 0; b < B; ++b) {
+      Vertex::Vector v = createRandomVertices(derivative_order::SNAP, K, Eigen::VectorXd::Constant(D, -10.0),
+                                              Eigen::VectorXd::Constant(D, 10.0), 5000 + b);
+      PolynomialOptimization<10> one(D);
+      one.setupFromVertices(v, estimateSegmentTimes(v, 3.0, 5.0));
+      one.solveLinear();
+      one.getTrajectory(&trajs[b]);
+    }
+    TrajectoryBatch batch(trajs);
+    std::vector<double> v_dev, a_dev;
+    EXPECT(batch.computeMaxVelocityAndAcceleration(&v_dev, &a_dev), "batch maxima");
+    std::vector<Extremum> mn, mx;
+    EXPECT(batch.computeMinMaxMagnitude(derivative_order::VELOCITY, {0, 2}, &mn, &mx), "batch minmax dims {0,2}");
+    EXPECT(!batch.computeMinMaxMagnitude(derivative_order::VELOCITY, {0, 3}, &mn, &mx), "dimension out of bounds");
+    EXPECT(!batch.computeMinMaxMagnitude(derivative_order::VELOCITY, {}, &mn, &mx), "no dimensions");
+    EXPECT(batch.computeMinMaxMagnitude(derivative_order::VELOCITY, {0, 2}, &mn, &mx), "batch minmax dims {0,2}");
+    for (int b = 0; b < B; ++b) {
+      double v, a;
+      trajs[b].computeMaxVelocityAndAcceleration(&v, &a);
+      EXPECT(std::abs(v - v_dev[b]) <= 1e-9 * v && std::abs(a - a_dev[b]) <= 1e-9 * a, "b=%d v %.15g/%.15g a %.15g/%.15g", b, v,
+             v_dev[b], a, a_dev[b]);
+      Extremum hmn, hmx;
+      trajs[b].computeMinMaxMagnitude(derivative_order::VELOCITY, {0, 2}, &hmn, &hmx);
+      EXPECT(std::abs(hmx.value - mx[b].value) <= 1e-9 * hmx.value, "b=%d partial-dimension maximum", b);
+      // Extremum::segment_idx / time: the device's reported point reproduces its value
+      const Segment& s = trajs[b].segments()[mx[b].segment_idx];
+      const Eigen::VectorXd vel = s.evaluate(mx[b].time, derivative_order::VELOCITY);
+      EXPECT(std::abs(std::sqrt(vel[0] * vel[0] + vel[2] * vel[2]) - mx[b].value) <= 1e-12 * (1 + mx[b].value), "b=%d extremum point", b);
+    }
+    // sampling: device grid vs host evaluate
+    std::vector<double> samples;
+    std::vector<int> n_valid;
+    const int S = 50, ND = 3;
+    const double dt = 0.37;
+    batch.sample(0.0, dt, S, ND, &samples, &n_valid);
+    for (int b = 0; b < B; b += 17) {
+      int want_valid = 0;
+      for (int i = 0; i < S; ++i) {
+        const double t = 0.0 + dt * i;
+        if (t <= trajs[b].getMaxTime()) ++want_valid;
+        for (int der = 0; der < ND; ++der) {
+          const Eigen::VectorXd h = trajs[b].evaluate(std::min(t, trajs[b].getMaxTime()), der);
+          for (int d = 0; d < D; ++d) {
+            const double g = samples[((size_t)(b * S + i) * ND + der) * D + d];
+            EXPECT(std::abs(g - h[d]) <= 1e-10 * (1.0 + std::abs(h[d])), "sample b=%d i=%d der=%d", b, i, der);
+          }
+        }
+      }
+      EXPECT(n_valid[b] == want_valid, "n_valid %d vs %d", n_valid[b], want_valid);
+    }
+    // feasibility scaling: device batch vs host loop
+    const double v_lim = 2.0, a_lim = 2.5;
+    std::vector<char> within;
+    std::vector<double> scaling;
+    EXPECT(batch.scaleSegmentTimesToMeetConstraints(v_lim, a_lim, &within, &scaling), "all within range after scaling");
+    std::vector<Trajectory> scaled;
+    batch.download(&scaled);
+    int n_scaled = 0;
+    for (int b = 0; b < B; ++b) {
+      Trajectory h = trajs[b];
+      EXPECT(h.scaleSegmentTimesToMeetConstraints(v_lim, a_lim), "host scaling b=%d", b);
+      n_scaled += scaling[b] > 1.0;
+      EXPECT(std::abs(h.getMaxTime() - scaled[b].getMaxTime()) <= 1e-9 * h.getMaxTime(), "b=%d total time %.15g vs %.15g", b,
+             h.getMaxTime(), scaled[b].getMaxTime());
+      EXPECT(std::abs(scaling[b] - h.getMaxTime() / trajs[b].getMaxTime()) <= 1e-9 * scaling[b], "b=%d scaling", b);
+      for (int k = 0; k < K; ++k)
+        for (int d = 0; d < D; ++d) {
+          const Eigen::VectorXd ch = h.segments()[k][d].getCoefficients(), cd = scaled[b].segments()[k][d].getCoefficients();
+          double cmax = 0.0, err = 0.0;
+          for (int n = 0; n < 10; ++n) { cmax = std::max(cmax, std::abs(ch[n])); err = std::max(err, std::abs(ch[n] - cd[n])); }
+          EXPECT(err <= 1e-9 * cmax, "b=%d k=%d d=%d scaled coefficients", b, k, d);
+        }
+    }
+    EXPECT(n_scaled > 0, "the case exercises the scaling branch");
   }
   std::printf(g_fail ? "VENEER TESTS FAILED: %d\n" : "VENEER TESTS PASSED%.0d\n", g_fail);
   return g_fail ? 1 : 0;
