@@ -29,7 +29,14 @@ def cpu_baseline(n_sample, seed):
     from oracle import cpu_ref
     masks = m.ends_full_masks(10, 8)
     t, f = m.random_waypoint_batch(n_sample, 8, 3, 10, masks, seed=seed, device="cpu")
-    return cpu_ref.timed_baseline(10, 4, masks, t.numpy(), f.numpy(), target_seconds=12.0)
+    out = cpu_ref.timed_baseline(10, 4, masks, t.numpy(), f.numpy(), target_seconds=12.0)
+    # beside it: the reference's own code (oracle/_ref/libmtg_ref.so, compiled from /root/reference against the
+    # Eigen/glog container stand-ins -- slower than real Eigen, hence reported as context, not as the baseline value)
+    from oracle import ref_linear
+    if ref_linear.available():
+        out["reference_build"] = ref_linear.timed_baseline(10, 4, masks, t.numpy()[:20_000], f.numpy()[:20_000],
+                                                           target_seconds=6.0)
+    return out
 
 
 def measured_traffic(batch):

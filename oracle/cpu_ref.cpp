@@ -8,7 +8,8 @@
 // It performs the SAME arithmetic steps as the reference (pow-based Q, Schur-complement A^-1 with a dense LU of
 // the h x h block, H = A^-T Q A^-1 as two N^3 products, R = M^T H M, Householder-QR solve of R_PP, A^-1 M d),
 // but none of Eigen's sparse bookkeeping or per-Polynomial heap allocation -- i.e. it is a conservative
-// (faster-than-real-Eigen) stand-in for "the Eigen path on the host cores".  Parity status: see oracle_np.py.
+// (faster-than-real-Eigen) stand-in for "the Eigen path on the host cores".  Parity status: pinned against the reference's own code
+// (oracle/_ref/libmtg_ref.so) in tests/test_reference_build.py; see oracle_np.py.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include <algorithm>

@@ -1,15 +1,22 @@
 """CPU ORACLE (test infrastructure, NOT product code) — numpy float64 restatement of
 mav_trajectory_generation's PolynomialOptimization<N>::solveLinear() hot path.
 
-PARITY STATUS: the reference cannot be compiled in this image (Eigen and glog are
-un-vendored third-party dependencies, fetched un-pinned by
-install/mav_trajectory_generation_https.rosinstall:1-6), so this restatement is pinned
-against the reference's own golden vector (test_polynomial_optimization.cpp:777-780,
-n_free==0 branch) and its property tests (AMatrixInversion :731-741, ConstraintPacking
-:505-564, checkPath :113-174).  The numerical result of the SparseQR solve (d_P) has no
-known-answer test in the reference => for that sub-step parity is "unpinned" below the
-1e-6 property level; oracle/oracle_mp.py (mpmath, 50 digits) is the ground truth used
-to arbitrate.
+PARITY STATUS: PINNED against the reference itself run in the build container.  The
+reference's own PolynomialOptimization<N> code is compiled from /root/reference where it
+lies into oracle/_ref/libmtg_ref.so (oracle/Makefile `ref`; Eigen and glog -- un-vendored,
+un-pinned dependencies fetched by install/mav_trajectory_generation_https.rosinstall:1-6,
+absent offline -- are replaced by the container stand-ins in oracle/ref_shim/, whose
+header says exactly what is not Eigen's: Gauss-Jordan inverse, natural-order Householder
+QR for SparseQR+COLAMD).  tests/test_reference_build.py checks this restatement against
+that library step by step (A, Q bit/ulp-equal; M identical; A^-1, R, d_P, coefficients,
+cost to round-off x cond: <= 7e-11 norm-wise for N = 10 snap) and against its committed
+outputs (tests/golden/reference_solve_linear.npz).  It is additionally pinned on the
+reference's golden vector (test_polynomial_optimization.cpp:777-780, n_free == 0) and its
+property tests (AMatrixInversion :731-741, ConstraintPacking :505-564, checkPath
+:113-174); oracle/oracle_mp.py (mpmath, 50 digits) arbitrates below the float64
+evaluation error of the reference's own formulas (1e-11 for N = 10 .. 1e-8 for N = 12).
+What stays unpinned: real Eigen's last-bits behaviour (its LU / SparseQR pivot order),
+which no reference test constrains either.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 
