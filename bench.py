@@ -35,7 +35,7 @@ def cpu_baseline(n_sample, seed):
     from oracle import ref_linear
     if ref_linear.available():
         out["reference_build"] = ref_linear.timed_baseline(10, 4, masks, t.numpy()[:20_000], f.numpy()[:20_000],
-                                                           target_seconds=6.0)
+                                                           target_seconds=2.0)
     return out
 
 
