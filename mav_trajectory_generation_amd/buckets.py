@@ -1,6 +1,12 @@
 """Mixed batches (BASELINE config 4): trajectories with different N / K / constraint structure are bucketed on the
 host by plan key (N, D, K, d, masks); each bucket is one launch of the matching kernel variant.  Mirrors what a
-caller of the reference would do with a list of independent PolynomialOptimization<N> problems."""
+caller of the reference would do with a list of independent PolynomialOptimization<N> problems.
+
+Buckets are independent, and a bucket of a few thousand trajectories fills only a fraction of the 256 CUs (a
+2500-trajectory bucket is 40 tiles), so the buckets are spread over `n_streams` HIP streams -- one library context
+per stream (include/mtg_hip.h: a context is (device, stream, scratch)) -- forked from the caller's stream and joined
+back onto it: the launches overlap on the device instead of queueing behind each other.  Longest chains first, so
+the short buckets fill in behind the long ones."""
 from __future__ import annotations
 
 from typing import Dict, List, Sequence, Tuple
@@ -11,37 +17,105 @@ from .core import Context, Plan
 
 
 class MixedBatchSolver:
-    def __init__(self, ctx: Context):
+    def __init__(self, ctx: Context, n_streams: int = 4):
         self.ctx = ctx
+        # lane 0 is the caller's context; further lanes own their own stream (created lazily: n_streams = 1 keeps the
+        # plain one-stream behaviour)
+        self.lanes: List[Context] = [ctx]
+        self.n_streams = max(1, int(n_streams))
         self.plans: Dict[Tuple, Plan] = {}
 
-    def plan_for(self, n_coeffs: int, dimension: int, n_segments: int, derivative: int, masks: Sequence[int]) -> Plan:
-        key = (n_coeffs, dimension, n_segments, derivative, tuple(int(m) for m in masks))
+    def _lane(self, i: int) -> Context:
+        while len(self.lanes) < min(self.n_streams, i + 1):
+            self.lanes.append(Context(self.ctx.device))
+        return self.lanes[i % self.n_streams]
+
+    def plan_for(self, n_coeffs: int, dimension: int, n_segments: int, derivative: int, masks: Sequence[int],
+                 lane: int = 0) -> Plan:
+        key = (n_coeffs, dimension, n_segments, derivative, tuple(int(m) for m in masks), lane % self.n_streams)
         if key not in self.plans:
-            self.plans[key] = Plan(self.ctx, n_coeffs, dimension, n_segments, derivative, list(key[4]))
+            self.plans[key] = Plan(self._lane(lane), n_coeffs, dimension, n_segments, derivative, list(key[4]))
         return self.plans[key]
+
+    def solve_device(self, buckets: List[dict], want_cost: bool = False, _capturing: bool = False):
+        """Device-resident mixed batch.  buckets: dicts with n_coeffs, derivative, masks and CUDA tensors times /
+        d_fixed in `layout` ('aos' default; all the bucket's trajectories share the plan).  Asynchronous: results are
+        ordered on torch's current stream.  Returns [(coeffs [B][K][D][N], cost [B] or None)] in bucket order."""
+        import torch
+        cur = torch.cuda.current_stream(self.ctx.device)
+        order = sorted(range(len(buckets)),
+                       key=lambda i: -(buckets[i]["n_coeffs"] ** 2) * len(buckets[i]["masks"]))   # longest first
+        jobs = []
+        for lane, i in enumerate(order):
+            b = buckets[i]
+            layout = b.get("layout", "aos")
+            t, f = b["times"], b["d_fixed"]
+            k = len(b["masks"]) - 1
+            dim = f.shape[1] if layout == "aos" else f.shape[0]
+            batch = t.shape[0] if layout == "aos" else t.shape[1]
+            plan = self.plan_for(int(b["n_coeffs"]), dim, k, int(b["derivative"]), b["masks"], lane)
+            co = torch.empty((batch, k, dim, plan.N), dtype=torch.float64, device=t.device)
+            cost = torch.empty((batch,), dtype=torch.float64, device=t.device) if want_cost else None
+            jobs.append((i, plan, t, f, layout, co, cost))
+        used = {id(j[1].ctx): j[1].ctx for j in jobs}
+        for c in used.values():          # fork: every lane starts after the work already queued by the caller
+            if c.stream != cur:
+                c.stream.wait_stream(cur)
+        out = [None] * len(buckets)
+        for i, plan, t, f, layout, co, cost in jobs:
+            plan.solve(t, f, layout=layout, coeffs=co, cost=cost, want_cost=want_cost, ordered=False)
+            out[i] = (co, cost)
+            if not _capturing:
+                for x in (t, f, co, cost):   # tensors allocated on the caller's stream, used on the lane's
+                    if x is not None:
+                        x.record_stream(plan.ctx.stream)
+        for c in used.values():          # join
+            if c.stream != cur:
+                cur.wait_stream(c.stream)
+        return out
+
+    def capture(self, buckets: List[dict], want_cost: bool = False):
+        """Capture the whole mixed batch -- every bucket's launch, forked over the lanes' streams and joined -- into
+        ONE hipGraph (torch.cuda.CUDAGraph): a request made of many small launches is bound by the host's per-launch
+        cost, not by the device; a replay is a single hipGraphLaunch.  The graph reads the buckets' input tensors in
+        place (refill them, then `graph.replay()`) and writes the returned output tensors.  This is what a time
+        optimiser does with a mixed population: same structure, new segment times, every iteration.
+        Returns (graph, [(coeffs, cost)] in bucket order)."""
+        import torch
+        self.solve_device(buckets, want_cost)          # warm-up: plans, lane contexts, rolled-kernel workspaces
+        torch.cuda.synchronize(self.ctx.device)
+        self.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.solve_device(buckets, want_cost, _capturing=True)
+        return graph, out
+
+    def sync(self):
+        for c in self.lanes:
+            c.sync()
 
     def solve(self, problems: List[dict], want_cost: bool = False):
         """problems: dicts with n_coeffs, derivative, masks [K+1], times [K], d_fixed [D][n_fixed] (host arrays).
         Returns (list of coeff arrays [K][D][N] in input order, list of costs or None)."""
         import torch
-        buckets: Dict[Tuple, List[int]] = {}
+        groups: Dict[Tuple, List[int]] = {}
         for i, p in enumerate(problems):
             t = np.asarray(p["times"], dtype=np.float64)
             f = np.asarray(p["d_fixed"], dtype=np.float64)
             key = (int(p["n_coeffs"]), f.shape[0], t.shape[0], int(p["derivative"]), tuple(int(m) for m in p["masks"]))
-            buckets.setdefault(key, []).append(i)
-        coeffs: List = [None] * len(problems)
-        costs: List = [None] * len(problems)
-        pending = []
-        for key, idx in buckets.items():
-            plan = self.plan_for(*key)
+            groups.setdefault(key, []).append(i)
+        buckets, index = [], []
+        for key, idx in groups.items():
             t = torch.from_numpy(np.stack([np.asarray(problems[i]["times"], dtype=np.float64) for i in idx])).cuda()
             f = torch.from_numpy(np.stack([np.asarray(problems[i]["d_fixed"], dtype=np.float64) for i in idx])).cuda()
-            co, _, cost = plan.solve(t, f, want_cost=want_cost)
-            pending.append((idx, co, cost))
-        self.ctx.sync()
-        for idx, co, cost in pending:
+            buckets.append(dict(n_coeffs=key[0], derivative=key[3], masks=list(key[4]), times=t, d_fixed=f))
+            index.append(idx)
+        results = self.solve_device(buckets, want_cost=want_cost)
+        torch.cuda.current_stream(self.ctx.device).synchronize()
+        self.sync()   # raises if any bucket flagged a bad segment time / singular system
+        coeffs: List = [None] * len(problems)
+        costs: List = [None] * len(problems)
+        for idx, (co, cost) in zip(index, results):
             co = co.cpu().numpy()
             cj = cost.cpu().numpy() if cost is not None else None
             for j, i in enumerate(idx):
@@ -54,3 +128,6 @@ class MixedBatchSolver:
         for p in self.plans.values():
             p.close()
         self.plans.clear()
+        for c in self.lanes[1:]:
+            c.close()
+        self.lanes = self.lanes[:1]

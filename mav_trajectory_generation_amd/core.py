@@ -195,9 +195,12 @@ class Plan:
         return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
-              coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto"):
+              coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
-        'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost)."""
+        'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
+        ordered=False skips the automatic ordering against torch's current stream (the caller forks / joins the
+        context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors
+        must then be passed in, allocated by the caller before the fork."""
         import torch
         batch = times.shape[0] if layout == "aos" else times.shape[1]
         assert times.dtype == torch.float64 and times.is_cuda and times.is_contiguous()
@@ -213,10 +216,11 @@ class Plan:
         lay = self.layout(batch, layout)
         flags = L.FLAG_GENERIC_KERNEL if generic else 0
         flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS}[dims]
-        cur = self.ctx._enter()
+        cur = self.ctx._enter() if ordered else None
         rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), self._ptr(times), self._ptr(d_fixed),
                                        self._ptr(coeffs), self._ptr(d_free), self._ptr(cost), flags)
-        self.ctx._leave(cur)
+        if ordered:
+            self.ctx._leave(cur)
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
 

@@ -287,6 +287,55 @@ def test_mixed_batch_config4_buckets(ctx):
     solver.close()
 
 
+def test_mixed_batch_streams_and_graph_replay(ctx):
+    """Config 4 as one device-resident request: buckets spread over 4 HIP streams, then the whole request captured
+    into one hipGraph and replayed on refreshed inputs -- every variant must reproduce the one-stream results bit for
+    bit, and those match the oracle."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    buckets, hosts = [], []
+    for (n, d) in ((8, 3), (10, 4), (12, 5)):
+        for k in (4, 8, 16, 32):
+            masks, times, d_fixed = helpers.reference_batch(70, k, n, 3, 9000 + n * 100 + k)
+            hosts.append((n, d, masks, times, d_fixed))
+            buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=torch.from_numpy(times).cuda(),
+                                d_fixed=torch.from_numpy(d_fixed).cuda()))
+    one = m.MixedBatchSolver(ctx, n_streams=1)
+    ref = [(c.clone(), j.clone()) for c, j in one.solve_device(buckets, want_cost=True)]
+    torch.cuda.synchronize()
+    one.sync()
+    for (n, d, masks, times, d_fixed), (c, j) in zip(hosts, ref):
+        if n <= 10:
+            c_lit, _, j_lit = onp.solve_batch(n, d, masks, times[:4], d_fixed[:4])
+            assert helpers.poly_relerr(c[:4].cpu().numpy(), c_lit) < 1e-9
+            assert np.allclose(j[:4].cpu().numpy(), j_lit, rtol=1e-7)
+    four = m.MixedBatchSolver(ctx, n_streams=4)
+    got = four.solve_device(buckets, want_cost=True)
+    torch.cuda.synchronize()
+    four.sync()
+    assert len(four.lanes) == 4
+    for (c, j), (c0, j0) in zip(got, ref):
+        assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
+    graph, out = four.capture(buckets, want_cost=True)
+    for c, j in out:
+        c.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for (c, j), (c0, j0) in zip(out, ref):
+        assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
+    # new segment times in place (what a time optimiser does between iterations), replay, compare with a fresh solve
+    for b in buckets:
+        b["times"].mul_(1.25)
+    graph.replay()
+    fresh = one.solve_device(buckets, want_cost=True)
+    torch.cuda.synchronize()
+    for (c, j), (c1, j1) in zip(out, fresh):
+        assert torch.equal(c, c1)
+    del graph
+    four.close()
+    one.close()
+
+
 def test_config5_full_size_properties(ctx):
     """BASELINE config 5 shape at its per-GPU share (100k / 8): K = 16, D = 4 (x, y, z, yaw), interior vertices fix
     position, velocity and acceleration.  checkPath over the whole batch + oracle parity on a subset, for both the
