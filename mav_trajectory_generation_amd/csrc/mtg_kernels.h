@@ -131,6 +131,17 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   P.dim0 += (int)blockIdx.y * C::D;
   const int lane = threadIdx.x & (kWave - 1);
   const int dir = threadIdx.x >> 6;  // wave-uniform
+  // Static variants: the first tile's inputs are requested before ANY other set-up (staging offsets, LDS pointers,
+  // workspace slabs): at small batch every wave solves exactly one tile and the input round trip heads its serial
+  // latency chain, so nothing may sit in front of the loads.
+  MtgLane<C> ln;
+  auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
+    long long bb = (long long)tile_ * kWave + lane;
+    if (bb >= P.B) bb = P.B - 1;
+    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
+    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
+  };
+  if (C::kStatic && (int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
   const int mm = C::kRolled ? C::MI : mtg_mask<C>(P, vm);
@@ -143,7 +154,6 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   const double* other = xch + (size_t)(1 - dir) * nslots * kWave + lane;
   double* wsl = (P.ws && !C::kStatic)
                     ? P.ws + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x) : nullptr;
-  MtgLane<C> ln;
 #if defined(MTG_TIMING)
   long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + dir) * 16;
   const bool tdo = C::kStatic && P.ws != nullptr;
@@ -155,13 +165,6 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   // and rely on the co-resident wave instead.
   constexpr bool kPrefetch = C::kStatic && mtg_waves_per_simd<C>() == 1;
   double nT[C::KCS], nfx[C::D][C::NC];
-  auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
-    long long bb = (long long)tile_ * kWave + lane;
-    if (bb >= P.B) bb = P.B - 1;
-    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
-    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
-  };
-  if (kPrefetch && (int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     io.b0 = (long long)tile * kWave;
     const long long bl = io.b0 + lane;
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
     const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
     const bool has_next = kPrefetch && tile + (int)gridDim.x < ntiles;
     if (has_next) fetch(tile + gridDim.x, nT, nfx);
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, !kPrefetch);
-    else mtg_lane_forward<C, -1>(P, b, ln, wsl, !kPrefetch);
+    const bool need_preload = !kPrefetch && !(C::kStatic && tile == (int)blockIdx.x);   // first tile: fetched at the top
+    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, need_preload);
+    else mtg_lane_forward<C, -1>(P, b, ln, wsl, need_preload);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
     MTG_TSTAMP(1);
     __syncthreads();
