@@ -602,6 +602,19 @@ bool operator!=(const DenseBase<A, T>& a, const DenseBase<B, T>& b) {
   return !(a == b);
 }
 
+// Map<M>(ptr, n) / Map<M>(ptr, rows, cols): window onto caller-owned, column-major storage.
+template <class M>
+class Map : public View<typename M::Scalar> {
+  typedef typename M::Scalar T;
+
+ public:
+  Map(T* p, Index n) : View<T>(p, M::ColsAtCompileTime == 1 ? n : 1, M::ColsAtCompileTime == 1 ? n : 1, M::ColsAtCompileTime == 1 ? 1 : n) {}
+  Map(const T* p, Index n) : Map(const_cast<T*>(p), n) {}
+  Map(T* p, Index r, Index c) : View<T>(p, r, r, c) {}
+  Map(const T* p, Index r, Index c) : View<T>(const_cast<T*>(p), r, r, c) {}
+  using View<T>::operator=;
+};
+
 typedef Matrix<double, Dynamic, Dynamic> MatrixXd;
 typedef Matrix<double, Dynamic, 1> VectorXd;
 typedef Matrix<double, 1, Dynamic> RowVectorXd;
