@@ -5,13 +5,14 @@
 //
 // One lane per (trajectory, sample); lanes of a wave are consecutive samples of (mostly) one trajectory, so the
 // coefficient reads are wave-broadcasts served by L1 and the kernel is bound by its output stream.  Each lane's
-// n_derivatives*D results are transposed through LDS so the wave writes 512 contiguous bytes per store.
+// n_derivatives*D results are transposed through the wave's LDS slab so the wave writes 1 KiB contiguous per store.
 // Differences to the reference, by design: sample times are t_start + i*dt in closed form (the reference
 // accumulates dt, a sequential loop); samples past the end of a trajectory are evaluated at its end time and
 // reported through n_valid[b] instead of being dropped.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/mtg_hip.h"
 
@@ -31,101 +32,305 @@ struct SampleParams {
   double t_start, dt;
 };
 
+// Per-lane sample descriptor: where the sample lives (coefficient pointer of its segment) and its segment-local time.
+struct SampleSite {
+  const double* c;   // coeffs of (trajectory, segment), dimension 0
+  double local;      // time inside the segment, clamped to the segment's duration
+};
+
+// (trajectory, sample) -> segment lookup: the first segment whose accumulated end time exceeds t
+// (src/trajectory.cpp:52-66); t at or beyond the last vertex -> last segment, clamped to its end.
+// Branch-free scan (no early exit: the loads of all K times are independent and stay in flight together).
+__device__ __forceinline__ SampleSite mtg_sample_site(const SampleParams& P, long long b, int s) {
+  const double t = P.t_start + P.dt * s;
+  const double* tt = P.times + b * P.ts_b;
+  double acc = 0.0, seg_start = 0.0, seg_time = 0.0;
+  int seg = 0;
+  bool found = false;
+#pragma unroll 8
+  for (int i = 0; i < P.K; ++i) {
+    const double ti = tt[(long long)i * P.ts_k];
+    if (!found) { seg_time = ti; seg_start = acc; seg = i; }
+    acc += ti;
+    found = found || acc > t;
+  }
+  SampleSite r;
+  r.local = t - seg_start;
+  if (r.local > seg_time) r.local = seg_time;
+  r.c = P.coeffs + ((b * P.K + seg) * P.D) * (long long)P.N;
+  return r;
+}
+
+// Run-time-shape kernel (any N <= 12, any D, any K).  Every WAVE is an independent worker: it owns 64 consecutive
+// (trajectory, sample) slots per step, its own LDS slab for the transposition and its own grid-stride sequence -- no
+// workgroup barrier anywhere.
 template <int ND>   // number of derivatives sampled (compile time: the ND running Horner sums stay in registers)
 __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, long long total) {
-  extern __shared__ double lds[];
+  extern __shared__ double lds_all[];
   const int R = ND * P.D;          // results per lane
   const int RP = R | 1;            // odd row stride: conflict-free ds_write_b64
-  // (trajectory, sample) of the block's first lane, advanced incrementally: one 64-bit division per thread per launch
-  const long long step = (long long)gridDim.x * kThreads;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* lds = lds_all + (size_t)wave * 64 * RP;
+  // (trajectory, sample) of the wave's first lane, advanced incrementally: one 64-bit division per wave per launch
+  const long long nworkers = (long long)gridDim.x * (kThreads / 64);
+  const long long step = nworkers * 64;
   const long long step_b = step / P.S;
   const int step_s = (int)(step - step_b * P.S);
-  long long blk_b = ((long long)blockIdx.x * kThreads) / P.S;
-  int blk_s = (int)((long long)blockIdx.x * kThreads - blk_b * P.S);
-  for (long long base = (long long)blockIdx.x * kThreads; base < total; base += step) {
-    if (base + threadIdx.x < total) {
-      const unsigned off = (unsigned)blk_s + threadIdx.x;
-      const unsigned q = off / (unsigned)P.S;
-      const long long b = blk_b + q;
-      const int s = (int)(off - q * (unsigned)P.S);
-      const double t = P.t_start + P.dt * s;
-      // segment lookup: the first segment whose accumulated end time exceeds t (src/trajectory.cpp:52-66);
-      // t at or beyond the last vertex -> last segment, clamped to its end
-      const double* tt = P.times + b * P.ts_b;
-      // branch-free scan (no early exit: the loads of all K times are independent and stay in flight together)
-      double acc = 0.0, seg_start = 0.0, seg_time = 0.0;
-      int seg = 0;
-      bool found = false;
-#pragma unroll 4
-      for (int i = 0; i < P.K; ++i) {
-        const double ti = tt[(long long)i * P.ts_k];
-        if (!found) { seg_time = ti; seg_start = acc; seg = i; }
-        acc += ti;
-        found = found || acc > t;
+  long long base = ((long long)blockIdx.x * (kThreads / 64) + wave) * 64;
+  long long blk_b = base / P.S;
+  int blk_s = (int)(base - blk_b * P.S);
+  auto site_of = [&](long long base_, long long blk_b_, int blk_s_) {
+    // lanes past the end of the launch re-evaluate the last sample (their results are never stored)
+    long long idx = base_ + lane;
+    unsigned off = (unsigned)blk_s_ + (unsigned)lane;
+    if (idx >= total) off -= (unsigned)(idx - (total - 1));
+    const unsigned q = off / (unsigned)P.S;
+    return mtg_sample_site(P, blk_b_ + q, (int)(off - q * (unsigned)P.S));
+  };
+  double cur[kMaxN], nxt[kMaxN];
+  SampleSite site;
+  if (base < total) {
+    site = site_of(base, blk_b, blk_s);
+#pragma unroll
+    for (int j = 0; j < kMaxN; ++j) cur[j] = j < P.N ? site.c[j] : 0.0;
+  }
+  while (base < total) {
+    // ---- arithmetic of this chunk: coefficients of one dimension are a register batch (static indices, uniform
+    // j < N guards); the next dimension's batch is requested before this one is consumed
+    for (int d = 0; d < P.D; ++d) {
+      if (d + 1 < P.D) {
+        const double* cn = site.c + (d + 1) * P.N;
+#pragma unroll
+        for (int j = 0; j < kMaxN; ++j) nxt[j] = j < P.N ? cn[j] : 0.0;
       }
-      double local = t - seg_start;
-      if (local > seg_time) local = seg_time;
-      const double* c = P.coeffs + ((b * P.K + seg) * P.D) * (long long)P.N;
-      // coefficients of one dimension are loaded as a batch (static register indices, uniform j < N guards) and the
-      // next dimension's batch is issued before this one is consumed: one memory latency per lane, not N * D
-      double cur[kMaxN], nxt[kMaxN];
+      // all derivatives in one pass: a[m] accumulates p^(m)(t) / m!  (Horner with derivatives; polynomial.h:137-149
+      // evaluates each derivative with its own Horner loop -- same values to rounding)
+      double a[ND];
 #pragma unroll
-      for (int j = 0; j < kMaxN; ++j) cur[j] = j < P.N ? c[j] : 0.0;
-      for (int d = 0; d < P.D; ++d) {
-        if (d + 1 < P.D) {
-          const double* cn = c + (d + 1) * P.N;
+      for (int m = 0; m < ND; ++m) a[m] = 0.0;
 #pragma unroll
-          for (int j = 0; j < kMaxN; ++j) nxt[j] = j < P.N ? cn[j] : 0.0;
+      for (int j = kMaxN - 1; j >= 0; --j) {
+        if (j < P.N) {
+#pragma unroll
+          for (int m = ND - 1; m >= 1; --m) a[m] = __builtin_fma(a[m], site.local, a[m - 1]);
+          a[0] = __builtin_fma(a[0], site.local, cur[j]);
         }
-        // all derivatives in one pass: a[m] accumulates p^(m)(t) / m!  (Horner with derivatives; polynomial.h:137-149
-        // evaluates each derivative with its own Horner loop -- same values to rounding)
-        double a[ND];
+      }
+      double fact = 1.0;
 #pragma unroll
-        for (int m = 0; m < ND; ++m) a[m] = 0.0;
-#pragma unroll
-        for (int j = kMaxN - 1; j >= 0; --j) {
-          if (j < P.N) {
-#pragma unroll
-            for (int m = ND - 1; m >= 1; --m) a[m] = __builtin_fma(a[m], local, a[m - 1]);
-            a[0] = __builtin_fma(a[0], local, cur[j]);
-          }
-        }
-        double fact = 1.0;
-#pragma unroll
-        for (int m = 0; m < ND; ++m) {
-          if (m > 1) fact *= (double)m;
-          lds[threadIdx.x * RP + m * P.D + d] = a[m] * fact;
-        }
+      for (int m = 0; m < ND; ++m) {
+        if (m > 1) fact *= (double)m;
+        lds[lane * RP + m * P.D + d] = a[m] * fact;
+      }
+      if (d + 1 < P.D) {
 #pragma unroll
         for (int j = 0; j < kMaxN; ++j) cur[j] = nxt[j];
       }
     }
-    blk_b += step_b;
-    blk_s += step_s;
-    if (blk_s >= P.S) { blk_s -= P.S; ++blk_b; }
-    __syncthreads();
-    // coalesced write-out of this block's contiguous [kThreads][R] slab, two doubles (16 B) per lane per store;
-    // element e belongs to lane e / R.  The slab starts 16-byte aligned (base is a multiple of kThreads).
+    // ---- inputs of the next chunk, requested ahead of this chunk's stores
+    const long long nbase = base + step;
+    long long nblk_b = blk_b + step_b;
+    int nblk_s = blk_s + step_s;
+    if (nblk_s >= P.S) { nblk_s -= P.S; ++nblk_b; }
+    if (nbase < total) {
+      site = site_of(nbase, nblk_b, nblk_s);
+#pragma unroll
+      for (int j = 0; j < kMaxN; ++j) cur[j] = j < P.N ? site.c[j] : 0.0;
+    }
+    // ---- coalesced write-out of this chunk's contiguous [64][R] slab, two doubles (16 B) per lane per store;
+    // element e belongs to lane e / R.  The slab starts 16-byte aligned (base is a multiple of 64).  Wave-level
+    // hand-off through LDS: LDS operations of one wave execute in order; the compiler is fenced on both sides.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     const long long slab = base * R;
-    const int slab_len = (int)((total - base < kThreads ? total - base : kThreads) * R);
-    const int e0 = 2 * (int)threadIdx.x;
+    const int slab_len = (int)((total - base < 64 ? total - base : 64) * R);
+    const int e0 = 2 * lane;
     int owner = e0 / R, r = e0 - owner * R;
-    const int qstep2 = (2 * kThreads) / R, rstep2 = 2 * kThreads - qstep2 * R;
-    for (int e = e0; e < slab_len; e += 2 * kThreads) {
+    const int qstep2 = 128 / R, rstep2 = 128 - qstep2 * R;
+    for (int e = e0; e < slab_len; e += 128) {
       const double v0 = lds[owner * RP + r];
       const int o1 = r + 1 == R ? owner + 1 : owner, r1 = r + 1 == R ? 0 : r + 1;
       if (e + 1 < slab_len) {
         const double v1 = lds[o1 * RP + r1];
-        *reinterpret_cast<double2*>(P.out + slab + e) = make_double2(v0, v1);
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 v;
+        v.x = v0;
+        v.y = v1;
+        __builtin_nontemporal_store(v, reinterpret_cast<d2*>(P.out + slab + e));   // see the note in the ct kernel
       } else {
-        P.out[slab + e] = v0;
+        __builtin_nontemporal_store(v0, P.out + slab + e);
       }
       owner += qstep2;
       r += rstep2;
       if (r >= R) { r -= R; ++owner; }
     }
-    __syncthreads();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    base = nbase;
+    blk_b = nblk_b;
+    blk_s = nblk_s;
   }
+}
+
+// Compile-time (ND, N, D) kernel for the common shapes with an ODD number of results per sample (R = ND*D: position..
+// snap in 3-D is 15) and K <= 8 segments.  What the measurements on the run-time-shape kernel showed (100k x 1000
+// samples, 12 GB out: 3.8 ms; same kernel with its stores removed 2.4 ms, with stores AND arithmetic AND coefficient
+// loads removed still 1.6 ms; a bare store stream of the same shape 2.15 ms, tools/micro/write_pattern.hip):
+//   * index arithmetic, register shuffles of the d-loop and the owner/remainder bookkeeping of the write-out were 40 %
+//     of the issue slots.  Here every offset is an immediate: the D*N coefficients of a sample are one batch of loads
+//     off one base pointer, a wave's LDS slab IS the output image of its 64 samples (row length R is odd, hence
+//     conflict-free without padding) and the write-out is a straight ds_read_b128 -> global_store_dwordx4 copy;
+//   * nothing overlapped.  On gfx9-family hardware loads and stores share the vmcnt counter and retire in issue order,
+//     so a wave that stores chunk i and THEN requests inputs of chunk i+1 cannot consume them before every store of
+//     chunk i is acknowledged: one store-drain latency per step, serialised with the arithmetic.  The loop is therefore
+//     software-pipelined with a FIXED issue order per step -- segment times of chunk i+2, coefficients of chunk i+1,
+//     stores of chunk i -- straight-line, so that the compiler's waitcnt counts stay exact: arithmetic of chunk i+1
+//     waits for "all but the 8 youngest" (the stores), never for a store.
+// Only full 64-sample chunks run through the pipeline; the (at most one) partial chunk of a launch takes the plain
+// path at the end.
+template <int ND, int N, int D>
+__global__ __launch_bounds__(kThreads) void mtg_sample_kernel_ct(SampleParams P, long long total) {
+  constexpr int R = ND * D;
+  constexpr int KMAX = 8;
+  static_assert(R % 2 == 1, "LDS image == output image needs an odd row length");
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* lds = lds_all + (size_t)wave * 64 * R;
+  double* row = lds + lane * R;
+  const long long nworkers = (long long)gridDim.x * (kThreads / 64);
+  const long long worker = (long long)blockIdx.x * (kThreads / 64) + wave;
+  const long long nfull = total / 64;                 // chunks that exist completely
+  const int K = P.K;
+
+  // this lane's (trajectory, sample) in chunk `ch` (clamped to the last full chunk: the pipeline requests up to two
+  // chunks past the end, harmlessly)
+  auto locate = [&](long long ch, long long& b, int& s_idx) {
+    if (ch >= nfull) ch = nfull - 1;
+    const long long idx = ch * 64 + lane;
+    b = idx / P.S;
+    s_idx = (int)(idx - b * P.S);
+  };
+  auto request_times = [&](long long b, double (&T)[KMAX]) {
+    const double* tt = P.times + b * P.ts_b;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) T[i] = tt[(long long)(i < K ? i : K - 1) * P.ts_k];   // branch-free: K <= KMAX
+  };
+  auto scan = [&](const double (&T)[KMAX], long long b, int s_idx) {
+    const double t = P.t_start + P.dt * s_idx;
+    double acc = 0.0, seg_start = 0.0, seg_time = T[0];
+    int seg = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      if (i < K) {                                     // wave-uniform, arithmetic only
+        if (!found) { seg_time = T[i]; seg_start = acc; seg = i; }
+        acc += T[i];
+        found = found || acc > t;
+      }
+    }
+    SampleSite r;
+    r.local = t - seg_start;
+    if (r.local > seg_time) r.local = seg_time;
+    r.c = P.coeffs + ((b * K + seg) * D) * (long long)N;
+    return r;
+  };
+  auto evaluate_into_row = [&](const double (&c)[D * N], double t) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double a[ND];
+#pragma unroll
+      for (int m = 0; m < ND; ++m) a[m] = 0.0;
+#pragma unroll
+      for (int j = N - 1; j >= 0; --j) {
+#pragma unroll
+        for (int m = ND - 1; m >= 1; --m) a[m] = __builtin_fma(a[m], t, a[m - 1]);
+        a[0] = __builtin_fma(a[0], t, c[d * N + j]);
+      }
+      double fact = 1.0;
+#pragma unroll
+      for (int m = 0; m < ND; ++m) {
+        if (m > 1) fact *= (double)m;
+        row[m * D + d] = m > 1 ? a[m] * fact : a[m];
+      }
+    }
+  };
+  auto fence = [] {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (worker < nfull) {
+    double c[D * N], T[KMAX];
+    long long b;
+    int s_idx;
+    // prologue: site and coefficients of the first chunk, times of the second
+    locate(worker, b, s_idx);
+    request_times(b, T);
+    SampleSite site = scan(T, b, s_idx);
+#pragma unroll
+    for (int i = 0; i < D * N; ++i) c[i] = site.c[i];
+    locate(worker + nworkers, b, s_idx);
+    request_times(b, T);
+    for (long long ch = worker; ch < nfull; ch += nworkers) {
+      evaluate_into_row(c, site.local);                          // needs c: every VMEM op younger than c is a store
+      site = scan(T, b, s_idx);                                  // chunk ch + W (its times arrived a step ago)
+      locate(ch + 2 * nworkers, b, s_idx);
+      request_times(b, T);                                       // issue order: times(ch + 2W) ...
+#pragma unroll
+      for (int i = 0; i < D * N; ++i) c[i] = site.c[i];          // ... coefficients(ch + W) ...
+      fence();
+      double* dst = P.out + ch * (64 * R);                       // ... stores(ch).  16-byte aligned: 64 * R is even
+      constexpr int kPairs = 64 * R / 2, kIter = (kPairs + 63) / 64;
+      d2 v[kIter];
+#pragma unroll
+      for (int i = 0; i < kIter; ++i)
+        if (lane + 64 * i < kPairs) v[i] = *reinterpret_cast<const d2*>(lds + 2 * (lane + 64 * i));
+#pragma unroll
+      for (int i = 0; i < kIter; ++i)
+        if (lane + 64 * i < kPairs) {
+          // non-temporal: a plain store stream fills the (write-back, write-allocate) L2 with dirty output lines and
+          // evicts the trajectory data every wave is about to read -- read latency under that load is what bounded the
+          // kernel (100k x 1000 samples: 3.2 ms with plain stores, 2.2 ms with nt).  The output is never re-read here.
+          __builtin_nontemporal_store(v[i], reinterpret_cast<d2*>(dst + 2 * (lane + 64 * i)));
+        }
+      fence();
+    }
+  }
+  // the partial last chunk of the launch (total % 64 samples): plain path, one wave
+  const int tail = (int)(total - nfull * 64);
+  if (tail > 0 && worker == (nfull % nworkers)) {
+    long long idx = nfull * 64 + (lane < tail ? lane : tail - 1);
+    const long long b = idx / P.S;
+    const SampleSite site = mtg_sample_site(P, b, (int)(idx - b * P.S));
+    double c[D * N];
+#pragma unroll
+    for (int i = 0; i < D * N; ++i) c[i] = site.c[i];
+    evaluate_into_row(c, site.local);
+    fence();
+    double* dst = P.out + nfull * (64 * R);
+    for (int e = lane; e < tail * R; e += 64) dst[e] = lds[e];
+    fence();
+  }
+}
+
+using SampleFn = void (*)(SampleParams, long long);
+template <int N, int D>
+SampleFn mtg_pick_sample_ct(int nd) {
+  if constexpr (D % 2 == 1) {
+    switch (nd) {
+      case 1: return mtg_sample_kernel_ct<1, N, D>;
+      case 3: return mtg_sample_kernel_ct<3, N, D>;
+      case 5: return mtg_sample_kernel_ct<5, N, D>;
+      default: return nullptr;
+    }
+  }
+  return nullptr;
 }
 
 __global__ void mtg_sample_valid_kernel(SampleParams P) {
@@ -173,7 +378,6 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
   const int R = n_derivatives * dimension;
   const size_t lds = (size_t)kThreads * (R | 1) * sizeof(double);
   long long blocks = (total + kThreads - 1) / kThreads;
-  if (blocks > 256 * 16) blocks = 256 * 16;
   void (*fn)(SampleParams, long long) = nullptr;
   switch (n_derivatives) {
     case 1: fn = mtg_sample_kernel<1>; break;
@@ -183,7 +387,23 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
     case 5: fn = mtg_sample_kernel<5>; break;
     default: return MTG_ERR_UNSUPPORTED;   // position .. snap (sampleTrajectoryInRange samples exactly these five)
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, P, total);
+  // compile-time shapes (odd results-per-sample, K <= 8): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D
+  SampleFn fast = nullptr;
+  if (n_segments <= 8 && total >= 64 && !getenv("MTG_SAMPLE_GENERIC")) {
+    if (n_coeffs == 10 && dimension == 3) fast = mtg_pick_sample_ct<10, 3>(n_derivatives);
+    else if (n_coeffs == 12 && dimension == 3) fast = mtg_pick_sample_ct<12, 3>(n_derivatives);
+    else if (n_coeffs == 8 && dimension == 3) fast = mtg_pick_sample_ct<8, 3>(n_derivatives);
+    else if (n_coeffs == 10 && dimension == 1) fast = mtg_pick_sample_ct<10, 1>(n_derivatives);
+  }
+  // persistent waves: as many workgroups as the device holds at once (occupancy x CUs), several chunks each
+  SampleFn launch_fn = fast ? fast : fn;
+  const size_t launch_lds = fast ? (size_t)kThreads * R * sizeof(double) : lds;
+  int per_cu = 0, n_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, launch_fn, kThreads, launch_lds) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu < 1) n_cu = 256;
+  if (blocks > (long long)per_cu * n_cu) blocks = (long long)per_cu * n_cu;
+  hipLaunchKernelGGL(launch_fn, dim3((unsigned)blocks), dim3(kThreads), launch_lds, (hipStream_t)stream, P, total);
   if (n_valid)
     hipLaunchKernelGGL(mtg_sample_valid_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
   return hipGetLastError() == hipSuccess ? MTG_OK : MTG_ERR_DEVICE;

@@ -412,7 +412,13 @@ def test_batched_sampling_vs_oracle(ctx):
     samples past the end (clamped, counted out by n_valid), SoA times, N = 12 and D = 4."""
     import torch
     import mav_trajectory_generation_amd as m
-    for (n, d, k, dim, bsz, S, nd) in [(10, 4, 8, 3, 37, 101, 5), (12, 5, 3, 4, 5, 64, 5), (8, 3, 5, 1, 9, 33, 3)]:
+    # shapes: compile-time kernels (N in {10, 12, 8} x D = 3, N = 10 x D = 1; ND in {1, 3, 5}; K <= 8) with full chunks,
+    # a partial last chunk, fewer than 64 samples in total and more workers than chunks; run-time-shape kernel otherwise
+    # (even ND * D, K > 8, other N)
+    for (n, d, k, dim, bsz, S, nd) in [(10, 4, 8, 3, 37, 101, 5), (12, 5, 3, 4, 5, 64, 5), (8, 3, 5, 1, 9, 33, 3),
+                                       (10, 4, 8, 3, 700, 128, 5), (10, 4, 8, 3, 3, 17, 5), (10, 4, 2, 3, 64, 9, 3),
+                                       (12, 5, 4, 3, 50, 77, 1), (8, 3, 8, 3, 41, 100, 5), (10, 4, 6, 1, 33, 65, 5),
+                                       (10, 4, 16, 3, 21, 90, 5), (10, 4, 8, 3, 20, 50, 2), (6, 2, 4, 3, 11, 70, 3)]:
         masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 515 + n)
         plan = m.Plan(ctx, n, dim, k, d, masks)
         t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
@@ -423,7 +429,10 @@ def test_batched_sampling_vs_oracle(ctx):
         ctx.sync()
         want, want_nv = onp.sample_batch(co.cpu().numpy(), times, 0.0, dt, S, nd)
         got = out.cpu().numpy()
-        scale = np.abs(want).max(axis=(1, 3), keepdims=True) + 1e-300
+        # per (trajectory, derivative) scale, floored by the trajectory's overall magnitude: with few segments and a
+        # coarse grid every sample can sit on a rest vertex, where the true derivatives are 0 and both sides hold noise
+        scale = np.abs(want).max(axis=(1, 3), keepdims=True)
+        scale = np.maximum(scale, 1e-2 * np.abs(want).max(axis=(1, 2, 3), keepdims=True)) + 1e-300
         assert (np.abs(got - want) / scale).max() < 1e-11
         assert np.array_equal(nv.cpu().numpy(), want_nv)
         assert torch.equal(out, out_soa)
