@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef MTG_SAMPLE_CT_WAVES
+#define MTG_SAMPLE_CT_WAVES 4   // waves per SIMD the compile-time-shape kernels are held to (A/B knob)
+#endif
 constexpr int kMaxN = MTG_MAX_N;
 
 struct SampleParams {
@@ -192,16 +195,25 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, lo
 // Only full 64-sample chunks run through the pipeline; the (at most one) partial chunk of a launch takes the plain
 // path at the end.
 template <int ND, int N, int D>
-__global__ __launch_bounds__(kThreads) void mtg_sample_kernel_ct(SampleParams P, long long total) {
+__global__ __launch_bounds__(kThreads, MTG_SAMPLE_CT_WAVES) void mtg_sample_kernel_ct(SampleParams P, long long total) {
   constexpr int R = ND * D;
+  constexpr int RS = R | 1;        // LDS row stride: odd => the transposing ds_write_b64 are conflict-free
   constexpr int KMAX = 8;
-  static_assert(R % 2 == 1, "LDS image == output image needs an odd row length");
   typedef double d2 __attribute__((ext_vector_type(2)));
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  double* lds = lds_all + (size_t)wave * 64 * R;
-  double* row = lds + lane * R;
+  double* lds = lds_all + (size_t)wave * 64 * RS;
+  double* row = lds + lane * RS;
+  // write-out: pair p = lane + 64*i of the chunk's 64*R/2 output pairs.  Odd R: the slab is the output image, pair p
+  // sits at doubles [2p, 2p+1].  Even R: rows are padded by one double; a pair never straddles a row (R/2 pairs each).
+  constexpr int kPairs = 64 * R / 2, kIter = (kPairs + 63) / 64;
+  int loff[kIter];
+#pragma unroll
+  for (int i = 0; i < kIter; ++i) {
+    const int pr = lane + 64 * i;
+    loff[i] = (R % 2) ? 2 * pr : (pr / (R / 2 > 0 ? R / 2 : 1)) * RS + 2 * (pr % (R / 2 > 0 ? R / 2 : 1));
+  }
   const long long nworkers = (long long)gridDim.x * (kThreads / 64);
   const long long worker = (long long)blockIdx.x * (kThreads / 64) + wave;
   const long long nfull = total / 64;                 // chunks that exist completely
@@ -286,19 +298,28 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel_ct(SampleParams P,
       for (int i = 0; i < D * N; ++i) c[i] = site.c[i];          // ... coefficients(ch + W) ...
       fence();
       double* dst = P.out + ch * (64 * R);                       // ... stores(ch).  16-byte aligned: 64 * R is even
-      constexpr int kPairs = 64 * R / 2, kIter = (kPairs + 63) / 64;
-      d2 v[kIter];
+      // non-temporal: a plain store stream fills the (write-back, write-allocate) L2 with dirty output lines and
+      // evicts the trajectory data every wave is about to read -- read latency under that load is what bounded the
+      // kernel (100k x 1000 samples: 3.2 ms with plain stores, 2.2 ms with nt).  The output is never re-read here.
+      constexpr int G = 4;   // LDS reads in groups ahead of their stores
 #pragma unroll
-      for (int i = 0; i < kIter; ++i)
-        if (lane + 64 * i < kPairs) v[i] = *reinterpret_cast<const d2*>(lds + 2 * (lane + 64 * i));
+      for (int i0 = 0; i0 < kIter; i0 += G) {
+        d2 v[G];
 #pragma unroll
-      for (int i = 0; i < kIter; ++i)
-        if (lane + 64 * i < kPairs) {
-          // non-temporal: a plain store stream fills the (write-back, write-allocate) L2 with dirty output lines and
-          // evicts the trajectory data every wave is about to read -- read latency under that load is what bounded the
-          // kernel (100k x 1000 samples: 3.2 ms with plain stores, 2.2 ms with nt).  The output is never re-read here.
-          __builtin_nontemporal_store(v[i], reinterpret_cast<d2*>(dst + 2 * (lane + 64 * i)));
-        }
+        for (int i = 0; i < G; ++i)
+          if (i0 + i < kIter && lane + 64 * (i0 + i) < kPairs) {
+            if constexpr (R % 2 == 1) {
+              v[i] = *reinterpret_cast<const d2*>(lds + loff[i0 + i]);
+            } else {
+              v[i].x = lds[loff[i0 + i]];
+              v[i].y = lds[loff[i0 + i] + 1];
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          if (i0 + i < kIter && lane + 64 * (i0 + i) < kPairs)
+            __builtin_nontemporal_store(v[i], reinterpret_cast<d2*>(dst + 2 * (lane + 64 * (i0 + i))));
+      }
       fence();
     }
   }
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel_ct(SampleParams P,
     evaluate_into_row(c, site.local);
     fence();
     double* dst = P.out + nfull * (64 * R);
-    for (int e = lane; e < tail * R; e += 64) dst[e] = lds[e];
+    for (int e = lane; e < tail * R; e += 64) dst[e] = lds[(e / R) * RS + e % R];
     fence();
   }
 }
@@ -322,15 +343,14 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel_ct(SampleParams P,
 using SampleFn = void (*)(SampleParams, long long);
 template <int N, int D>
 SampleFn mtg_pick_sample_ct(int nd) {
-  if constexpr (D % 2 == 1) {
-    switch (nd) {
-      case 1: return mtg_sample_kernel_ct<1, N, D>;
-      case 3: return mtg_sample_kernel_ct<3, N, D>;
-      case 5: return mtg_sample_kernel_ct<5, N, D>;
-      default: return nullptr;
-    }
+  switch (nd) {
+    case 1: return mtg_sample_kernel_ct<1, N, D>;
+    case 2: return mtg_sample_kernel_ct<2, N, D>;
+    case 3: return mtg_sample_kernel_ct<3, N, D>;
+    case 4: return mtg_sample_kernel_ct<4, N, D>;
+    case 5: return mtg_sample_kernel_ct<5, N, D>;
+    default: return nullptr;
   }
-  return nullptr;
 }
 
 __global__ void mtg_sample_valid_kernel(SampleParams P) {
@@ -387,17 +407,19 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
     case 5: fn = mtg_sample_kernel<5>; break;
     default: return MTG_ERR_UNSUPPORTED;   // position .. snap (sampleTrajectoryInRange samples exactly these five)
   }
-  // compile-time shapes (odd results-per-sample, K <= 8): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D
+  // compile-time shapes (K <= 8): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D (yaw) and 4-D (x, y, z, yaw)
   SampleFn fast = nullptr;
   if (n_segments <= 8 && total >= 64 && !getenv("MTG_SAMPLE_GENERIC")) {
     if (n_coeffs == 10 && dimension == 3) fast = mtg_pick_sample_ct<10, 3>(n_derivatives);
     else if (n_coeffs == 12 && dimension == 3) fast = mtg_pick_sample_ct<12, 3>(n_derivatives);
     else if (n_coeffs == 8 && dimension == 3) fast = mtg_pick_sample_ct<8, 3>(n_derivatives);
     else if (n_coeffs == 10 && dimension == 1) fast = mtg_pick_sample_ct<10, 1>(n_derivatives);
+    else if (n_coeffs == 10 && dimension == 4) fast = mtg_pick_sample_ct<10, 4>(n_derivatives);
+    else if (n_coeffs == 12 && dimension == 4) fast = mtg_pick_sample_ct<12, 4>(n_derivatives);
   }
   // persistent waves: as many workgroups as the device holds at once (occupancy x CUs), several chunks each
   SampleFn launch_fn = fast ? fast : fn;
-  const size_t launch_lds = fast ? (size_t)kThreads * R * sizeof(double) : lds;
+  const size_t launch_lds = fast ? (size_t)kThreads * (R | 1) * sizeof(double) : lds;
   int per_cu = 0, n_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, launch_fn, kThreads, launch_lds) != hipSuccess || per_cu < 1)
     per_cu = 4;
