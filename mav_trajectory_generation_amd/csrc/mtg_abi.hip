@@ -443,8 +443,14 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     // dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.
     const MtgStaticEntry* var = nullptr;
     if (!(flags & MTG_FLAG_GENERIC_KERNEL)) {
-      const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) ||
-                              (!(flags & MTG_FLAG_FUSED_DIMS) && ntiles < 4 * ctx->n_cu);
+      // Dimension-split form while ALL its workgroups (tiles x dimension groups) are resident at once at <= 2 waves per
+      // SIMD (4 x CUs workgroups); beyond that it runs in rounds and the fused form -- no repeated factorisation, one
+      // round up to 2 x CUs tiles -- wins (measured, N = 10 / K = 8 / D = 3: B = 20k 15.0 vs 15.4 us, B = 30k 25.5 vs
+      // 18.3 us, B = 60k 44.1 vs 34.3 us).  Plans whose fused kernel spills ("heavy") keep the split form longer.
+      bool auto_split = ntiles < 4 * ctx->n_cu;
+      if (p->fast && p->fast_split && !p->fast->heavy)
+        auto_split = (long long)ntiles * (p->D / p->fast_split->d) <= 4ll * ctx->n_cu;
+      const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) || (!(flags & MTG_FLAG_FUSED_DIMS) && auto_split);
       var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
       if (var && var->heavy && !want_split) {   // large launch, spilling static kernel: the rolled form is faster
         const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
