@@ -125,8 +125,9 @@ def main():
         torch.cuda.synchronize()
         fill_us = e0.elapsed_time(e1) * 1e3 / 50
         extra = {}
-        if args.extra and rank == 0:
-            for big in (125_000, 1_000_000):
+        if rank == 0:
+            # the per-GPU share of BASELINE configs[2] (1M over 8 GPUs) always; --extra adds 1M on this GPU + host paths
+            for big in ((125_000, 1_000_000) if args.extra else (125_000,)):
                 tb, fb = m.random_waypoint_batch(big, K, D, N, masks, seed=99, device=dev, layout=args.layout)
                 cb = torch.empty((big, K, D, N), dtype=torch.float64, device=dev)
                 plan.solve(tb, fb, layout=args.layout, coeffs=cb, dims=args.dims)
@@ -136,14 +137,20 @@ def main():
                                          "GBps": big * plan.bytes_per_trajectory / us * 1e-3,
                                          "frac_of_8TBps": big * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
                 del tb, fb, cb
-            # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value
-            th, fh = t.t().contiguous().cpu().numpy() if args.layout == "soa" else t.cpu().numpy(), None
-            fh = (f.permute(2, 0, 1).contiguous() if args.layout == "soa" else f).cpu().numpy()
-            plan.solve_host(th, fh, want_free=False, want_cost=False)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                plan.solve_host(th, fh, want_free=False, want_cost=False)
-            extra["host_pointers_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
+        if args.extra and rank == 0:
+            # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value.  Pageable
+            # numpy arrays go through the runtime's staged copies; page-locked ones (here: torch pinned tensors viewed as
+            # numpy) are DMA'd directly.
+            th = (t.t().contiguous() if args.layout == "soa" else t).cpu()
+            fh = (f.permute(2, 0, 1).contiguous() if args.layout == "soa" else f).cpu()
+            for tag, tt_, ff_ in (("pageable", th.numpy(), fh.numpy()),
+                                  ("pinned", th.pin_memory().numpy(), fh.pin_memory().numpy())):
+                co_h = torch.empty((B, K, D, N), dtype=torch.float64, pin_memory=(tag == "pinned")).numpy()
+                plan.solve_host(tt_, ff_, want_free=False, want_cost=False, coeffs=co_h)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    plan.solve_host(tt_, ff_, want_free=False, want_cost=False, coeffs=co_h)
+                extra[f"host_pointers_{tag}_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")

@@ -255,12 +255,16 @@ class Plan:
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, cost
 
-    def solve_host(self, times: np.ndarray, d_fixed: np.ndarray, want_free=True, want_cost=True, generic=False):
-        """Host-buffer convenience (AoS numpy in/out, staged through the device by the library)."""
+    def solve_host(self, times: np.ndarray, d_fixed: np.ndarray, want_free=True, want_cost=True, generic=False,
+                   coeffs: Optional[np.ndarray] = None):
+        """Host-buffer convenience (AoS numpy in/out, staged through the device by the library).  Pass page-locked
+        arrays (e.g. pinned torch tensors viewed as numpy, also for `coeffs`) to have them DMA'd directly."""
         times = np.ascontiguousarray(times, dtype=np.float64)
         d_fixed = np.ascontiguousarray(d_fixed, dtype=np.float64)
         batch = times.shape[0]
-        coeffs = np.empty((batch, self.K, self.D, self.N))
+        if coeffs is None:
+            coeffs = np.empty((batch, self.K, self.D, self.N))
+        assert coeffs.dtype == np.float64 and coeffs.flags.c_contiguous and coeffs.size == batch * self.K * self.D * self.N
         d_free = np.empty((batch, self.D, self.n_free)) if want_free else None
         cost = np.empty((batch,)) if want_cost else None
         lay = self.layout(batch, "aos")
