@@ -353,29 +353,25 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
 
 // One forward elimination step (chain step j): completes the left vertex, produces
 // (G, g) for back-substitution and the carried Schur complement for the right vertex.
+// The arithmetic of one step on inputs that are already in registers: segment time T and the (unscaled) fixed values of
+// the left / right vertex, zeros at free slots.  The rolled chain loops request the inputs of step j+1 before step j's
+// back-substitution data is stored (see mtg_lane_forward).
 template <class C, int DIR>
-MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, int ml, int mr, MtgLane<C>& ln,
-                         double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
+MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln, double T,
+                              const double (&fix_l)[C::D][C::H], const double (&fix_r)[C::D][C::H],
+                              double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D, N = C::N;
-  const int K = mtg_nseg<C>(P);
-  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j), vr = mtg_vr<DIR>(K, j);
-
-  double T;
-  if constexpr (C::kStatic) T = ln.T[j];
-  else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   double s[H], bs[H], tinv;
   mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, ln.flags);
 
-  double val_l[D][H], val_r[D][H];
-  mtg_load_vals<C, DIR>(P, b, vl, ml, ln, val_l);
-  mtg_load_vals<C, DIR>(P, b, vr, mr, ln, val_r);
   // scaled fixed values
+  double val_l[D][H], val_r[D][H];
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      val_l[dm][p] *= s[p];
-      val_r[dm][p] *= s[p];
+      val_l[dm][p] = fix_l[dm][p] * s[p];
+      val_r[dm][p] = fix_r[dm][p] * s[p];
     }
   }
 
@@ -501,6 +497,24 @@ MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, int ml, int mr,
       for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-U[m][p], g[dm][m], ln.rc[dm][p]);
     }
   }
+}
+
+// segment time of chain step j (static mode: preloaded register; otherwise a global load)
+template <class C, int DIR>
+MTG_HD double mtg_step_time(const MtgParams& P, long long b, int j, const MtgLane<C>& ln) {
+  if constexpr (C::kStatic) return ln.T[j];
+  else return P.times[b * P.ts_b + (long long)mtg_seg<DIR>(mtg_nseg<C>(P), j) * P.ts_k];
+}
+
+template <class C, int DIR>
+MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, int ml, int mr, MtgLane<C>& ln,
+                         double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
+  const int K = mtg_nseg<C>(P);
+  const double T = mtg_step_time<C, DIR>(P, b, j, ln);
+  double fix_l[C::D][C::H], fix_r[C::D][C::H];
+  mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, j), ml, ln, fix_l);
+  mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, j), mr, ln, fix_r);
+  mtg_fwd_step_core<C, DIR>(P, ml, mr, ln, T, fix_l, fix_r, G, g);
 }
 
 // Output policy that stores one lane's D*N coefficients of a segment straight to global memory
@@ -759,21 +773,16 @@ MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, con
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
-template <class C, int DIR, int OUT, class IO>
-MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int mr, const MtgLane<C>& ln,
-                           const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
-                           double (&xr)[C::D][C::H], IO& io, bool active) {
+// Back-substitution of one chain step: xl = [fixed values | g - G xr] (all slots of the left vertex).  fix_l: the
+// (unscaled) fixed values of the left vertex, already in registers.  G and g are dead afterwards.
+template <class C>
+MTG_HD void mtg_bwd_backsub(int ml, int mr, const double (&fix_l)[C::D][C::H], const double (&G)[C::H][C::H],
+                            const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H], double (&xl)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D;
-  const int K = mtg_nseg<C>(P);
-  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j);
-  double xl[D][H];
-  mtg_load_vals<C, DIR>(P, b, vl, ml, ln, xl);
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
-    for (int p = 0; p < H; ++p) {
-      if (!((ml >> p) & 1)) xl[dm][p] = g[dm][p];
-    }
+    for (int p = 0; p < H; ++p) xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : g[dm][p];
   }
 #pragma unroll
   for (int q = 0; q < H; ++q) {
@@ -785,13 +794,20 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
       for (int dm = 0; dm < D; ++dm) xl[dm][p] = mtg_fma(-G[p][q], xr[dm][q], xl[dm][p]);
     }
   }
-  // No `active` guard here: tail lanes are clamped duplicates of the last trajectory and store identical values
-  // to identical addresses.  A per-lane condition inside this loop makes the compiler unswitch the loop on it,
-  // and the wave-cooperative coefficient drain (all 64 lanes must take part together) would run in two halves.
+}
+
+// Second half of a backward step: optional d_P output, coefficient recovery of the segment the step completes
+// (T: its time), xr <- xl.
+// No `active` guard: tail lanes are clamped duplicates of the last trajectory and store identical values to identical
+// addresses.  A per-lane condition here makes the compiler unswitch the chain loop on it, and the wave-cooperative
+// coefficient drain (all 64 lanes must take part together) would run in two halves.
+template <class C, int DIR, int OUT, class IO>
+MTG_HD double mtg_bwd_finish(const MtgParams& P, long long b, int j, int ml, double T, const double (&xl)[C::D][C::H],
+                             double (&xr)[C::D][C::H], IO& io) {
+  constexpr int H = C::H, D = C::D;
+  const int K = mtg_nseg<C>(P);
+  const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j);
   mtg_store_free<C, OUT>(P, b, vl, ml, xl);
-  double T;
-  if constexpr (C::kStatic) T = ln.T[j];
-  else T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   double cost;
   if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr, io);
   else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl, io);
@@ -801,6 +817,17 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
     for (int p = 0; p < H; ++p) xr[dm][p] = xl[dm][p];
   }
   return cost;
+}
+
+template <class C, int DIR, int OUT, class IO>
+MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int mr, const MtgLane<C>& ln,
+                           const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
+                           double (&xr)[C::D][C::H], IO& io, bool active) {
+  (void)active;
+  double fix_l[C::D][C::H], xl[C::D][C::H];
+  mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(mtg_nseg<C>(P), j), ml, ln, fix_l);
+  mtg_bwd_backsub<C>(ml, mr, fix_l, G, g, xr, xl);
+  return mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
 }
 
 // Back-substitution data of one chain step in the lane-coalesced workspace (element stride = number of lanes):
@@ -886,26 +913,47 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
   } else {
     const int K = P.K;
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
-    for (int j = 0; j < kc; ++j) {
-      double G[H][H], g[D][H];
-      int ml, mr;
-      if constexpr (C::kRolled) {
-        // K >= 2: step 0 starts at a trajectory end, every other vertex of the half-chain (incl. the middle
-        // one) carries the interior mask => the loop body is compiled once with constant masks
-        mr = C::MI;
-        if (j == 0) {
-          ml = DIR > 0 ? C::MS : C::ME;
-          mtg_fwd_step<C, DIR>(P, b, j, DIR > 0 ? C::MS : C::ME, C::MI, ln, G, g);
-        } else {
-          ml = C::MI;
-          mtg_fwd_step<C, DIR>(P, b, j, C::MI, C::MI, ln, G, g);
+    if constexpr (C::kRolled) {
+      // K >= 2: step 0 starts at a trajectory end, every other vertex of the half-chain (incl. the middle one)
+      // carries the interior mask => the loop body is compiled with constant masks.
+      // Issue order per step: inputs of step j+1 (segment time, fixed values of its right vertex), arithmetic of step
+      // j, then step j's back-substitution stores.  Loads and stores share the in-order vmcnt counter on this
+      // hardware: with the loads at the top of the NEXT iteration instead, waiting for them meant waiting for every
+      // one of the ~H*H + D*H workspace stores of the previous step to be acknowledged -- one full store round trip
+      // per chain step, serialised (measured: ~10 us per step at B = 100k, K = 32).
+      constexpr int M0 = DIR > 0 ? C::MS : C::ME;
+      double T_cur = mtg_step_time<C, DIR>(P, b, 0, ln);
+      double fl[D][H], fr[D][H];
+      mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, 0), M0, ln, fl);
+      mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, 0), C::MI, ln, fr);
+      for (int j = 0; j < kc; ++j) {
+        double G[H][H], g[D][H];
+        const int jn = j + 1 < kc ? j + 1 : j;     // last step: harmless reload, keeps the issue pattern uniform
+        const double T_nxt = mtg_step_time<C, DIR>(P, b, jn, ln);
+        double fn[D][H];
+        mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, jn), C::MI, ln, fn);
+        if (j == 0) mtg_fwd_step_core<C, DIR>(P, M0, C::MI, ln, T_cur, fl, fr, G, g);
+        else mtg_fwd_step_core<C, DIR>(P, C::MI, C::MI, ln, T_cur, fl, fr, G, g);
+        mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, j == 0 ? M0 : C::MI,
+                        C::MI);
+        T_cur = T_nxt;
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+          for (int p = 0; p < H; ++p) {
+            fl[dm][p] = fr[dm][p];
+            fr[dm][p] = fn[dm][p];
+          }
         }
-      } else {
-        ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j));
-        mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
-        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
       }
-      mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, ml, mr);
+    } else {
+      for (int j = 0; j < kc; ++j) {
+        double G[H][H], g[D][H];
+        const int ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j));
+        const int mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
+        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
+        mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, ml, mr);
+      }
     }
   }
 }
@@ -940,18 +988,37 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
     }
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;
-    for (int j = kc - 1; j >= 0; --j) {
-      double G[H][H], g[D][H];
-      const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
-      if constexpr (C::kRolled) {
+    if constexpr (C::kRolled) {
+      // Same discipline as the forward loop: the back-substitution data (G, g), segment time and fixed values of step
+      // j-1 are requested right after step j's back-substitution has consumed its own (same registers), i.e. BEFORE
+      // step j recovers its segment and streams out the previous one -- waiting for them never includes a store.
+      constexpr int M0 = DIR > 0 ? C::MS : C::ME;
+      double G[H][H], g[D][H], fl[D][H];
+      double T_cur = 0.0;
+      auto request = [&](int j) {
+        const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
         if (j == 0) {
-          mtg_ws_load<C>(w, P.ws_stride, G, g, DIR > 0 ? C::MS : C::ME, C::MI);
-          cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, DIR > 0 ? C::MS : C::ME, C::MI, ln, G, g, xr, io, active);
+          mtg_ws_load<C>(w, P.ws_stride, G, g, M0, C::MI);
+          mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, j), M0, ln, fl);
         } else {
           mtg_ws_load<C>(w, P.ws_stride, G, g, C::MI, C::MI);
-          cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, C::MI, C::MI, ln, G, g, xr, io, active);
+          mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, j), C::MI, ln, fl);
         }
-      } else {
+        T_cur = mtg_step_time<C, DIR>(P, b, j, ln);
+      };
+      if (kc > 0) request(kc - 1);
+      for (int j = kc - 1; j >= 0; --j) {
+        double xl[D][H];
+        const double T_use = T_cur;
+        if (j == 0) mtg_bwd_backsub<C>(M0, C::MI, fl, G, g, xr, xl);
+        else mtg_bwd_backsub<C>(C::MI, C::MI, fl, G, g, xr, xl);
+        if (j > 0) request(j - 1);
+        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, j == 0 ? M0 : C::MI, T_use, xl, xr, io);
+      }
+    } else {
+      for (int j = kc - 1; j >= 0; --j) {
+        double G[H][H], g[D][H];
+        const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
         const int ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
         mtg_ws_load<C>(w, P.ws_stride, G, g, ml, mr);
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, G, g, xr, io, active);
