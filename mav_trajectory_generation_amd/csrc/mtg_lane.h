@@ -1069,16 +1069,28 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b, IO& io, bool active
       }
     }
   };
+  // Issue order per segment: vertex i+2 and time i+1 are requested BEFORE segment i is recovered (which streams out
+  // segment i-1): loads and stores retire through one in-order counter, so a load issued after a store cannot be
+  // consumed before that store is acknowledged.
+  double xc[D][H];
   load_vertex(0, xa);
+  load_vertex(1, xb);
+  double T = P.times[b * P.ts_b];
   for (int i = 0; i < K; ++i) {
-    load_vertex(i + 1, xb);
-    const double T = P.times[b * P.ts_b + (long long)i * P.ts_k];
+    const int vn = i + 2 <= K ? i + 2 : K;         // last segment: harmless reload of the end vertex
+    const int tn = i + 1 < K ? i + 1 : i;
+    load_vertex(vn, xc);
+    const double T_nxt = P.times[b * P.ts_b + (long long)tn * P.ts_k];
     if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
     cost += mtg_recover<C, OUT>(P, b, i, T, xa, xb, io);
+    T = T_nxt;
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
-      for (int p = 0; p < H; ++p) xa[dm][p] = xb[dm][p];
+      for (int p = 0; p < H; ++p) {
+        xa[dm][p] = xb[dm][p];
+        xb[dm][p] = xc[dm][p];
+      }
     }
   }
   io.drain(P);
