@@ -18,6 +18,8 @@
 #include <numeric>
 #include <vector>
 
+#include <map>
+
 #include "../../mtg_hip.h"
 #include "motion_defines.h"
 #include "polynomial.h"
@@ -29,12 +31,23 @@
 namespace mav_trajectory_generation {
 
 namespace mtg_compat_detail {
+// One library context per host thread, plus that thread's plans keyed by constraint structure: the reference's callers
+// set the same structure up over and over (every nlopt objective call, every run of the timing benchmark), and a plan
+// costs a device allocation + a synchronous table upload to create and a stream synchronisation to destroy.
 struct ThreadContext {
   mtg_context* ctx = nullptr;
-  ~ThreadContext() { if (ctx) mtg_context_destroy(ctx); }
+  std::map<std::vector<uint32_t>, std::shared_ptr<mtg_plan>> plans;
+  ~ThreadContext() {
+    plans.clear();
+    if (ctx) mtg_context_destroy(ctx);
+  }
 };
-inline mtg_context* context() {
+inline ThreadContext& thread_state() {
   static thread_local ThreadContext tc;
+  return tc;
+}
+inline mtg_context* context() {
+  ThreadContext& tc = thread_state();
   if (!tc.ctx) {
     const int rc = mtg_context_create(0, nullptr, &tc.ctx);
     CHECK(rc == MTG_OK) << "mtg_context_create: " << mtg_status_string(rc) << " (the solver has no CPU fallback)";
@@ -42,11 +55,20 @@ inline mtg_context* context() {
   return tc.ctx;
 }
 inline std::shared_ptr<mtg_plan> make_plan(int N, int D, int K, int derivative, const std::vector<uint32_t>& mask) {
+  std::vector<uint32_t> key{(uint32_t)N, (uint32_t)D, (uint32_t)K, (uint32_t)derivative};
+  key.insert(key.end(), mask.begin(), mask.end());
+  mtg_context* ctx = context();
+  ThreadContext& tc = thread_state();
+  auto it = tc.plans.find(key);
+  if (it != tc.plans.end()) return it->second;
   mtg_plan_desc desc{N, D, K, derivative, mask.data()};
   mtg_plan* p = nullptr;
-  const int rc = mtg_plan_create(context(), &desc, &p);
-  CHECK(rc == MTG_OK) << "mtg_plan_create: " << mtg_status_string(rc) << " " << mtg_last_error_string(context());
-  return std::shared_ptr<mtg_plan>(p, [](mtg_plan* q) { mtg_plan_destroy(q); });
+  const int rc = mtg_plan_create(ctx, &desc, &p);
+  CHECK(rc == MTG_OK) << "mtg_plan_create: " << mtg_status_string(rc) << " " << mtg_last_error_string(ctx);
+  std::shared_ptr<mtg_plan> sp(p, [](mtg_plan* q) { mtg_plan_destroy(q); });
+  if (tc.plans.size() >= 256) tc.plans.clear();   // bounded; live optimisers keep their own references
+  tc.plans.emplace(std::move(key), sp);
+  return sp;
 }
 inline void check_sync() {
   const int rc = mtg_context_sync(context());

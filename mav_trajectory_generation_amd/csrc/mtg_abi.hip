@@ -94,6 +94,12 @@ struct mtg_context {
   bool own_stream = false;
   int* d_status = nullptr;
   int* h_status = nullptr;  // pinned
+  // small host-pointer calls (the single-trajectory drop-in path): one page-locked bounce buffer, so that a call is one
+  // H2D DMA, the kernel, one D2H DMA and one synchronisation instead of five staged pageable copies
+  double* h_bounce = nullptr;
+  size_t h_bounce_bytes = 0;
+  int pending_status = 0;   // flags already fetched from the device by a host-pointer call, reported at the next sync
+  bool dirty = true;        // device work enqueued since the status word was last fetched
   int n_cu = 256;
   // measurement knobs, read once from the environment at context creation (A/B runs in tools/; 0 = off)
   int knob_force_dg = 0;        // MTG_FORCE_DG: dimension-group size of the specialised kernels
@@ -232,6 +238,7 @@ int mtg_context_destroy(mtg_context* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->d_status) hipFree(ctx->d_status);
   if (ctx->h_status) hipHostFree(ctx->h_status);
+  if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return MTG_OK;
@@ -242,6 +249,7 @@ int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device) {
   if (!ctx || !stream || !device) return MTG_ERR_INVALID_ARGUMENT;
   *stream = (void*)ctx->stream;
   *device = ctx->device;
+  ctx->dirty = true;   // the caller is about to enqueue kernels that may raise status flags
   return MTG_OK;
 }
 
@@ -289,10 +297,15 @@ int mtg_copy_to_host(mtg_context* ctx, void* dst_host, const void* src_device, s
 int mtg_context_sync(mtg_context* ctx) {
   if (!ctx) return MTG_ERR_INVALID_ARGUMENT;
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
-  MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const int st = *ctx->h_status;
+  if (ctx->dirty) {
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+    MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pending_status |= *ctx->h_status;
+    ctx->dirty = false;
+  }
+  const int st = ctx->pending_status;
+  ctx->pending_status = 0;
   if (st & MTG_FLAG_BAD_TIME) return set_err(ctx, MTG_ERR_BAD_SEGMENT_TIME, mtg_status_string(MTG_ERR_BAD_SEGMENT_TIME));
   if (st & MTG_FLAG_SINGULAR) return set_err(ctx, MTG_ERR_SINGULAR, mtg_status_string(MTG_ERR_SINGULAR));
   return MTG_OK;
@@ -397,6 +410,9 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
 
   const double* dt = times; const double* dfx = d_fixed; double* dco = coeffs; double* dfr = d_free; double* dcs = cost;
   const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
+  bool bounce = false;
+  constexpr size_t kBounceLimit = 1u << 20;
+  if (!host) ctx->dirty = true;
   if (host) {
     const size_t need = (size_t)(n_times + n_fix + n_fre + n_coef + batch) * sizeof(double);
     int rc = ensure_buffer(ctx, &p->stage, &p->stage_bytes, need);
@@ -407,9 +423,26 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     double* s_p = s; s += n_fre;
     double* s_c = s; s += n_coef;
     double* s_j = s;
-    MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, times, n_times * sizeof(double), hipMemcpyHostToDevice, st));
-    if (n_fix) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_f, d_fixed, n_fix * sizeof(double), hipMemcpyHostToDevice, st));
-    if (update_only && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_p, d_free, n_fre * sizeof(double), hipMemcpyHostToDevice, st));
+    // small calls go through the context's page-locked bounce buffer: [times | d_fixed | d_free] is one H2D DMA
+    const size_t n_in = (size_t)(n_times + n_fix + (update_only ? n_fre : 0));
+    bounce = need <= kBounceLimit;
+    if (bounce) {
+      if (ctx->h_bounce_bytes < need) {
+        if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
+        ctx->h_bounce = nullptr;
+        ctx->h_bounce_bytes = 0;
+        MTG_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_bounce, kBounceLimit, hipHostMallocDefault));
+        ctx->h_bounce_bytes = kBounceLimit;
+      }
+      std::memcpy(ctx->h_bounce, times, n_times * sizeof(double));
+      if (n_fix) std::memcpy(ctx->h_bounce + n_times, d_fixed, n_fix * sizeof(double));
+      if (update_only && n_fre) std::memcpy(ctx->h_bounce + n_times + n_fix, d_free, n_fre * sizeof(double));
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, ctx->h_bounce, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, times, n_times * sizeof(double), hipMemcpyHostToDevice, st));
+      if (n_fix) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_f, d_fixed, n_fix * sizeof(double), hipMemcpyHostToDevice, st));
+      if (update_only && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_p, d_free, n_fre * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     dt = s_t; dfx = s_f; dco = s_c;
     dfr = (d_free && n_fre) ? s_p : nullptr;
     dcs = cost ? s_j : nullptr;
@@ -518,10 +551,27 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   MTG_HIP_TRY(ctx, hipGetLastError());
 
   if (host) {
-    MTG_HIP_TRY(ctx, hipMemcpyAsync(coeffs, dco, n_coef * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
-    MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (bounce) {
+      // [d_free | coeffs | cost] sit back to back in the device staging area: one D2H DMA, plus the status word (the
+      // call synchronises anyway, so the flags are fetched now and reported by the next mtg_context_sync for free)
+      double* s_p = p->stage + n_times + n_fix;
+      const size_t n_out = (size_t)(n_fre + n_coef + batch);
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounce, s_p, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+      MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
+      MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+      ctx->pending_status |= *ctx->h_status;
+      ctx->dirty = false;
+      if (!update_only && d_free && n_fre) std::memcpy(d_free, ctx->h_bounce, n_fre * sizeof(double));
+      std::memcpy(coeffs, ctx->h_bounce + n_fre, n_coef * sizeof(double));
+      if (cost) std::memcpy(cost, ctx->h_bounce + n_fre + n_coef, batch * sizeof(double));
+    } else {
+      ctx->dirty = true;
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(coeffs, dco, n_coef * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
+      MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
   }
   return MTG_OK;
 }
@@ -550,6 +600,7 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   mtg_context* ctx = p->ctx;
   if (p->last.empty()) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "no recorded solve launch");
   std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->dirty = true;
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   MTG_HIP_TRY(ctx, hipEventCreate(&e0));
