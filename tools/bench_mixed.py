@@ -35,7 +35,7 @@ for n_streams in (1, 2, 4, 8):
     solver.close()
 
 # the same request captured once into a hipGraph (fork over 4 streams + join) and replayed: one host call per mixed batch
-for n_streams in (1, 4):
+for n_streams in (1, 4, 8, 12):
     solver = m.MixedBatchSolver(ctx, n_streams=n_streams)
     graph, out = solver.capture(buckets)
     for _ in range(5):
