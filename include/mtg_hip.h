@@ -186,6 +186,35 @@ int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coef
                                                 double a_max, int32_t max_iterations, double* workspace,
                                                 double* scaling, int32_t* within_range);
 
+/* ---- mixed requests: several plans in one launch ------------------------------------------
+ * What a caller of the reference does with a list of independent PolynomialOptimization<N>
+ * problems of different structure (BASELINE config 4: N in {8, 10, 12}, 4..32 segments): each
+ * structure is a plan + a batch.  A mixed request is created once -- items that share N, D, the
+ * start / interior / end constraint pattern and the derivative (any K >= 2) are merged into ONE
+ * kernel launch whose tiles are ordered longest-chain-first -- and solved as often as wanted
+ * with new values in the same device buffers (same structure, new segment times: every
+ * iteration of a time optimiser).  mtg_multi_solve only enqueues kernels (and memsets of the
+ * cost outputs) on the context's stream: it can be stream-captured into a hipGraph.
+ * Items that cannot be merged run as ordinary mtg_solve_linear launches.
+ * Device pointers only; all plans must belong to `ctx`.                                       */
+typedef struct mtg_multi mtg_multi;
+typedef struct mtg_multi_item {
+  mtg_plan* plan;
+  int64_t batch;
+  mtg_layout layout;
+  const double* times;     /* device */
+  const double* d_fixed;   /* device */
+  double* coeffs;          /* device, 16-byte aligned, [batch][K][D][N] */
+  double* d_free;          /* device, optional */
+  double* cost;            /* device, optional */
+} mtg_multi_item;
+/* flags: 0, or MTG_FLAG_FUSED_DIMS / MTG_FLAG_SPLIT_DIMS to fix the launch geometry of the merged groups (a caller
+ * that runs several mixed requests concurrently knows the total load; the default looks at this request only).    */
+int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* items, uint32_t flags, mtg_multi** out);
+int mtg_multi_solve(mtg_multi* multi);              /* asynchronous on the context's stream */
+int mtg_multi_launch_count(const mtg_multi* multi); /* kernel launches one mtg_multi_solve enqueues */
+int mtg_multi_destroy(mtg_multi* multi);
+
 /* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
 /* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the
  * context's stream, bracketed by hipEvents recorded on that same stream; returns the mean

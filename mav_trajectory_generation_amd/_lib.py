@@ -27,6 +27,12 @@ class Layout(ctypes.Structure):
         "free_stride_b", "free_stride_d", "free_stride_c")]
 
 
+class MultiItem(ctypes.Structure):
+    _fields_ = [("plan", ctypes.c_void_p), ("batch", ctypes.c_int64), ("layout", Layout), ("times", ctypes.c_void_p),
+                ("d_fixed", ctypes.c_void_p), ("coeffs", ctypes.c_void_p), ("d_free", ctypes.c_void_p),
+                ("cost", ctypes.c_void_p)]
+
+
 EXPORTS = {
     "mtg_context_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "mtg_context_destroy": (ctypes.c_int, [ctypes.c_void_p]),
@@ -57,6 +63,11 @@ EXPORTS = {
         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
         ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_double_p, c_double_p,
         ctypes.c_void_p]),
+    "mtg_multi_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(MultiItem), ctypes.c_uint32,
+                                        ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_multi_solve": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_multi_launch_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_multi_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mtg_time_last_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mtg_selftest_rcp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }

@@ -13,7 +13,7 @@ from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
-from .core import Context, Plan
+from .core import Context, MultiSolve, Plan
 
 
 class MixedBatchSolver:
@@ -90,6 +90,11 @@ class MixedBatchSolver:
             out = self.solve_device(buckets, want_cost, _capturing=True)
         return graph, out
 
+    def merged(self, buckets: List[dict], want_cost: bool = False) -> "MergedRequest":
+        """The same request with buckets that share N, D, the constraint pattern and the derivative merged into ONE
+        kernel launch each (mtg_multi_*): see MergedRequest."""
+        return MergedRequest(self, buckets, want_cost)
+
     def sync(self):
         for c in self.lanes:
             c.sync()
@@ -131,3 +136,74 @@ class MixedBatchSolver:
         for c in self.lanes[1:]:
             c.close()
         self.lanes = self.lanes[:1]
+
+
+class MergedRequest:
+    """A mixed request whose buckets of equal structure-up-to-K run as one launch (C ABI: mtg_multi_create / _solve):
+    BASELINE config 4 becomes 3 launches (N = 8, 10, 12) instead of 12, each on its own HIP stream, every tile of every
+    bucket in flight at once -- the request then takes about as long as its longest chain.  Created once for a set of
+    device tensors; `solve()` re-solves with whatever values those tensors hold; `capture()` wraps that in one hipGraph."""
+
+    def __init__(self, solver: MixedBatchSolver, buckets: List[dict], want_cost: bool = False):
+        self.solver = solver
+        groups: Dict[Tuple, List[int]] = {}
+        for i, b in enumerate(buckets):
+            masks = [int(m) for m in b["masks"]]
+            layout = b.get("layout", "aos")
+            dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
+            key = (int(b["n_coeffs"]), dim, int(b["derivative"]), masks[0], masks[-1], tuple(sorted(set(masks[1:-1]))))
+            groups.setdefault(key, []).append(i)
+        self.multis: List[MultiSolve] = []
+        self.out: List = [None] * len(buckets)
+        # launch geometry from the load of the WHOLE request (its groups run concurrently): one dimension per workgroup
+        # only while every workgroup of every group is resident at once (4 x CUs)
+        import torch
+        n_cu = torch.cuda.get_device_properties(solver.ctx.device).multi_processor_count
+        wgs = 0
+        for b in buckets:
+            layout = b.get("layout", "aos")
+            batch = b["times"].shape[0] if layout == "aos" else b["times"].shape[1]
+            dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
+            wgs += ((batch + 63) // 64) * dim
+        dims = "split" if wgs <= 4 * n_cu else "fused"
+        for lane, (key, idx) in enumerate(groups.items()):
+            items = []
+            for i in idx:
+                b = buckets[i]
+                plan = solver.plan_for(key[0], key[1], len(b["masks"]) - 1, key[2], b["masks"], lane)
+                items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=b.get("layout", "aos")))
+            ms = MultiSolve(solver._lane(lane), items, want_cost=want_cost, dims=dims)
+            self.multis.append(ms)
+            for i, it in zip(idx, ms.items):
+                self.out[i] = (it["coeffs"], it["cost"])
+        self.launch_count = sum(ms.launch_count for ms in self.multis)
+
+    def solve(self):
+        """Asynchronous; results ordered on torch's current stream.  Returns [(coeffs, cost)] in bucket order."""
+        import torch
+        cur = torch.cuda.current_stream(self.solver.ctx.device)
+        for ms in self.multis:
+            if ms.ctx.stream != cur:
+                ms.ctx.stream.wait_stream(cur)
+        for ms in self.multis:
+            ms.solve(ordered=False)
+        for ms in self.multis:
+            if ms.ctx.stream != cur:
+                cur.wait_stream(ms.ctx.stream)
+        return self.out
+
+    def capture(self):
+        """One hipGraph for the whole request (fork, the merged launches, join)."""
+        import torch
+        self.solve()
+        torch.cuda.synchronize(self.solver.ctx.device)
+        self.solver.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.solve()
+        return graph
+
+    def close(self):
+        for ms in self.multis:
+            ms.close()
+        self.multis = []

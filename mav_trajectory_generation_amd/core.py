@@ -294,6 +294,70 @@ class Plan:
             pass
 
 
+class MultiSolve:
+    """A mixed request (mtg_multi_*): several (plan, batch) items created once, solved as often as wanted with new
+    values in the same device tensors.  Items that share N, D, the constraint pattern and the derivative run as ONE
+    kernel launch.  items: dicts with plan, times, d_fixed (CUDA tensors), optional layout ('aos' | 'soa'), coeffs,
+    d_free, cost tensors (coeffs allocated here when missing; cost / d_free only when want_cost / want_free)."""
+
+    def __init__(self, ctx: Context, items: Sequence[dict], want_cost: bool = False, want_free: bool = False,
+                 dims: str = "auto"):
+        import torch
+        self.ctx, self.lib = ctx, ctx.lib
+        self.items = []
+        arr = (L.MultiItem * len(items))()
+        for i, it in enumerate(items):
+            plan: Plan = it["plan"]
+            assert plan.ctx is ctx
+            layout = it.get("layout", "aos")
+            t, f = it["times"], it["d_fixed"]
+            batch = t.shape[0] if layout == "aos" else t.shape[1]
+            co = it.get("coeffs")
+            if co is None:
+                co = torch.empty((batch, plan.K, plan.D, plan.N), dtype=torch.float64, device=t.device)
+            cost = it.get("cost")
+            if cost is None and want_cost:
+                cost = torch.empty((batch,), dtype=torch.float64, device=t.device)
+            fr = it.get("d_free")
+            if fr is None and want_free:
+                shape = (batch, plan.D, plan.n_free) if layout == "aos" else (plan.D, plan.n_free, batch)
+                fr = torch.empty(shape, dtype=torch.float64, device=t.device)
+            arr[i].plan = plan.handle
+            arr[i].batch = batch
+            arr[i].layout = plan.layout(batch, layout)
+            arr[i].times, arr[i].d_fixed, arr[i].coeffs = t.data_ptr(), f.data_ptr(), co.data_ptr()
+            arr[i].d_free = fr.data_ptr() if fr is not None else None
+            arr[i].cost = cost.data_ptr() if cost is not None else None
+            self.items.append(dict(plan=plan, times=t, d_fixed=f, coeffs=co, d_free=fr, cost=cost, layout=layout))
+        h = ctypes.c_void_p()
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS}[dims]
+        _check(self.lib, self.lib.mtg_multi_create(ctx.handle, len(items), arr, flags, ctypes.byref(h)), ctx.handle)
+        self.handle = h
+        self.launch_count = self.lib.mtg_multi_launch_count(h)
+        ctx._plans.add(self)   # closed with the context
+
+    def solve(self, ordered: bool = True):
+        """Enqueue the whole request (asynchronous).  Returns [(coeffs, d_free, cost)] in item order."""
+        cur = self.ctx._enter() if ordered else None
+        rc = self.lib.mtg_multi_solve(self.handle)
+        if ordered:
+            self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+        return [(it["coeffs"], it["d_free"], it["cost"]) for it in self.items]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            if getattr(self.ctx, "handle", None):
+                self.lib.mtg_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def solve_linear_batch(n_coeffs, derivative, fixed_mask, times: np.ndarray, d_fixed: np.ndarray, device: int = 0,
                        generic: bool = False):
     """One-shot host convenience: numpy AoS in -> (coeffs, d_free, cost) numpy out, via the HIP path."""

@@ -595,6 +595,176 @@ int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layou
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, const_cast<double*>(d_free), cost, flags, true);
 }
 
+// ---- mixed requests ---------------------------------------------------------------------------
+struct MtgMultiGroup {
+  const MtgStaticEntry* entry = nullptr;   // rolled configuration shared by the group's items
+  std::vector<int> items;
+  MtgParams* d_table = nullptr;
+  MtgTileRef* d_tiles = nullptr;
+  double* d_ws = nullptr;
+  int ntiles = 0, grid = 0, ngroups = 1;    // ngroups: dimension groups (grid.y) of the launch
+  size_t lds = 0;
+  bool extra = false;                       // any item wants d_free / cost
+};
+struct mtg_multi {
+  mtg_context* ctx = nullptr;
+  std::vector<mtg_multi_item> items;
+  std::vector<MtgMultiGroup> groups;
+  std::vector<int> singles;                 // items launched through the ordinary path
+};
+
+int mtg_multi_destroy(mtg_multi* m) {
+  if (!m) return MTG_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (MtgMultiGroup& g : m->groups) {
+    if (g.d_table) hipFree(g.d_table);
+    if (g.d_tiles) hipFree(g.d_tiles);
+    if (g.d_ws) hipFree(g.d_ws);
+  }
+  delete m;
+  return MTG_OK;
+}
+
+int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* items, uint32_t flags, mtg_multi** out) {
+  if (!ctx || !items || !out || n_items < 1) return MTG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  for (int i = 0; i < n_items; ++i) {
+    const mtg_multi_item& it = items[i];
+    if (!it.plan || it.plan->ctx != ctx || it.batch < 0 || !it.times || !it.coeffs || (it.plan->n_fixed > 0 && !it.d_fixed))
+      return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "mtg_multi_create: bad item");
+    if (reinterpret_cast<uintptr_t>(it.coeffs) & 15) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");
+  }
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  mtg_multi* m = new (std::nothrow) mtg_multi();
+  if (!m) return MTG_ERR_DEVICE;
+  m->ctx = ctx;
+  m->items.assign(items, items + n_items);
+  // group by rolled configuration
+  for (int i = 0; i < n_items; ++i) {
+    mtg_plan* p = items[i].plan;
+    const MtgStaticEntry* e = (items[i].batch > 0 && p->K >= 2)
+                                  ? mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true) : nullptr;
+    if (!e || !e->multi[0]) {
+      if (items[i].batch > 0) m->singles.push_back(i);
+      continue;
+    }
+    MtgMultiGroup* g = nullptr;
+    for (MtgMultiGroup& c : m->groups) if (c.entry == e) g = &c;
+    if (!g) {
+      m->groups.emplace_back();
+      g = &m->groups.back();
+      g->entry = e;
+    }
+    g->items.push_back(i);
+  }
+  // a group of one gains nothing from the merged form: leave it to the ordinary path (static variants, heuristics)
+  for (size_t gi = 0; gi < m->groups.size();) {
+    if (m->groups[gi].items.size() < 2) {
+      m->singles.push_back(m->groups[gi].items[0]);
+      m->groups.erase(m->groups.begin() + gi);
+    } else {
+      ++gi;
+    }
+  }
+  long long total_tiles = 0;
+  for (const MtgMultiGroup& g : m->groups)
+    for (int i : g.items) total_tiles += (items[i].batch + kWave - 1) / kWave;
+  for (MtgMultiGroup& g : m->groups) {
+    const MtgStaticEntry* e = g.entry;
+    const int H = e->h, D = e->d;
+    // tiles, longest chain first
+    std::vector<int> order(g.items.begin(), g.items.end());
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].plan->K > items[b].plan->K; });
+    std::vector<MtgTileRef> tiles;
+    std::vector<MtgParams> table(order.size());
+    int kc_max = 1;
+    for (size_t bi = 0; bi < order.size(); ++bi) {
+      const mtg_multi_item& it = items[order[bi]];
+      const int nt = (int)((it.batch + kWave - 1) / kWave);
+      for (int t = 0; t < nt; ++t) tiles.push_back(MtgTileRef{(int)bi, t});
+      kc_max = std::max(kc_max, (it.plan->K + 1) / 2);
+      g.extra = g.extra || it.cost != nullptr || (it.d_free != nullptr && it.plan->n_free > 0);
+    }
+    g.ntiles = (int)tiles.size();
+    // few tiles: the one-dimension-per-workgroup form of the same configuration (D x the workgroups, lighter waves, two
+    // per SIMD) while all of them are resident at once -- the same rule as for single-plan launches
+    int Dw = D;
+    {
+      const mtg_plan* p0 = items[order[0]].plan;
+      const MtgStaticEntry* es = D > 1 ? mtg_find_static(H, 1, p0->K, p0->deriv, p0->mask.data(), true) : nullptr;
+      // the split form only while the request's workgroups are all resident at once (flags override)
+      const bool want = (flags & MTG_FLAG_SPLIT_DIMS) ||
+                        (!(flags & MTG_FLAG_FUSED_DIMS) && total_tiles * D <= 4ll * ctx->n_cu);
+      if (es && es->multi[0] && want) {
+        g.entry = es;
+        g.ngroups = D;
+        Dw = 1;
+      }
+    }
+    g.grid = std::min(g.ntiles, std::max(1, ctx->n_cu * 4 / g.ngroups));
+    const size_t E = (size_t)H * H + (size_t)Dw * H;
+    const size_t ws_bytes = (size_t)kc_max * E * (size_t)g.grid * g.ngroups * kBlock * sizeof(double);
+    const int fm = H - __builtin_popcount((unsigned)e->mi);
+    const size_t stage = (size_t)64 * ((size_t)(Dw * 2 * H / 2) | 1) * 2 * sizeof(double);
+    g.lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + Dw * fm) * kWave * sizeof(double);
+    if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
+        hipMalloc((void**)&g.d_table, table.size() * sizeof(MtgParams)) != hipSuccess ||
+        hipMalloc((void**)&g.d_tiles, tiles.size() * sizeof(MtgTileRef)) != hipSuccess) {
+      mtg_multi_destroy(m);
+      return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: device allocation failed");
+    }
+    for (size_t bi = 0; bi < order.size(); ++bi) {
+      const mtg_multi_item& it = items[order[bi]];
+      MtgParams& P = table[bi];
+      fill_common(it.plan, P, it.batch, &it.layout);
+      P.times = it.times; P.dfix = it.d_fixed; P.coeffs = it.coeffs;
+      P.dfree = it.plan->n_free ? it.d_free : nullptr;
+      P.cost = it.cost;
+      P.ws = g.d_ws;
+      P.ws_stride = (long long)g.grid * g.ngroups * kBlock;
+    }
+    if (hipMemcpy(g.d_table, table.data(), table.size() * sizeof(MtgParams), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g.d_tiles, tiles.data(), tiles.size() * sizeof(MtgTileRef), hipMemcpyHostToDevice) != hipSuccess) {
+      mtg_multi_destroy(m);
+      return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: table upload failed");
+    }
+  }
+  *out = m;
+  return MTG_OK;
+}
+
+int mtg_multi_launch_count(const mtg_multi* m) { return m ? (int)(m->groups.size() + m->singles.size()) : 0; }
+
+int mtg_multi_solve(mtg_multi* m) {
+  if (!m) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = m->ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->dirty = true;
+    for (const MtgMultiGroup& g : m->groups) {
+      for (int i : g.items) {
+        const mtg_multi_item& it = m->items[i];
+        if (it.cost) MTG_HIP_TRY(ctx, hipMemsetAsync(it.cost, 0, it.batch * sizeof(double), ctx->stream));
+      }
+      // few tiles: write-through stores (no serial end-of-kernel L2 write-back), as for single-plan launches
+      const bool write_through = (long long)g.ntiles * g.ngroups <= 4ll * ctx->n_cu;
+      SolveMultiFn fn = g.entry->multi[(g.extra ? 1 : 0) + (write_through ? 2 : 0)];
+      hipLaunchKernelGGL(fn, dim3(g.grid, g.ngroups), dim3(kBlock), g.lds, ctx->stream, (const MtgParams*)g.d_table,
+                         (const MtgTileRef*)g.d_tiles, g.ntiles);
+    }
+    MTG_HIP_TRY(ctx, hipGetLastError());
+  }
+  for (int i : m->singles) {
+    const mtg_multi_item& it = m->items[i];
+    const int rc = solve_impl(it.plan, it.batch, &it.layout, it.times, it.d_fixed, it.coeffs, it.d_free, it.cost, 0, false);
+    if (rc != MTG_OK) return rc;
+  }
+  return MTG_OK;
+}
+
 int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   if (!p || !mean_us || iters < 1) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = p->ctx;

@@ -199,6 +199,49 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   }
 }
 
+// Several plans in ONE launch (BASELINE config 4: a mixed request whose buckets share N, D, masks and derivative but not
+// K).  Rolled configurations only: K is a run-time field of MtgParams, so tiles of different buckets run the same code.
+// `table[bucket]` holds the bucket's parameters (pointers, strides, B, K; all buckets share one workspace sized for the
+// longest chain), `tiles[t]` names the bucket and the tile inside it; the host sorts tiles longest-chain-first so that
+// the short ones fill in behind the long ones.  One launch instead of one per bucket: a 2500-trajectory bucket is 40
+// tiles, far too few to fill 256 CUs, and back-to-back launches each pay their own latency chain.
+struct MtgTileRef { int bucket, tile; };
+
+template <class C, int OUT>
+__global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_multi_kernel(const MtgParams* __restrict__ table,
+                                                                                         const MtgTileRef* __restrict__ tiles,
+                                                                                         int ntiles) {
+  static_assert(C::kRolled, "multi-plan launches use the rolled (run-time K) configurations");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int dir = threadIdx.x >> 6;  // wave-uniform
+  constexpr int kFreeMid = C::H - C::popc(C::MI);                     // the middle vertex is an interior one
+  constexpr int nslots = kFreeMid * (kFreeMid + 1) / 2 + C::D * kFreeMid;
+  double* xch = lds + 2 * mtg_stage_doubles<C>();
+  double* mine = xch + (size_t)dir * nslots * kWave + lane;
+  const double* other = xch + (size_t)(1 - dir) * nslots * kWave + lane;
+  MtgLane<C> ln;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const MtgTileRef ref = tiles[t];
+    MtgParams P = table[ref.bucket];
+    P.dim0 += (int)blockIdx.y * C::D;   // grid.y = dimension groups, as in mtg_solve_kernel
+    double* wsl = P.ws + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x);
+    MtgLdsOut<C, (OUT & 4) != 0> io;
+    io.init(P, lds + (size_t)dir * mtg_stage_doubles<C>(), lane);
+    io.b0 = (long long)ref.tile * kWave;
+    const long long bl = io.b0 + lane;
+    const bool active = bl < P.B;
+    const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
+    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, true);
+    else mtg_lane_forward<C, -1>(P, b, ln, wsl, true);
+    mtg_pack_mid<C>(ln, C::MI, mine, kWave);
+    __syncthreads();
+    if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+    else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+    __syncthreads();
+  }
+}
+
 // setFreeConstraints path: one wave = 64 trajectories, one lane per trajectory, recovery only; coefficients leave
 // through the same LDS-staged coalesced drain as the solve kernel.  Dynamic LDS = mtg_stage_doubles<C>() doubles.
 template <class C, int OUT>
@@ -219,6 +262,7 @@ __global__ __launch_bounds__(kWave) void mtg_update_kernel(MtgParams P, int ntil
 
 using SolveFn = void (*)(MtgParams, int);
 using UpdateFn = void (*)(MtgParams, int);
+using SolveMultiFn = void (*)(const MtgParams*, const MtgTileRef*, int);
 template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
 
 // per-TU pickers (mtg_generic_hN.hip, mtg_static.hip)
@@ -229,6 +273,7 @@ struct MtgStaticEntry {
   int heavy;       // static variant that spills: prefer a rolled variant for large launches
   SolveFn fn[5];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]; [4] = cost only (OUT 9)
   void (*upd[2])(MtgParams, int);   // rolled entries: setFreeConstraints kernel [with cost]; static entries: null
+  SolveMultiFn multi[4];            // rolled entries: several plans in one launch, [extra outputs] + 2 * [write-through]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
 

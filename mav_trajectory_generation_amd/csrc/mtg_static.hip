@@ -10,7 +10,8 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 4>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 9>},         \
-   {nullptr, nullptr}},
+   {nullptr, nullptr},                                                      \
+   {nullptr, nullptr, nullptr, nullptr}},
 #define MTG_ROLLED(H, D, MS, MI, ME, DV)                                    \
   {H, D, -1, MS, MI, ME, DV, 0,                                             \
    {(SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,         \
@@ -19,7 +20,11 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 7>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 9>},        \
    {(UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,       \
-    (UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1>}},
+    (UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1>},      \
+   {(SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>, \
+    (SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>, \
+    (SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 4>, \
+    (SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 7>}},
 static const MtgStaticEntry kStaticTable[] = {
 #include "mtg_variants.inc"
 };

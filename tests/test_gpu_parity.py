@@ -336,6 +336,69 @@ def test_mixed_batch_streams_and_graph_replay(ctx):
     one.close()
 
 
+def test_merged_mixed_request(ctx):
+    """mtg_multi_*: buckets that share N, D, masks pattern and derivative run as ONE launch (config 4: 3 launches instead
+    of 12).  Results must equal the per-bucket launches bit for bit -- eager, replayed from a hipGraph, with cost and d_P
+    outputs, with an un-mergeable item (ragged masks -> ordinary path) and a single-item group in the same request."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    buckets = []
+    for (n, d) in ((8, 3), (10, 4), (12, 5)):
+        for k in (4, 8, 16, 32):
+            masks, times, d_fixed = helpers.reference_batch(70, k, n, 3, 9100 + n * 100 + k)
+            buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=torch.from_numpy(times).cuda(),
+                                d_fixed=torch.from_numpy(d_fixed).cuda()))
+    # not mergeable: ragged per-vertex masks; and a group of one (N = 6)
+    for (n, d, k, masks) in ((10, 4, 6, [31, 1, 3, 1, 5, 9, 31]), (6, 2, 5, None)):
+        masks, times, d_fixed = helpers.reference_batch(33, k, n, 3, 777, masks)
+        buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=torch.from_numpy(times).cuda(),
+                            d_fixed=torch.from_numpy(d_fixed).cuda()))
+    one = m.MixedBatchSolver(ctx, n_streams=1)
+    ref = [(c.clone(), j.clone()) for c, j in one.solve_device(buckets, want_cost=True)]
+    torch.cuda.synchronize()
+    one.sync()
+    solver = m.MixedBatchSolver(ctx, n_streams=3)
+    req = solver.merged(buckets, want_cost=True)
+    assert req.launch_count == 3 + 2            # three merged groups + the two ordinary launches
+    got = req.solve()
+    torch.cuda.synchronize()
+    solver.sync()
+    for (c, j), (c0, j0) in zip(got, ref):
+        assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
+    graph = req.capture()
+    for c, j in req.out:
+        c.zero_()
+    for b in buckets:
+        b["times"].mul_(1.1)
+    graph.replay()
+    fresh = one.solve_device(buckets, want_cost=True)
+    torch.cuda.synchronize()
+    for (c, j), (c1, j1) in zip(req.out, fresh):
+        assert torch.equal(c, c1) and torch.allclose(j, j1, rtol=1e-12)
+    del graph
+    req.close()
+    # d_P output through the C-ABI wrapper directly, SoA layout, two items of one structure
+    plan_a = m.Plan(ctx, 10, 3, 16, 4, m.ends_full_masks(10, 16))
+    plan_b = m.Plan(ctx, 10, 3, 5, 4, m.ends_full_masks(10, 5))
+    items = []
+    for plan, k in ((plan_a, 16), (plan_b, 5)):
+        t, f = m.random_waypoint_batch(100, k, 3, 10, plan.fixed_mask, seed=3 + k, device="cuda", layout="soa")
+        items.append(dict(plan=plan, times=t, d_fixed=f, layout="soa"))
+    ms = m.MultiSolve(ctx, items, want_cost=True, want_free=True)
+    assert ms.launch_count == 1
+    res = ms.solve()
+    ctx.sync()
+    for it, (co, fr, cost) in zip(items, res):
+        co1, fr1, cost1 = it["plan"].solve(it["times"], it["d_fixed"], layout="soa", want_free=True, want_cost=True)
+        ctx.sync()
+        assert torch.equal(co, co1) and torch.equal(fr, fr1) and torch.allclose(cost, cost1, rtol=1e-12)
+    ms.close()
+    plan_a.close()
+    plan_b.close()
+    solver.close()
+    one.close()
+
+
 def test_config5_full_size_properties(ctx):
     """BASELINE config 5 shape at its per-GPU share (100k / 8): K = 16, D = 4 (x, y, z, yaw), interior vertices fix
     position, velocity and acceleration.  checkPath over the whole batch + oracle parity on a subset, for both the

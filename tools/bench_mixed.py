@@ -7,6 +7,9 @@ import torch
 import mav_trajectory_generation_amd as m
 
 per_bucket = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
+# modes run in separate processes (python tools/bench_mixed.py 2500 merged): streams created by one section stay alive
+# in torch's pool and share the hardware queues with the next section's, which hides the overlap being measured
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["streams", "graph", "merged"]
 ctx = m.Context(0)
 buckets, algo_bytes = [], 0
 for (N, d) in ((8, 3), (10, 4), (12, 5)):
@@ -16,7 +19,7 @@ for (N, d) in ((8, 3), (10, 4), (12, 5)):
         buckets.append(dict(n_coeffs=N, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
         algo_bytes += per_bucket * 8 * (K + 3 * (N + K - 1) + K * 3 * N)
 total = per_bucket * len(buckets)
-for n_streams in (1, 2, 4, 8):
+for n_streams in ((1, 2, 4, 8) if "streams" in modes else ()):
     solver = m.MixedBatchSolver(ctx, n_streams=n_streams)
     for _ in range(5):
         solver.solve_device(buckets)
@@ -35,7 +38,7 @@ for n_streams in (1, 2, 4, 8):
     solver.close()
 
 # the same request captured once into a hipGraph (fork over 4 streams + join) and replayed: one host call per mixed batch
-for n_streams in (1, 4, 8, 12):
+for n_streams in ((1, 4, 8) if "graph" in modes else ()):
     solver = m.MixedBatchSolver(ctx, n_streams=n_streams)
     graph, out = solver.capture(buckets)
     for _ in range(5):
@@ -59,3 +62,34 @@ for n_streams in (1, 4, 8, 12):
                           replay_equals_eager=bool(same))))
     del graph
     solver.close()
+
+# buckets of equal structure-up-to-K merged into one launch each (mtg_multi_*): 3 launches on 3 streams, eager and as a graph
+if "merged" not in modes:
+    sys.exit(0)
+solver = m.MixedBatchSolver(ctx, n_streams=3)
+req = solver.merged(buckets)
+for mode in ("eager", "graph"):
+    graph = req.capture() if mode == "graph" else None
+    run = (lambda: graph.replay()) if graph is not None else (lambda: req.solve())
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    solver.sync()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    one = m.MixedBatchSolver(ctx, n_streams=1)
+    eager = one.solve_device(buckets)
+    torch.cuda.synchronize()
+    same = all(torch.equal(a[0], b[0]) for a, b in zip(req.out, eager))
+    one.close()
+    print(json.dumps(dict(config="config4-mixed-merged-" + mode, per_bucket=per_bucket, launches=req.launch_count,
+                          us_per_mixed_batch=round(us, 1), traj_per_s=total / us * 1e6, GBps=algo_bytes / us * 1e-3,
+                          frac_8TBps=algo_bytes / us * 1e-3 / 8000.0, equals_per_bucket_launches=bool(same))))
+req.close()
+solver.close()
