@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, lo
 }
 
 // Compile-time (ND, N, D) kernel for the common shapes with an ODD number of results per sample (R = ND*D: position..
-// snap in 3-D is 15) and K <= 8 segments.  What the measurements on the run-time-shape kernel showed (100k x 1000
+// snap in 3-D is 15) and K <= 8 / K <= 16 segments (KMAX).  What the measurements on the run-time-shape kernel showed (100k x 1000
 // samples, 12 GB out: 3.8 ms; same kernel with its stores removed 2.4 ms, with stores AND arithmetic AND coefficient
 // loads removed still 1.6 ms; a bare store stream of the same shape 2.15 ms, tools/micro/write_pattern.hip):
 //   * index arithmetic, register shuffles of the d-loop and the owner/remainder bookkeeping of the write-out were 40 %
@@ -194,11 +194,10 @@ __global__ __launch_bounds__(kThreads) void mtg_sample_kernel(SampleParams P, lo
 //     waits for "all but the 8 youngest" (the stores), never for a store.
 // Only full 64-sample chunks run through the pipeline; the (at most one) partial chunk of a launch takes the plain
 // path at the end.
-template <int ND, int N, int D>
-__global__ __launch_bounds__(kThreads, MTG_SAMPLE_CT_WAVES) void mtg_sample_kernel_ct(SampleParams P, long long total) {
+template <int ND, int N, int D, int KMAX>   // KMAX: segment times held in registers (K <= KMAX)
+__global__ __launch_bounds__(kThreads, KMAX <= 8 ? MTG_SAMPLE_CT_WAVES : 3) void mtg_sample_kernel_ct(SampleParams P, long long total) {
   constexpr int R = ND * D;
   constexpr int RS = R | 1;        // LDS row stride: odd => the transposing ds_write_b64 are conflict-free
-  constexpr int KMAX = 8;
   typedef double d2 __attribute__((ext_vector_type(2)));
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63;
@@ -341,16 +340,20 @@ __global__ __launch_bounds__(kThreads, MTG_SAMPLE_CT_WAVES) void mtg_sample_kern
 }
 
 using SampleFn = void (*)(SampleParams, long long);
-template <int N, int D>
+template <int N, int D, int KMAX>
 SampleFn mtg_pick_sample_ct(int nd) {
   switch (nd) {
-    case 1: return mtg_sample_kernel_ct<1, N, D>;
-    case 2: return mtg_sample_kernel_ct<2, N, D>;
-    case 3: return mtg_sample_kernel_ct<3, N, D>;
-    case 4: return mtg_sample_kernel_ct<4, N, D>;
-    case 5: return mtg_sample_kernel_ct<5, N, D>;
+    case 1: return mtg_sample_kernel_ct<1, N, D, KMAX>;
+    case 2: return mtg_sample_kernel_ct<2, N, D, KMAX>;
+    case 3: return mtg_sample_kernel_ct<3, N, D, KMAX>;
+    case 4: return mtg_sample_kernel_ct<4, N, D, KMAX>;
+    case 5: return mtg_sample_kernel_ct<5, N, D, KMAX>;
     default: return nullptr;
   }
+}
+template <int N, int D>
+SampleFn mtg_pick_sample_ct(int nd, int k) {
+  return k <= 8 ? mtg_pick_sample_ct<N, D, 8>(nd) : mtg_pick_sample_ct<N, D, 16>(nd);
 }
 
 __global__ void mtg_sample_valid_kernel(SampleParams P) {
@@ -407,15 +410,15 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
     case 5: fn = mtg_sample_kernel<5>; break;
     default: return MTG_ERR_UNSUPPORTED;   // position .. snap (sampleTrajectoryInRange samples exactly these five)
   }
-  // compile-time shapes (K <= 8): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D (yaw) and 4-D (x, y, z, yaw)
+  // compile-time shapes (K <= 16): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D (yaw) and 4-D (x, y, z, yaw)
   SampleFn fast = nullptr;
-  if (n_segments <= 8 && total >= 64 && !getenv("MTG_SAMPLE_GENERIC")) {
-    if (n_coeffs == 10 && dimension == 3) fast = mtg_pick_sample_ct<10, 3>(n_derivatives);
-    else if (n_coeffs == 12 && dimension == 3) fast = mtg_pick_sample_ct<12, 3>(n_derivatives);
-    else if (n_coeffs == 8 && dimension == 3) fast = mtg_pick_sample_ct<8, 3>(n_derivatives);
-    else if (n_coeffs == 10 && dimension == 1) fast = mtg_pick_sample_ct<10, 1>(n_derivatives);
-    else if (n_coeffs == 10 && dimension == 4) fast = mtg_pick_sample_ct<10, 4>(n_derivatives);
-    else if (n_coeffs == 12 && dimension == 4) fast = mtg_pick_sample_ct<12, 4>(n_derivatives);
+  if (n_segments <= 16 && total >= 64 && !getenv("MTG_SAMPLE_GENERIC")) {
+    if (n_coeffs == 10 && dimension == 3) fast = mtg_pick_sample_ct<10, 3>(n_derivatives, n_segments);
+    else if (n_coeffs == 12 && dimension == 3) fast = mtg_pick_sample_ct<12, 3>(n_derivatives, n_segments);
+    else if (n_coeffs == 8 && dimension == 3) fast = mtg_pick_sample_ct<8, 3>(n_derivatives, n_segments);
+    else if (n_coeffs == 10 && dimension == 1) fast = mtg_pick_sample_ct<10, 1>(n_derivatives, n_segments);
+    else if (n_coeffs == 10 && dimension == 4) fast = mtg_pick_sample_ct<10, 4>(n_derivatives, n_segments);
+    else if (n_coeffs == 12 && dimension == 4) fast = mtg_pick_sample_ct<12, 4>(n_derivatives, n_segments);
   }
   // persistent waves: as many workgroups as the device holds at once (occupancy x CUs), several chunks each
   SampleFn launch_fn = fast ? fast : fn;

@@ -482,7 +482,8 @@ def test_batched_sampling_vs_oracle(ctx):
                                        (10, 4, 8, 3, 700, 128, 5), (10, 4, 8, 3, 3, 17, 5), (10, 4, 2, 3, 64, 9, 3),
                                        (12, 5, 4, 3, 50, 77, 1), (8, 3, 8, 3, 41, 100, 5), (10, 4, 6, 1, 33, 65, 5),
                                        (10, 4, 16, 3, 21, 90, 5), (10, 4, 8, 3, 20, 50, 2), (6, 2, 4, 3, 11, 70, 3),
-                                       (10, 4, 8, 4, 30, 70, 5), (10, 4, 5, 4, 19, 33, 4), (12, 5, 8, 4, 12, 129, 3)]:
+                                       (10, 4, 8, 4, 30, 70, 5), (10, 4, 5, 4, 19, 33, 4), (12, 5, 8, 4, 12, 129, 3),
+                                       (10, 4, 16, 4, 25, 80, 5), (10, 4, 12, 3, 40, 64, 5), (8, 3, 9, 3, 17, 100, 3)]:
         masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 515 + n)
         plan = m.Plan(ctx, n, dim, k, d, masks)
         t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
