@@ -90,5 +90,5 @@ def timed_baseline(n, deriv, masks, times, d_fixed, target_seconds=12.0):
     return {"value": bsz * repeat / s_all, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "single_thread_value": probe / s_one,
             "sample": f"{repeat} x {bsz} trajectories of the bench workload (setupFromVertices + solveLinear per "
-                      f"trajectory), C++17 -O3 -march=native restatement of the reference algorithm (Eigen unavailable "
+                      f"trajectory), C++17 -O3 -march=x86-64-v3 restatement of the reference algorithm (real Eigen unavailable "
                       f"offline), std::thread over {cores} host threads, {s_all:.1f} s"}
