@@ -157,7 +157,13 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
 #if defined(MTG_TIMING)
   long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + dir) * 16;
   const bool tdo = C::kStatic && P.ws != nullptr;
-  if (tdo && lane == 0) tdbg[0] = clock64();
+  if (tdo && lane == 0) {   // [14]/[15]: device-wide 100 MHz clock; [13]: where the wave runs (HW_ID | XCC_ID << 32)
+    tdbg[0] = clock64();
+    tdbg[14] = wall_clock64();
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    tdbg[13] = (long long)hw | ((long long)xcc << 32);
+  }
 #endif
   // Software prefetch (register-rich static variants): the inputs of this workgroup's NEXT tile are requested
   // before the current tile is solved and land while it computes (measured: the exposed input latency was
@@ -186,6 +192,9 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     MTG_TSTAMP(4);
+#if defined(MTG_TIMING)
+    if (tdo && lane == 0 && tile == (int)blockIdx.x) tdbg[15] = wall_clock64();
+#endif
     if (has_next) {
 #pragma unroll
       for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];

@@ -35,3 +35,32 @@ for i, n in enumerate(names):
 d = lambda a, b: int(np.median(T[:, a] - T[:, b]))
 print("  medians: preload %d | forward %d | barrier %d | mid %d | bwd3 %d | bwd2 %d | bwd1 %d | bwd0 %d | tail %d | store drain %d"
       % (d(5, 0), d(1, 5), d(2, 1), d(6, 2), d(10, 6), d(9, 10), d(8, 9), d(7, 8), d(3, 7), d(4, 3)))
+
+# device-wide 100 MHz clock (comparable across XCDs, 10 ns resolution): dispatch skew and in-kernel span
+w0, w1 = T[:, 14], T[:, 15]
+ok = (w0 > 0) & (w1 > 0)
+if ok.any():
+    base = w0[ok].min()
+    s0 = (w0[ok] - base) * 0.01
+    s1 = (w1[ok] - base) * 0.01
+    print("  wave start  [us after the first wave]: median %.2f  p90 %.2f  max %.2f" % (np.median(s0), np.percentile(s0, 90), s0.max()))
+    print("  wave end    [us after the first wave]: median %.2f  p90 %.2f  max %.2f" % (np.median(s1), np.percentile(s1, 90), s1.max()))
+    print("  wave lifetime [us]: median %.2f  max %.2f" % (np.median(s1 - s0), (s1 - s0).max()))
+
+    # placement: HW_ID bits  simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID bits [3:0]
+    hw = T[ok, 13] & 0xffffffff
+    xcc = (T[ok, 13] >> 32) & 0xf
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+    key_cu = xcc * 10000 + se * 1000 + sh * 100 + cu
+    key_simd = key_cu * 10 + simd
+    import collections
+    per_simd = collections.Counter(key_simd.tolist())
+    per_cu = collections.Counter(key_cu.tolist())
+    print("  CUs used %d, SIMDs used %d; waves per SIMD histogram %s; waves per CU histogram %s" % (
+        len(per_cu), len(per_simd), dict(collections.Counter(per_simd.values())), dict(sorted(collections.Counter(per_cu.values()).items()))))
+    life = s1 - s0
+    share = np.array([per_simd[k] for k in key_simd.tolist()])
+    for c in sorted(set(share.tolist())):
+        print("  lifetime of waves with %d wave(s) on their SIMD: median %.2f max %.2f (n=%d)" % (c, np.median(life[share == c]), life[share == c].max(), (share == c).sum()))
+    late = s0 > np.percentile(s0, 75)
+    print("  lifetime of the last-started quarter: median %.2f; of the first-started quarter: median %.2f" % (np.median(life[late]), np.median(life[s0 <= np.percentile(s0, 25)])))
