@@ -67,3 +67,17 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "C ABI ok" in r.stdout
+
+
+def test_multi_entry_points_validate_arguments_without_a_device():
+    """mtg_multi_* (mixed requests): null / empty arguments are rejected before any device work."""
+    import ctypes
+    from mav_trajectory_generation_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    items = (_lib.MultiItem * 1)()
+    assert lib.mtg_multi_create(None, 1, items, 0, ctypes.byref(h)) == -1
+    assert lib.mtg_multi_solve(None) == -1
+    assert lib.mtg_multi_launch_count(None) == 0
+    assert lib.mtg_multi_destroy(None) == 0
+    assert ctypes.sizeof(_lib.MultiItem) == 8 + 8 + 8 * 8 + 5 * 8     # plan, batch, layout (8 strides), 5 pointers
