@@ -463,5 +463,113 @@ class PolynomialOptimizationBatch {
   mtg_plan_info info_;
 };
 
+// New API: a heterogeneous list of problems (same N and dimension; any number of segments / constraint structure per
+// problem) solved as one mixed request -- what a caller of the reference does with a loop over independent
+// PolynomialOptimization<N> objects.  Problems are bucketed by structure, uploaded once, and solved through
+// mtg_multi_create / mtg_multi_solve: buckets that differ only in their number of segments share ONE kernel launch.
+// segments->at(i) receives problem i's solution (Segment::Vector as from PolynomialOptimization<N>::getSegments).
+template <int _N>
+bool solveLinearMixed(size_t dimension, const std::vector<Vertex::Vector>& problems,
+                      const std::vector<std::vector<double>>& segment_times, int derivative_to_optimize,
+                      std::vector<Segment::Vector>* segments, std::vector<double>* costs = nullptr) {
+  CHECK_NOTNULL(segments);
+  CHECK(problems.size() == segment_times.size());
+  constexpr int N = _N;
+  mtg_context* ctx = mtg_compat_detail::context();
+  struct Bucket {
+    std::vector<uint32_t> mask;
+    std::vector<size_t> members;
+    std::shared_ptr<mtg_plan> plan;
+    mtg_plan_info info;
+    std::vector<double> t, f, c, j;
+    double *dt = nullptr, *df = nullptr, *dc = nullptr, *dj = nullptr;
+  };
+  std::vector<Bucket> buckets;
+  std::map<std::vector<uint32_t>, size_t> index;
+  for (size_t i = 0; i < problems.size(); ++i) {
+    CHECK(problems[i].size() == segment_times[i].size() + 1) << "Size of times must be one less than positions.";
+    std::vector<uint32_t> mask = PolynomialOptimizationBatch<N>::masksFromVertices(problems[i]);
+    auto it = index.find(mask);
+    if (it == index.end()) {
+      it = index.emplace(mask, buckets.size()).first;
+      buckets.emplace_back();
+      buckets.back().mask = mask;
+    }
+    buckets[it->second].members.push_back(i);
+  }
+  auto check = [&](int rc) { CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(ctx); };
+  std::vector<mtg_multi_item> items(buckets.size());
+  for (size_t bi = 0; bi < buckets.size(); ++bi) {
+    Bucket& bk = buckets[bi];
+    const size_t K = bk.mask.size() - 1, B = bk.members.size();
+    bk.plan = mtg_compat_detail::make_plan(N, (int)dimension, (int)K, derivative_to_optimize, bk.mask);
+    mtg_plan_get_info(bk.plan.get(), &bk.info);
+    const size_t nf = bk.info.n_fixed;
+    bk.t.resize(B * K);
+    bk.f.assign(B * dimension * nf, 0.0);
+    for (size_t m = 0; m < B; ++m) {
+      const size_t i = bk.members[m];
+      for (size_t k = 0; k < K; ++k) bk.t[m * K + k] = segment_times[i][k];
+      size_t col = 0;
+      for (size_t v = 0; v <= K; ++v)
+        for (int p = 0; p < N / 2; ++p) {
+          Eigen::VectorXd value;
+          if (!problems[i][v].getConstraint(p, &value)) continue;
+          for (size_t d = 0; d < dimension; ++d) bk.f[(m * dimension + d) * nf + col] = value[d];
+          ++col;
+        }
+    }
+    bk.c.resize(B * K * dimension * N);
+    bk.j.resize(B);
+    check(mtg_device_malloc(ctx, bk.t.size() * sizeof(double), (void**)&bk.dt));
+    check(mtg_device_malloc(ctx, std::max<size_t>(1, bk.f.size()) * sizeof(double), (void**)&bk.df));
+    check(mtg_device_malloc(ctx, bk.c.size() * sizeof(double), (void**)&bk.dc));
+    check(mtg_device_malloc(ctx, bk.j.size() * sizeof(double), (void**)&bk.dj));
+    check(mtg_copy_to_device(ctx, bk.dt, bk.t.data(), bk.t.size() * sizeof(double)));
+    if (!bk.f.empty()) check(mtg_copy_to_device(ctx, bk.df, bk.f.data(), bk.f.size() * sizeof(double)));
+    mtg_multi_item& it = items[bi];
+    it.plan = bk.plan.get();
+    it.batch = (int64_t)B;
+    mtg_layout_aos(bk.plan.get(), (int64_t)B, &it.layout);
+    it.times = bk.dt;
+    it.d_fixed = bk.df;
+    it.coeffs = bk.dc;
+    it.d_free = nullptr;
+    it.cost = costs ? bk.dj : nullptr;
+  }
+  mtg_multi* multi = nullptr;
+  check(mtg_multi_create(ctx, (int32_t)items.size(), items.data(), 0, &multi));
+  check(mtg_multi_solve(multi));
+  mtg_compat_detail::check_sync();
+  segments->assign(problems.size(), Segment::Vector());
+  if (costs) costs->assign(problems.size(), 0.0);
+  for (Bucket& bk : buckets) {
+    const size_t K = bk.mask.size() - 1, B = bk.members.size();
+    check(mtg_copy_to_host(ctx, bk.c.data(), bk.dc, bk.c.size() * sizeof(double)));
+    if (costs) check(mtg_copy_to_host(ctx, bk.j.data(), bk.dj, bk.j.size() * sizeof(double)));
+    for (size_t m = 0; m < B; ++m) {
+      Segment::Vector& out = (*segments)[bk.members[m]];
+      out.assign(K, Segment(N, (int)dimension));
+      for (size_t k = 0; k < K; ++k) {
+        out[k].setTime(bk.t[m * K + k]);
+        for (size_t d = 0; d < dimension; ++d) {
+          Eigen::VectorXd c(N);
+          for (int n = 0; n < N; ++n) c[n] = bk.c[((m * K + k) * dimension + d) * N + n];
+          out[k][d] = Polynomial(N, c);
+        }
+      }
+      if (costs) (*costs)[bk.members[m]] = bk.j[m];
+    }
+  }
+  mtg_multi_destroy(multi);
+  for (Bucket& bk : buckets) {
+    mtg_device_free(ctx, bk.dt);
+    mtg_device_free(ctx, bk.df);
+    mtg_device_free(ctx, bk.dc);
+    mtg_device_free(ctx, bk.dj);
+  }
+  return true;
+}
+
 }  // namespace mav_trajectory_generation
 #endif

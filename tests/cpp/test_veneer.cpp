@@ -306,6 +306,42 @@ int main() {
     }
     EXPECT(n_scaled > 0, "the case exercises the scaling branch");
   }
+  {  // mixed request: problems of different length / structure in one call vs one optimiser object each
+    std::vector<Vertex::Vector> problems;
+    std::vector<std::vector<double>> times;
+    const int Ks[6] = {2, 5, 8, 16, 8, 16};
+    for (int i = 0; i < 36; ++i) {
+      Vertex::Vector v = createRandomVertices(derivative_order::SNAP, Ks[i % 6], Eigen::VectorXd::Constant(3, -10.0),
+                                              Eigen::VectorXd::Constant(3, 10.0), 500 + i);
+      if (i % 5 == 0) {   // another structure
+        Eigen::VectorXd vel(3);
+        vel[0] = 0.3; vel[1] = -0.2; vel[2] = 0.1;
+        v[1].addConstraint(derivative_order::VELOCITY, vel);
+      }
+      problems.push_back(v);
+      times.push_back(estimateSegmentTimes(v, 3.0, 5.0));
+    }
+    std::vector<Segment::Vector> mixed;
+    std::vector<double> mixed_costs;
+    EXPECT(solveLinearMixed<10>(3, problems, times, derivative_order::SNAP, &mixed, &mixed_costs), "solveLinearMixed");
+    for (size_t i = 0; i < problems.size(); ++i) {
+      PolynomialOptimization<10> opt(3);
+      opt.setupFromVertices(problems[i], times[i], derivative_order::SNAP);
+      opt.solveLinear();
+      Segment::Vector ref;
+      opt.getSegments(&ref);
+      EXPECT(ref.size() == mixed[i].size(), "problem %zu segment count", i);
+      double worst = 0.0, scale = 0.0;
+      for (size_t k = 0; k < ref.size(); ++k)
+        for (int d = 0; d < 3; ++d) {
+          const Eigen::VectorXd a = ref[k][d].getCoefficients(), b = mixed[i][k][d].getCoefficients();
+          for (int n = 0; n < 10; ++n) { worst = std::max(worst, std::abs(a[n] - b[n])); scale = std::max(scale, std::abs(a[n])); }
+        }
+      EXPECT(worst <= 1e-9 * scale, "problem %zu mixed vs single: %.3e of %.3e", i, worst, scale);
+      EXPECT(std::abs(mixed_costs[i] - opt.computeCost()) <= 1e-8 * std::abs(opt.computeCost()), "problem %zu cost", i);
+      EXPECT(checkPath(problems[i], mixed[i], 10) < 1e-6, "problem %zu checkPath", i);
+    }
+  }
   std::printf(g_fail ? "VENEER TESTS FAILED: %d\n" : "VENEER TESTS PASSED%.0d\n", g_fail);
   return g_fail ? 1 : 0;
 }
