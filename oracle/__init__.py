@@ -1,0 +1,27 @@
+
+
+def effective_cpus() -> int:
+    """Host CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a container
+    can see 256 hardware threads and be allowed 16 of them) -- the `cores` of bench.py's cpu_baseline."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, math.ceil(quota / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)

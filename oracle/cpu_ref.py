@@ -69,7 +69,8 @@ def timed_baseline(n, deriv, masks, times, d_fixed, target_seconds=12.0):
     times (sized from the calibration for ~target_seconds; a single thread spawn, so start-up cost is amortised)."""
     lib = load()
     dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
-    cores = max(1, lib.cpu_ref_hardware_threads())
+    from oracle import effective_cpus
+    cores = min(max(1, lib.cpu_ref_hardware_threads()), effective_cpus())
     times = np.ascontiguousarray(times, dtype=np.float64)
     d_fixed = np.ascontiguousarray(d_fixed, dtype=np.float64)
     bsz, k = times.shape
