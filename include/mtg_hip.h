@@ -83,10 +83,13 @@ enum {
   MTG_FLAG_FUSED_DIMS = 1u << 2,     /* all D dimensions in one workgroup (large batches)     */
   MTG_FLAG_SPLIT_DIMS = 1u << 3,     /* one dimension group per workgroup (small batches);    */
                                      /* default: chosen from the batch size                   */
-  MTG_FLAG_COST_ONLY = 1u << 4       /* only cost[] is produced (coeffs may be NULL): the     */
+  MTG_FLAG_COST_ONLY = 1u << 4,      /* only cost[] is produced (coeffs may be NULL): the     */
                                      /* objective evaluations of the time optimisers          */
                                      /* (polynomial_optimization_nonlinear_impl.h:313-359,    */
                                      /* :569-571) need J = computeCost(), not the segments    */
+  MTG_FLAG_DIMLANE = 1u << 5         /* force the dimension-in-lane launch form where the     */
+                                     /* plan and the call are eligible (SoA inputs, coeffs    */
+                                     /* only); default: chosen from the batch size            */
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -94,7 +97,9 @@ enum {
 int mtg_context_create(int device, void* stream, mtg_context** out);
 int mtg_context_destroy(mtg_context* ctx);
 /* Waits for everything enqueued on the context; returns MTG_ERR_BAD_SEGMENT_TIME /
- * MTG_ERR_SINGULAR if any trajectory of a solve since the last sync raised it.            */
+ * MTG_ERR_SINGULAR if any trajectory of a device-pointer solve since the last sync raised it
+ * (also solves replayed from a captured hipGraph: the status word is read from the device on
+ * every call).  Host-pointer calls report their status themselves.                        */
 int mtg_context_sync(mtg_context* ctx);
 const char* mtg_last_error_string(const mtg_context* ctx);
 const char* mtg_status_string(int status);
@@ -130,6 +135,16 @@ int mtg_copy_to_host(mtg_context* ctx, void* dst_host, const void* src_device, s
 int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
                      const double* times, const double* d_fixed, double* coeffs,
                      double* d_free, double* cost, uint32_t flags);
+
+/* mtg_solve_linear with a per-trajectory status output: trajectory_status[b] (int32, optional, NULL = none) receives
+ * 0, or the OR of 1 (a segment time <= 0: LIN:297 CHECK_GT) and 2 (non-positive pivot: rank-deficient free system,
+ * where the reference's rank-revealing SparseQR LIN:365-367 would still return a basic solution) for trajectory b --
+ * the batch-wide codes MTG_ERR_BAD_SEGMENT_TIME / MTG_ERR_SINGULAR say THAT a trajectory failed, this says WHICH.
+ * The library zero-fills it.  Device pointer, or host pointer with MTG_FLAG_HOST_POINTERS.
+ * With MTG_FLAG_HOST_POINTERS every solve / update entry is synchronous and returns the batch status itself.     */
+int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
+                            const double* times, const double* d_fixed, double* coeffs,
+                            double* d_free, double* cost, int32_t* trajectory_status, uint32_t flags);
 
 /* Replaces updateSegmentTimes() + setFreeConstraints() (LIN:500-508): coefficients from
  * caller-provided free constraints, no solve (the nonlinear optimiser's path,

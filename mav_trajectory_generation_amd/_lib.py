@@ -47,6 +47,8 @@ EXPORTS = {
     "mtg_plan_set_workspace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mtg_solve_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
+    "mtg_solve_linear_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
+                                               c_double_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_device_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
@@ -77,6 +79,7 @@ FLAG_GENERIC_KERNEL = 2
 FLAG_FUSED_DIMS = 4
 FLAG_SPLIT_DIMS = 8
 FLAG_COST_ONLY = 16
+FLAG_DIMLANE = 32
 
 _lib = None
 

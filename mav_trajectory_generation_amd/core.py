@@ -195,9 +195,13 @@ class Plan:
         return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
-              coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True):
+              coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True,
+              traj_status=None):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
+        dims: launch form -- 'auto', 'fused', 'split' (one dimension group per workgroup) or 'dimlane' (all dimensions of
+        a trajectory in one wavefront; SoA inputs, coefficient output only -- falls back to 'auto' where not eligible).
+        traj_status: optional int32 CUDA tensor [B] that receives the per-trajectory status bits (1 bad time, 2 singular).
         ordered=False skips the automatic ordering against torch's current stream (the caller forks / joins the
         context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors
         must then be passed in, allocated by the caller before the fork."""
@@ -215,10 +219,13 @@ class Plan:
             cost = torch.empty((batch,), dtype=torch.float64, device=dev)
         lay = self.layout(batch, layout)
         flags = L.FLAG_GENERIC_KERNEL if generic else 0
-        flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS}[dims]
+        flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        if traj_status is not None:
+            assert traj_status.dtype == torch.int32 and traj_status.is_cuda and traj_status.numel() >= batch
         cur = self.ctx._enter() if ordered else None
-        rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), self._ptr(times), self._ptr(d_fixed),
-                                       self._ptr(coeffs), self._ptr(d_free), self._ptr(cost), flags)
+        rc = self.lib.mtg_solve_linear_status(self.handle, batch, ctypes.byref(lay), self._ptr(times),
+                                              self._ptr(d_fixed), self._ptr(coeffs), self._ptr(d_free), self._ptr(cost),
+                                              self._ptr(traj_status), flags)
         if ordered:
             self.ctx._leave(cur)
         _check(self.lib, rc, self.ctx.handle)

@@ -1,0 +1,42 @@
+// Dimension-in-lane kernel instantiations (mtg_dimlane.h, mtg_dimlane_variants.inc).  This translation unit is
+// compiled with -mllvm -amdgpu-kernarg-preload-count=14: the kernels' arguments arrive in user SGPRs at wave launch.
+#include "mtg_dimlane.h"
+
+namespace {
+template <class C, int DL, int NP>
+int launch_dl(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
+              int* traj_status, int B, int ntiles, int policy) {
+  constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
+  static bool attr_set[3] = {false, false, false};
+  hipStream_t st = (hipStream_t)stream;
+  // store policy: 0 = nt sc1 (small launches, resident or not), 1 = sc1, 2 = plain write-back
+  auto go = [&](auto kern, int slot) -> int {
+    if (!attr_set[slot]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid);
+    return 0;
+  };
+  if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
+  if (policy == 2) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 0>, 2);
+  return go(mtg_solve_dl_kernel<C, DL, NP, 0, 18>, 0);
+}
+}  // namespace
+
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP) \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>(), launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>},
+static const MtgDimlaneEntry kDimlaneTable[] = {
+#include "mtg_dimlane_variants.inc"
+};
+#undef MTG_DL
+
+const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask) {
+  for (const MtgDimlaneEntry& e : kDimlaneTable) {
+    if (e.h != h || e.dl != dl || e.k != k || e.dv != deriv) continue;
+    bool ok = mask[0] == e.ms && mask[k] == e.me;
+    for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
+    if (ok) return &e;
+  }
+  return nullptr;
+}

@@ -55,7 +55,8 @@ struct MtgLdsOut {
       loff[i] = (t * (unsigned)QP + r) * 16u;
     }
   }
-  __device__ __forceinline__ double* row() { return stage + (size_t)lane * QP * 2; }
+  __device__ __forceinline__ double* row(int) { return stage + (size_t)lane * QP * 2; }
+  __device__ __forceinline__ void flush(const MtgParams& P) { drain(P); }
   // Cross-lane hand-off through LDS inside one wave: LDS operations of a wave execute in order, so no hardware
   // barrier is needed, but the COMPILER must not move the staged writes / reads across each other (they use
   // different lanes' addresses, which alias analysis cannot see): compiler-level memory fences on both sides.
@@ -285,5 +286,17 @@ struct MtgStaticEntry {
   SolveMultiFn multi[4];            // rolled entries: several plans in one launch, [extra outputs] + 2 * [write-through]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
+
+// dimension-in-lane launch form (mtg_dimlane.h / mtg_dimlane.hip): canonical SoA inputs, coefficient output (+ status)
+struct MtgDimlaneEntry {
+  int h, k, ms, mi, me, dv, dl, np;
+  int tpw;            // trajectories per wave (64 / dl)
+  size_t lds;         // dynamic LDS per workgroup
+  // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
+  // cache policy (0 nt sc1, 1 sc1, 2 write-back); returns 0 or -1 (attribute / launch set-up failed)
+  int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
+                int* traj_status, int B, int ntiles, int policy);
+};
+const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask);
 
 #endif  // MTG_KERNELS_H_

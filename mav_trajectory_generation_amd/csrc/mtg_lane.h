@@ -43,6 +43,7 @@ struct MtgParams {
   double* cost;                                     // optional, pre-zeroed, atomically accumulated
   double* ws;           long long ws_stride;        // generic mode back-substitution store
   int* status;                                      // OR of MTG_FLAG_* over the batch
+  int* tstatus;                                     // optional [B]: OR of MTG_FLAG_* per trajectory (pre-zeroed)
   const int* vmask;                                 // [K+1] fixed masks        (generic mode)
   const int* offF;                                  // [K+2] prefix of fixed slots
   const int* offP;                                  // [K+2] prefix of free slots
@@ -133,8 +134,11 @@ MTG_HD double mtg_fma(double a, double b, double c) {
 MTG_HD double mtg_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
-  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
-  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
+#ifndef MTG_RCP_NEWTON
+#define MTG_RCP_NEWTON 2
+#endif
+#pragma unroll
+  for (int it = 0; it < MTG_RCP_NEWTON; ++it) r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
   return r;
 #else
   return 1.0 / x;
@@ -524,8 +528,9 @@ template <class C>
 struct MtgDirectOut {
   double buf[C::D * C::N];
   long long b;
-  MTG_HD double* row() { return buf; }
+  MTG_HD double* row(int) { return buf; }
   MTG_HD void drain(const MtgParams&) {}
+  MTG_HD void flush(const MtgParams&) {}
   MTG_HD void commit(const MtgParams& P, int seg) {
     const int K = mtg_nseg<C>(P);
     double* out = P.coeffs + (((long long)b * K + seg) * P.Dtot + P.dim0) * C::N;
@@ -568,7 +573,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
   double* row = dummy_row;
   if constexpr (kStore) {
     io.drain(P);               // stream out the previously committed segment before reusing the staging row
-    row = io.row();
+    row = io.row(seg);
   }
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
@@ -1025,7 +1030,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       }
     }
   }
-  io.drain(P);
+  io.flush(P);
   if constexpr ((OUT & 1) != 0) {
     if (P.cost != nullptr && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1038,8 +1043,10 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   if (ln.flags && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(P.status, ln.flags);
+    if (P.tstatus != nullptr) atomicOr(P.tstatus + b, ln.flags);
 #else
     *P.status |= ln.flags;
+    if (P.tstatus != nullptr) P.tstatus[b] |= ln.flags;
 #endif
   }
 }
@@ -1093,7 +1100,7 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b, IO& io, bool active
       }
     }
   }
-  io.drain(P);
+  io.flush(P);
   if constexpr ((OUT & 1) != 0) {
     if (active) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1106,8 +1113,10 @@ MTG_HD void mtg_lane_update(const MtgParams& P, long long b, IO& io, bool active
   if (flags && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(P.status, flags);
+    if (P.tstatus != nullptr) atomicOr(P.tstatus + b, flags);
 #else
     *P.status |= flags;
+    if (P.tstatus != nullptr) P.tstatus[b] |= flags;
 #endif
   }
 }

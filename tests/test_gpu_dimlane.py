@@ -1,0 +1,205 @@
+"""GPU tests of the dimension-in-lane launch form (csrc/mtg_dimlane.h): all dimensions of a trajectory in one wavefront,
+whole-sector coefficient stores.  Called through the C ABI; checked against the oracle (1e-9 norm-wise per polynomial,
+the north-star tolerance), against the committed golden fixtures, and bit-for-bit against the dimension-split form,
+whose per-lane arithmetic it shares.  Also: the per-trajectory status output and status flags raised by kernels that are
+replayed from a captured hipGraph."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "solve_linear_golden.npz"))
+
+
+def case(name):
+    pre = name + "/"
+    return {k[len(pre):]: GOLD[k] for k in GOLD.files if k.startswith(pre)}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import mav_trajectory_generation_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+def to_soa(times, d_fixed):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(times)).cuda().t().contiguous()
+    f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda().permute(1, 2, 0).contiguous()
+    return t, f
+
+
+# (N, K, D, derivative, interior mask): the shapes of csrc/mtg_dimlane_variants.inc
+SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 4, 3, 4, 1), (10, 2, 3, 4, 1), (8, 4, 3, 3, 1),
+          (8, 8, 3, 3, 1), (12, 4, 3, 5, 1), (12, 8, 3, 5, 1), (10, 16, 4, 4, 7)]
+
+
+# shapes that also have a one-dimension-per-workgroup static variant (csrc/mtg_variants.inc): same instruction stream per lane
+BITWISE_VS_SPLIT = {(10, 8, 3, 4, 1), (12, 8, 3, 5, 1), (12, 4, 3, 5, 1), (8, 8, 3, 3, 1), (10, 16, 4, 4, 7)}
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("bsz", [1, 20, 21, 22, 43, 64, 257, 3000])
+def test_dimlane_vs_oracle_and_split_form(ctx, shape, bsz):
+    """Ragged sizes around the tile width (64 / D trajectories per wave) for every instantiated shape."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, d, mi = shape
+    masks = helpers.masks_ends_full(n, k, mi)
+    _, times, d_fixed = helpers.reference_batch(min(bsz, 64), k, n, dim, 4242 + bsz, masks)
+    if bsz > 64:   # beyond 64 the bit-exact generator is slow: tile the 64 with scaled times (still distinct problems)
+        reps = (bsz + 63) // 64
+        scale = 1.0 + 0.01 * np.arange(reps).repeat(64)[:bsz]
+        times = np.tile(times, (reps, 1))[:bsz] * scale[:, None]
+        d_fixed = np.tile(d_fixed, (reps, 1, 1))[:bsz]
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = to_soa(times, d_fixed)
+    co = torch.full((bsz + 1, k, dim, n), 7.0, dtype=torch.float64, device="cuda")   # one guard row behind the batch
+    plan.solve(t, f, layout="soa", coeffs=co[:bsz], dims="dimlane")
+    ref, _, _ = plan.solve(t, f, layout="soa", dims="split")
+    ctx.sync()
+    assert float(co[bsz].min()) == 7.0 and float(co[bsz].max()) == 7.0, "stores past the end of the batch"
+    got = co[:bsz].cpu().numpy()
+    ref = ref.cpu().numpy()
+    assert helpers.poly_relerr(got, ref) < 1e-12
+    if shape in BITWISE_VS_SPLIT:
+        assert np.array_equal(got, ref), "dimension-in-lane and dimension-split forms share the lane arithmetic"
+    nchk = min(bsz, 64)
+    c_lit, _, _ = onp.solve_batch(n, d, masks, times[:nchk], d_fixed[:nchk])
+    tol = 1e-9 if n <= 10 else 5e-7     # N = 12: the literal float64 route itself is ~1e-8 from the 50-digit solution
+    assert helpers.poly_relerr(got[:nchk], c_lit) < tol
+    assert helpers.check_path(masks, times[:nchk], d_fixed[:nchk], got[:nchk]) < 1e-6
+    plan.close()
+
+
+@pytest.mark.parametrize("name", ["config2", "config5", "readme"])
+def test_dimlane_golden_fixtures(ctx, name):
+    import mav_trajectory_generation_amd as m
+    c = case(name)
+    n, d = int(c["n"]), int(c["d"])
+    masks = [int(x) for x in c["masks"]]
+    dim, k = c["d_fixed"].shape[1], c["times"].shape[1]
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = to_soa(c["times"], c["d_fixed"])
+    co, _, _ = plan.solve(t, f, layout="soa", dims="dimlane")
+    ctx.sync()
+    co = co.cpu().numpy()
+    assert helpers.poly_relerr(co, c["coeffs_lit"]) < 1e-9
+    assert helpers.poly_relerr(co, c["coeffs_mp"]) < 1e-11
+    plan.close()
+
+
+def test_dimlane_is_the_default_for_the_bench_call(ctx):
+    """bench.py's call (SoA inputs, coefficient output only, B = 10k) must take the dimension-in-lane form: the result is
+    bit-identical to the forced form and the library's own timing hook replays a dimension-in-lane launch."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(10_000, 8, 3, 10, masks, seed=3, device="cuda", layout="soa")
+    a, _, _ = plan.solve(t, f, layout="soa")
+    us_auto = plan.time_last_solve(20)
+    b, _, _ = plan.solve(t, f, layout="soa", dims="dimlane")
+    c, _, _ = plan.solve(t, f, layout="soa", dims="fused")
+    us_fused = plan.time_last_solve(20)
+    ctx.sync()
+    assert torch.equal(a, b)
+    den = c.abs().amax(dim=-1).clamp_min(1e-300)
+    assert float(((a - c).abs().amax(dim=-1) / den).max()) < 1e-11
+    assert us_auto < us_fused
+    plan.close()
+
+
+def test_full_size_dimlane_properties(ctx):
+    """BASELINE config 2 at full size through the default path: checkPath at 1e-6, linearity in d_F, oracle parity on
+    a strided subset."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    bsz = 10_000
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(bsz, 8, 3, 10, masks, seed=11, device="cuda", layout="soa")
+    co, _, _ = plan.solve(t, f, layout="soa")
+    co2, _, _ = plan.solve(t, (f * 2.0).contiguous(), layout="soa")
+    ctx.sync()
+    assert torch.isfinite(co).all()
+    den = co.abs().amax(dim=-1).clamp_min(1e-300)
+    assert float(((co2 - 2.0 * co).abs().amax(dim=-1) / den).max()) < 1e-11
+    idx = np.arange(0, bsz, 20)
+    th = t.t().contiguous().cpu().numpy()[idx]
+    fh = f.permute(2, 0, 1).contiguous().cpu().numpy()[idx]
+    c_lit, _, _ = onp.solve_batch(10, 4, masks, th, fh)
+    got = co.cpu().numpy()[idx]
+    assert helpers.poly_relerr(got, c_lit) < 1e-9
+    assert helpers.check_path(masks, th, fh, got) < 1e-6
+    plan.close()
+
+
+@pytest.mark.parametrize("dims", ["dimlane", "split", "fused", "generic"])
+def test_per_trajectory_status(ctx, dims):
+    """A batch with some non-positive segment times (LIN:297): the batch code says THAT a trajectory failed, the
+    per-trajectory status says which -- every launch form."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    bsz = 500
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(bsz, 8, 3, 10, masks, seed=5, device="cuda", layout="soa")
+    bad = [3, 20, 21, 63, 64, 255, 499]
+    for i, b in enumerate(bad):
+        t[i % 8, b] = -1.0 if i % 2 else 0.0
+    st = torch.full((bsz,), 99, dtype=torch.int32, device="cuda")
+    kw = dict(generic=True) if dims == "generic" else dict(dims=dims)
+    co, _, _ = plan.solve(t, f, layout="soa", traj_status=st, **kw)
+    with pytest.raises(m.MtgError) as e:
+        ctx.sync()
+    assert e.value.code == -2
+    got = st.cpu().numpy()
+    want = np.zeros(bsz, dtype=np.int32)
+    want[bad] = 1
+    assert np.array_equal(got & 1, want)
+    # T < 0 makes the first pivot of that segment's vertex negative (T^(1-2d) < 0): the singular bit names it too
+    neg = [b for i, b in enumerate(bad) if i % 2]
+    assert np.all(got[neg] == 3)
+    ok = np.setdiff1d(np.arange(bsz), bad)
+    assert np.all(got[ok] == 0)
+    assert torch.isfinite(co[torch.from_numpy(ok).cuda()]).all()
+    ctx.sync()
+    plan.close()
+
+
+def test_status_of_graph_replays_is_reported(ctx):
+    """Kernels replayed from a captured hipGraph never pass through the library: mtg_context_sync must still see the
+    flags they raise (the host-side dirty flag hid them)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(2000, 8, 3, 10, masks, seed=8, device="cuda", layout="soa")
+    co = torch.empty((2000, 8, 3, 10), dtype=torch.float64, device="cuda")
+    plan.solve(t, f, layout="soa", coeffs=co)     # warm-up outside the capture (LDS attribute, allocations)
+    ctx.sync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(ctx.stream):
+        with torch.cuda.graph(g, stream=ctx.stream):
+            plan.solve(t, f, layout="soa", coeffs=co, ordered=False)
+    g.replay()
+    ctx.sync()                                      # clean replay: no error
+    t[2, 77] = -3.0                                 # new values in the captured buffers
+    g.replay()
+    with pytest.raises(m.MtgError) as e:
+        ctx.sync()
+    assert e.value.code == -2
+    t[2, 77] = 1.0
+    g.replay()
+    ctx.sync()
+    plan.close()

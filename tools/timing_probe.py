@@ -64,3 +64,20 @@ if ok.any():
         print("  lifetime of waves with %d wave(s) on their SIMD: median %.2f max %.2f (n=%d)" % (c, np.median(life[share == c]), life[share == c].max(), (share == c).sum()))
     late = s0 > np.percentile(s0, 75)
     print("  lifetime of the last-started quarter: median %.2f; of the first-started quarter: median %.2f" % (np.median(life[late]), np.median(life[s0 <= np.percentile(s0, 25)])))
+
+    # absolute timeline on the device-wide clock: when does each phase begin / end across the launch?
+    # (shader-cycle stamps converted per wave: phase offset in cycles / that wave's cycles-per-us)
+    cyc = (T[ok, 4] - T[ok, 0]).astype(float)              # start .. stores_done in shader cycles
+    per_us = cyc / np.maximum(s1 - s0, 1e-9)
+    print("  shader clock during the wave lifetimes: median %.0f MHz (p10 %.0f, p90 %.0f)" % (
+        np.median(per_us), np.percentile(per_us, 10), np.percentile(per_us, 90)))
+    def abs_us(col):
+        return s0 + (T[ok, col] - T[ok, 0]) / per_us
+    pct = lambda v: "min %.2f p25 %.2f med %.2f p75 %.2f max %.2f" % (v.min(), np.percentile(v, 25), np.median(v), np.percentile(v, 75), v.max())
+    print("  [us after the first wave start]")
+    print("  wave start      : " + pct(s0))
+    print("  preload done    : " + pct(abs_us(5)))
+    print("  forward done    : " + pct(abs_us(1)))
+    print("  middle solved   : " + pct(abs_us(6)))
+    print("  last seg recov. : " + pct(abs_us(3)))
+    print("  stores acked    : " + pct(s1))
