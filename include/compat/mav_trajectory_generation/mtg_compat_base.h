@@ -40,6 +40,18 @@ struct Voidify { void operator&(const CheckFailure&) {} };
 #define CHECK_GT(a, b) CHECK((a) > (b))
 #define CHECK_LT(a, b) CHECK((a) < (b))
 #define CHECK_NOTNULL(p) (((p) == nullptr) ? (::mtg_compat::CheckFailure(__FILE__, __LINE__, #p " != nullptr"), (p)) : (p))
+namespace mtg_compat {
+// LOG(WARNING) / LOG(ERROR): one line on stderr, like glog's default sink
+class LogLine {
+ public:
+  LogLine(const char* sev, const char* file, int line) { s_ << sev << " " << file << ":" << line << "] "; }
+  ~LogLine() { std::cerr << s_.str() << std::endl; }
+  template <class T> LogLine& operator<<(const T& t) { s_ << t; return *this; }
+ private:
+  std::ostringstream s_;
+};
+}  // namespace mtg_compat
+#define LOG(severity) ::mtg_compat::LogLine(#severity, __FILE__, __LINE__)
 #endif
 
 #endif

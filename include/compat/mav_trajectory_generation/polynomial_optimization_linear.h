@@ -34,38 +34,40 @@ namespace mtg_compat_detail {
 // One library context per host thread, plus that thread's plans keyed by constraint structure: the reference's callers
 // set the same structure up over and over (every nlopt objective call, every run of the timing benchmark), and a plan
 // costs a device allocation + a synchronous table upload to create and a stream synchronisation to destroy.
+// Lifetime: the context is reference-counted and every plan's deleter holds a reference, so an optimiser that was
+// created (or copied) on one thread and outlives that thread keeps its context alive; solve calls with host pointers are
+// synchronous and return their own status, so no per-thread status ever has to be collected from another thread's context.
 struct ThreadContext {
-  mtg_context* ctx = nullptr;
+  std::shared_ptr<mtg_context> ctx;
   std::map<std::vector<uint32_t>, std::shared_ptr<mtg_plan>> plans;
-  ~ThreadContext() {
-    plans.clear();
-    if (ctx) mtg_context_destroy(ctx);
-  }
 };
 inline ThreadContext& thread_state() {
   static thread_local ThreadContext tc;
   return tc;
 }
-inline mtg_context* context() {
+inline std::shared_ptr<mtg_context> context_ref() {
   ThreadContext& tc = thread_state();
   if (!tc.ctx) {
-    const int rc = mtg_context_create(0, nullptr, &tc.ctx);
+    mtg_context* raw = nullptr;
+    const int rc = mtg_context_create(0, nullptr, &raw);
     CHECK(rc == MTG_OK) << "mtg_context_create: " << mtg_status_string(rc) << " (the solver has no CPU fallback)";
+    tc.ctx = std::shared_ptr<mtg_context>(raw, [](mtg_context* c) { mtg_context_destroy(c); });
   }
   return tc.ctx;
 }
+inline mtg_context* context() { return context_ref().get(); }
 inline std::shared_ptr<mtg_plan> make_plan(int N, int D, int K, int derivative, const std::vector<uint32_t>& mask) {
   std::vector<uint32_t> key{(uint32_t)N, (uint32_t)D, (uint32_t)K, (uint32_t)derivative};
   key.insert(key.end(), mask.begin(), mask.end());
-  mtg_context* ctx = context();
+  std::shared_ptr<mtg_context> ctx = context_ref();
   ThreadContext& tc = thread_state();
   auto it = tc.plans.find(key);
   if (it != tc.plans.end()) return it->second;
   mtg_plan_desc desc{N, D, K, derivative, mask.data()};
   mtg_plan* p = nullptr;
-  const int rc = mtg_plan_create(ctx, &desc, &p);
-  CHECK(rc == MTG_OK) << "mtg_plan_create: " << mtg_status_string(rc) << " " << mtg_last_error_string(ctx);
-  std::shared_ptr<mtg_plan> sp(p, [](mtg_plan* q) { mtg_plan_destroy(q); });
+  const int rc = mtg_plan_create(ctx.get(), &desc, &p);
+  CHECK(rc == MTG_OK) << "mtg_plan_create: " << mtg_status_string(rc) << " " << mtg_last_error_string(ctx.get());
+  std::shared_ptr<mtg_plan> sp(p, [ctx](mtg_plan* q) { mtg_plan_destroy(q); });   // the deleter keeps the context alive
   if (tc.plans.size() >= 256) tc.plans.clear();   // bounded; live optimisers keep their own references
   tc.plans.emplace(std::move(key), sp);
   return sp;
@@ -142,10 +144,12 @@ class PolynomialOptimization {
     segment_times_ = segment_times;
   }
 
+  // Returns false (instead of the reference's unconditional true) when the free-constraint system is rank deficient:
+  // the reference's rank-revealing SparseQR (LIN:365-367) still returns a basic solution there, the LDL^T solve on the
+  // device does not -- the segments are left untouched ("behaviour differences").
   bool solveLinear() {
     CHECK(derivative_to_optimize_ >= 0 && derivative_to_optimize_ <= kHighestDerivativeToOptimize);
-    run(/*solve=*/true);
-    return true;
+    return run(/*solve=*/true) == MTG_OK;
   }
 
   void setFreeConstraints(const std::vector<Eigen::VectorXd>& free_constraints) {
@@ -370,7 +374,7 @@ class PolynomialOptimization {
     return col;
   }
 
-  void run(bool solve) {
+  int run(bool solve) {
     CHECK(plan_ != nullptr) << "setupFromVertices() has to be called first";
     const size_t D = dimension_, K = n_segments_, nf = n_fixed_constraints_, np = n_free_constraints_;
     std::vector<double> d_fixed(D * nf), d_free(D * np + 1), coeffs(K * D * N);
@@ -388,8 +392,10 @@ class PolynomialOptimization {
       rc = mtg_update_segments_from_free(plan_.get(), 1, &lay, segment_times_.data(), d_fixed.data(), d_free.data(),
                                          coeffs.data(), nullptr, MTG_FLAG_HOST_POINTERS);
     }
-    CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_compat_detail::context());
-    mtg_compat_detail::check_sync();
+    // host-pointer calls are synchronous and return the batch status themselves (on the plan's own context, whichever
+    // thread created it)
+    if (rc == MTG_ERR_SINGULAR) return rc;
+    CHECK(rc == MTG_OK) << mtg_status_string(rc);   // LIN:297 CHECK_GT(segment_time, 0) and friends surface here
     for (size_t d = 0; d < D; ++d) {
       if (solve) for (size_t c = 0; c < np; ++c) free_constraints_compact_[d][c] = d_free[d * np + c];
       for (size_t k = 0; k < K; ++k) {
@@ -399,6 +405,7 @@ class PolynomialOptimization {
         segments_[k][d] = Polynomial(N, c);
       }
     }
+    return MTG_OK;
   }
 
   Vertex::Vector vertices_;
@@ -438,8 +445,8 @@ class PolynomialOptimizationBatch {
     mtg_layout_aos(plan_.get(), (int64_t)batch, &lay);
     const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
                                     device_pointers ? 0u : (uint32_t)MTG_FLAG_HOST_POINTERS);
+    if (rc == MTG_ERR_SINGULAR) return false;   // host-pointer calls report their status themselves
     CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_compat_detail::context());
-    if (!device_pointers) mtg_compat_detail::check_sync();
     return true;
   }
   void sync() { mtg_compat_detail::check_sync(); }

@@ -50,14 +50,25 @@ class Trajectory {
     for (const Segment& s : segments_) t.push_back(s.getTime());
     return t;
   }
-  // value of the derivative at absolute time t (clamped to the last segment's end)
+  // Value of the derivative at absolute time t, with the reference's segment choice (src/trajectory.cpp:48-79): a time
+  // that falls exactly on a vertex belongs to the segment RIGHT of it (derivatives of order >= N/2 jump there, and the
+  // device sampler makes the same choice); the trajectory's end time evaluates the last segment at its duration; a time
+  // beyond the end is an error in the reference (LOG(ERROR)) and yields the zero vector.
   Eigen::VectorXd evaluate(double t, int derivative_order = derivative_order::POSITION) const {
     CHECK(!segments_.empty());
+    double accumulated = 0.0;
     size_t i = 0;
-    double acc = 0.0;
-    while (i + 1 < segments_.size() && t > acc + segments_[i].getTime()) acc += segments_[i++].getTime();
-    const double local = std::min(t - acc, segments_[i].getTime());
-    return segments_[i].evaluate(local, derivative_order);
+    for (; i < segments_.size(); ++i) {
+      accumulated += segments_[i].getTime();
+      if (accumulated > t) break;
+    }
+    if (t > accumulated) {
+      LOG(ERROR) << "Time out of range of the trajectory!";
+      return Eigen::VectorXd::Zero(D());
+    }
+    if (i >= segments_.size()) i = segments_.size() - 1;
+    accumulated -= segments_[i].getTime();
+    return segments_[i].evaluate(t - accumulated, derivative_order);
   }
 
   // Samples derivative_order every dt from t_start while the running time is below t_end, walking the segments

@@ -146,6 +146,14 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
                             const double* times, const double* d_fixed, double* coeffs,
                             double* d_free, double* cost, int32_t* trajectory_status, uint32_t flags);
 
+/* A queue of n independent batches of the same plan (same batch size, layout and flags): solve i reads times[i] /
+ * d_fixed[i] and writes coeffs[i] (host arrays of n DEVICE pointers), one kernel launch each, enqueued back to back on the
+ * context's stream by ONE host call -- what a pipeline that streams batch after batch through the solver does (the
+ * reference's counterpart is a loop over setupFromVertices + solveLinear, polynomial_timing_evaluation.cpp:104-110).  */
+int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
+                              const double* const* times, const double* const* d_fixed, double* const* coeffs,
+                              uint32_t flags);
+
 /* Replaces updateSegmentTimes() + setFreeConstraints() (LIN:500-508): coefficients from
  * caller-provided free constraints, no solve (the nonlinear optimiser's path,
  * polynomial_optimization_nonlinear_impl.h:695-696).  d_free is an INPUT here.            */

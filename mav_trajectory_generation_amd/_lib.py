@@ -49,6 +49,8 @@ EXPORTS = {
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_solve_linear_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
                                                c_double_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "mtg_solve_linear_sequence": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_device_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),

@@ -642,6 +642,19 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false, trajectory_status);
 }
 
+int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
+                              const double* const* times, const double* const* d_fixed, double* const* coeffs,
+                              uint32_t flags) {
+  if (!plan || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
+  if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
+  for (int32_t i = 0; i < n; ++i) {
+    const int rc = solve_impl(plan, batch, layout, times[i], d_fixed ? d_fixed[i] : nullptr, coeffs[i], nullptr, nullptr,
+                              flags, false);
+    if (rc != MTG_OK) return rc;
+  }
+  return MTG_OK;
+}
+
 int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                                   const double* d_fixed, const double* d_free, double* coeffs, double* cost,
                                   uint32_t flags) {

@@ -48,3 +48,61 @@ def solve_sharded(plan, times, d_fixed, layout: str = "aos", gather: bool = Fals
         t, f = times[:, lo:hi].contiguous(), d_fixed[:, :, lo:hi].contiguous()
     coeffs, _, _ = plan.solve(t, f, layout=layout)
     return gather_coeffs(coeffs, batch, group) if gather else coeffs
+
+
+class ChunkedSolveGather:
+    """Solve this rank's batch in `n_chunks` pieces and all_gather every piece as soon as it is solved, on a second
+    stream: chunk i's gather (RCCL over xGMI) overlaps chunk i+1's solve (at 240 MB per rank the
+    gather takes ~10x the solve, so it is worth hiding the solve behind it, not the other way round).
+
+    The gathered buffer is chunk-major: gathered[c][r] = rank r's chunk c, shape [n_chunks][world][Bc][K][D][N]; global
+    trajectory index of gathered[c][r][i] = r * B + c * Bc + i (B divisible by n_chunks is required)."""
+
+    def __init__(self, plan, times, d_fixed, layout: str = "soa", n_chunks: int = 4, group=None):
+        import torch
+        import torch.distributed as dist
+        self.plan, self.layout, self.group = plan, layout, group
+        self.world = dist.get_world_size(group)
+        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        while n_chunks > 1 and batch % n_chunks:
+            n_chunks -= 1
+        self.n_chunks, self.bc = n_chunks, batch // n_chunks
+        dev = times.device
+        self.chunks = []
+        for c in range(n_chunks):
+            lo, hi = c * self.bc, (c + 1) * self.bc
+            if layout == "aos":
+                t, f = times[lo:hi].contiguous(), d_fixed[lo:hi].contiguous()
+            else:
+                t, f = times[:, lo:hi].contiguous(), d_fixed[:, :, lo:hi].contiguous()
+            self.chunks.append((t, f))
+        self.local = torch.empty((n_chunks, self.bc, plan.K, plan.D, plan.N), dtype=torch.float64, device=dev)
+        self.gathered = torch.empty((n_chunks, self.world, self.bc, plan.K, plan.D, plan.N), dtype=torch.float64, device=dev)
+        self.backend = dist.get_backend(group)
+        self.comm = torch.cuda.Stream(dev)
+        self.host_bounce = None
+        if self.backend != "nccl":   # gloo (multi-process tests on a 1-GPU box): the gather goes through host memory
+            self.host_bounce = (torch.empty(self.local[0].shape, dtype=torch.float64).pin_memory(),
+                                torch.empty(self.gathered[0].shape, dtype=torch.float64).pin_memory())
+
+    def run(self, solve: bool = True, gather: bool = True):
+        import torch
+        import torch.distributed as dist
+        ctx = self.plan.ctx
+        for c, (t, f) in enumerate(self.chunks):
+            if solve:
+                self.plan.solve(t, f, layout=self.layout, coeffs=self.local[c])
+            if gather:
+                if self.backend == "nccl":
+                    self.comm.wait_stream(ctx.stream)
+                    with torch.cuda.stream(self.comm):
+                        dist.all_gather_into_tensor(self.gathered[c].flatten(0, 1), self.local[c], group=self.group)
+                else:
+                    ctx.stream.synchronize()
+                    h_in, h_out = self.host_bounce
+                    h_in.copy_(self.local[c])
+                    dist.all_gather_into_tensor(h_out.flatten(0, 1), h_in, group=self.group)
+                    self.gathered[c].copy_(h_out)
+        if gather and self.backend == "nccl":
+            torch.cuda.current_stream().wait_stream(self.comm)
+        return self.gathered

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdio>
 #include <numeric>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include <mav_trajectory_generation/polynomial_optimization_linear.h>
@@ -341,6 +343,48 @@ int main() {
       EXPECT(std::abs(mixed_costs[i] - opt.computeCost()) <= 1e-8 * std::abs(opt.computeCost()), "problem %zu cost", i);
       EXPECT(checkPath(problems[i], mixed[i], 10) < 1e-6, "problem %zu checkPath", i);
     }
+  }
+  {  // Trajectory::evaluate: the reference's segment choice (src/trajectory.cpp:48-79)
+    Vertex::Vector v = createRandomVertices(derivative_order::SNAP, 3, Eigen::VectorXd::Constant(3, -10.0),
+                                            Eigen::VectorXd::Constant(3, 10.0), 77);
+    std::vector<double> times = estimateSegmentTimes(v, 3.0, 5.0);
+    PolynomialOptimization<10> opt(3);
+    opt.setupFromVertices(v, times, derivative_order::SNAP);
+    EXPECT(opt.solveLinear(), "solveLinear returns true on a well-posed problem");
+    Trajectory traj;
+    opt.getTrajectory(&traj);
+    // order-5 derivatives jump at a position-only waypoint: exactly on the vertex the RIGHT segment is evaluated
+    const Eigen::VectorXd at = traj.evaluate(times[0], 5), right = traj.segments()[1].evaluate(0.0, 5),
+                          left = traj.segments()[0].evaluate(times[0], 5);
+    // (the local time is t - (accumulated - T_1), zero only up to rounding -- as in the reference)
+    EXPECT((at - right).norm() <= 1e-9 * (1.0 + right.norm()), "vertex time evaluates the right segment");
+    EXPECT((at - left).norm() > 1e-6 * (1.0 + left.norm()), "derivative 5 is discontinuous at the waypoint (otherwise the check is vacuous)");
+    const double t_end = traj.getMaxTime();
+    const Eigen::VectorXd end = traj.evaluate(t_end, 0), last = traj.segments()[2].evaluate(times[2], 0);
+    EXPECT((end - last).norm() <= 1e-12 * (1.0 + last.norm()), "end time evaluates the last segment at its duration");
+    EXPECT(traj.evaluate(t_end + 1.0, 0).norm() == 0.0, "beyond the end: zero vector, as the reference");
+  }
+  {  // an optimiser created on one thread, solved on another after the first thread is gone
+    std::unique_ptr<PolynomialOptimization<10>> opt;
+    Vertex::Vector v = createRandomVertices(derivative_order::SNAP, 5, Eigen::VectorXd::Constant(3, -10.0),
+                                            Eigen::VectorXd::Constant(3, 10.0), 78);
+    std::vector<double> times = estimateSegmentTimes(v, 3.0, 5.0);
+    std::thread maker([&] {
+      opt.reset(new PolynomialOptimization<10>(3));
+      opt->setupFromVertices(v, times, derivative_order::SNAP);
+    });
+    maker.join();   // the creating thread (and its thread-local context handle) is gone; the plan keeps the context alive
+    bool ok = false;
+    Segment::Vector segs;
+    std::thread solver([&] {
+      PolynomialOptimization<10> copy = *opt;   // value semantics across threads
+      ok = copy.solveLinear();
+      copy.getSegments(&segs);
+    });
+    solver.join();
+    EXPECT(ok, "cross-thread solveLinear");
+    EXPECT(checkPath(v, segs, 10) < 1e-6, "cross-thread checkPath");
+    opt.reset();
   }
   std::printf(g_fail ? "VENEER TESTS FAILED: %d\n" : "VENEER TESTS PASSED%.0d\n", g_fail);
   return g_fail ? 1 : 0;

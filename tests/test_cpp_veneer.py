@@ -18,7 +18,7 @@ def build_exe():
         return
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include", "compat"),
                            "-I" + os.path.join(ROOT, "include"), "-o", EXE, src,
-                           "-L" + os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc"), "-lmtg_hip",
+                           "-L" + os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc"), "-lmtg_hip", "-pthread",
                            "-Wl,-rpath,$ORIGIN/../../mav_trajectory_generation_amd/csrc"])
 
 
