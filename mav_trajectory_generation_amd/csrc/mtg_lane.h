@@ -912,6 +912,12 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
+#if defined(MTG_TIE_NEXT) && defined(__HIP_DEVICE_COMPILE__)
+      // Scheduling hint (no instruction): the T-only work of step j+1 (scales, block assembly, right-hand-side partial
+      // sums) may not start before step j's dependent chain does -- it then fills that chain's latency gaps instead of
+      // being hoisted in front of all chains.
+      if (j + 1 < KC) asm("" : "+v"(ln.T[j + 1]) : "v"(ln.Sc[H - 1][H - 1]));
+#endif
       mtg_fwd_step<C, DIR>(P, b, j, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)), ln,
                            ln.G[j], ln.g[j]);
     }
