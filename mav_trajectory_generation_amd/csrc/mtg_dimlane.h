@@ -53,6 +53,7 @@ struct MtgSlabOut {
   __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_) {
     slab = slab_; lane = lane_; t = t_; d = d_;
     pn = 0;
+    init_map();
   }
   // tile = TPW trajectories starting at b0; the descriptor ends at the last existing trajectory, the hardware range
   // check drops the chunks of the tail tile's missing ones
@@ -78,22 +79,21 @@ struct MtgSlabOut {
   __device__ __forceinline__ double* row(int seg) {
     return reinterpret_cast<double*>(slab + t * ROWB + (seg * S - HALF_LO) + d * (N * 8));
   }
-  static constexpr int MAXI = (TPW * ((S + 64) / 16) + 63) / 64;   // store instructions of one range, at most
-  u4 pv[MAXI];          // chunks of the previously committed range, read from the slab, not yet stored
-  unsigned pg[MAXI];    // their byte offsets in the tile's output
-  int pn;               // how many of them are in use
-  __device__ __forceinline__ void store_pending() {
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      if (i < pn) __builtin_amdgcn_raw_buffer_store_b128(pv[i], rsrc, (int)pg[i], 0, AUX);
+  // Chunk -> (trajectory, offset) mapping of a drained range.  A lone wave pays ~4 cycles for EVERY instruction, so the
+  // index arithmetic matters: where the largest range has at most 16 chunks (256 bytes; BASELINE config 2: 192 / 256),
+  // a range is laid out as CHP = 4 / 8 / 16 chunks per trajectory (padded; surplus chunks are sent out of range), so that
+  // lane -> (trajectory, chunk) is a shift and a mask done ONCE per kernel (gl, ll below) and every chunk of every drain is
+  // that plus a compile-time constant.  Other shapes divide by the run-time-free chunk count (a multiply-high).
+  static constexpr int max_range_chunks() {
+    int m = 0;
+    for (int seg = (DIR > 0 ? 0 : KA); seg < (DIR > 0 ? KA : K); ++seg) {
+      int lo, hi;
+      range_of(seg, lo, hi);
+      if ((hi - lo) / 16 > m) m = (hi - lo) / 16;
     }
-    pn = 0;
+    return m;
   }
-  // The segment's rows are in the slab: stream out the PREVIOUS range (its LDS reads were issued one segment ago and
-  // have long landed), then issue the LDS reads of the range this segment completed.  The stores of a range thus trail
-  // its recovery by one back-substitution step and never wait for LDS.
-  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
-    int lo, hi;
+  static constexpr void range_of(int seg, int& lo, int& hi) {
     if (DIR > 0) {   // segments arrive KA-1, ..., 0: the completed range grows downwards
       lo = seg == 0 ? 0 : up64(seg * S);
       hi = seg == KA - 1 ? KA * S : up64((seg + 1) * S);
@@ -101,21 +101,69 @@ struct MtgSlabOut {
       lo = seg == KA ? KA * S : dn64(seg * S);
       hi = seg == K - 1 ? K * S : dn64((seg + 1) * S);
     }
+    if (hi < lo) hi = lo;
+  }
+  static constexpr int MAXCH = max_range_chunks();
+  static constexpr int CHP = MAXCH <= 4 ? 4 : (MAXCH <= 8 ? 8 : (MAXCH <= 16 ? 16 : 0));   // 0: generic mapping
+  static constexpr int RPI = CHP ? kWave / CHP : 0;                                        // trajectories per store instruction
+  static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
+  u4 pv[MAXI];          // chunks of the previously committed range, read from the slab, not yet stored
+  unsigned pg[MAXI];    // their byte offsets in the tile's output
+  int pn;               // how many of them are in use
+  unsigned gl, ll;      // CHP mapping: this lane's (trajectory, chunk) part of the global / LDS byte offset
+  __device__ __forceinline__ void init_map() {
+    if constexpr (CHP != 0) {
+      const unsigned tr = (unsigned)lane / (unsigned)CHP, rr = (unsigned)lane % (unsigned)CHP;
+      gl = tr * (unsigned)PIECE + rr * 16u;
+      ll = tr * (unsigned)ROWB + rr * 16u;
+    }
+  }
+  __device__ __forceinline__ void store_pending() {
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      if (i < pn) __builtin_amdgcn_raw_buffer_store_b128(pv[i], rsrc, (int)pg[i], 0, AUX);
+    }
+    pn = 0;
+  }
+  // The segment's rows are in the slab: issue the LDS reads of the 64-byte-aligned range this segment completed; the
+  // next drain() (start of the next segment's recovery, after its back-substitution) stores them, so the LDS round trip
+  // overlaps arithmetic.
+  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
+    int lo = 0, hi = 0;
+    range_of(seg, lo, hi);
     fence();
     __builtin_amdgcn_sched_barrier(0);
     if (hi > lo) {
       const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
-      const int total = TPW * nch;
+      if constexpr (CHP != 0) {
+        const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
 #pragma unroll
-      for (int i = 0; i < MAXI; ++i) {
-        if (i * 64 < total) {
-          const unsigned o = (unsigned)(i * 64 + lane);
-          const unsigned tt = o / (unsigned)nch, r = o - tt * (unsigned)nch;
-          const bool ok = o < (unsigned)total;
-          pg[i] = ok ? tt * (unsigned)PIECE + (unsigned)lo + r * 16u : 0x7ffffff0u;
-          const unsigned loff = ok ? tt * (unsigned)ROWB + (unsigned)(lo - HALF_LO) + r * 16u : 0u;
-          pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
+        for (int i = 0; i < MAXI; ++i) {
+          const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
+          unsigned g = gl + (unsigned)(i * RPI * PIECE + lo);
+          if (!all_chunks || !all_rows) {
+            bool ok = true;
+            if (!all_chunks) ok = ok && rr < (unsigned)nch;
+            if (!all_rows) ok = ok && tr < (unsigned)(TPW - i * RPI);
+            g = ok ? g : 0x7ffffff0u;
+          }
+          pg[i] = g;
+          pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + ll + (unsigned)(i * RPI * ROWB + (lo - HALF_LO))));
           pn = i + 1;
+        }
+      } else {
+        const int total = TPW * nch;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+          if (i * 64 < total) {
+            const unsigned o = (unsigned)(i * 64 + lane);
+            const unsigned tt = o / (unsigned)nch, r = o - tt * (unsigned)nch;
+            const bool ok = o < (unsigned)total;
+            pg[i] = ok ? tt * (unsigned)PIECE + (unsigned)lo + r * 16u : 0x7ffffff0u;
+            const unsigned loff = ok ? tt * (unsigned)ROWB + (unsigned)(lo - HALF_LO) + r * 16u : 0u;
+            pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
+            pn = i + 1;
+          }
         }
       }
     }
@@ -227,6 +275,7 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
     else mtg_dl_preload<C, -1>(times, dfix, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
   };
   if ((int)blockIdx.x < nunits) fetch(tile_of(blockIdx.x));
+  const int lane_io = lane, t_io = t, d_io = d;
 #if defined(MTG_LAB_TIMING)
   if (lane == 0) tdbg[1] = clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -240,12 +289,12 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
   char* base = lds_raw + (size_t)pair * mtg_dl_pair_bytes<C, DL>();
   constexpr size_t half = mtg_dl_pair_bytes<C, DL>() / 2;
   char* my_slab = base + (size_t)dir * half;
-  double* mine = reinterpret_cast<double*>(base + (size_t)(1 - dir) * half) + lane;
-  const double* other = reinterpret_cast<const double*>(my_slab) + lane;
+  double* mine = reinterpret_cast<double*>(base + (size_t)(1 - dir) * half) + lane_io;
+  const double* other = reinterpret_cast<const double*>(my_slab) + lane_io;
   MtgSlabOut<C, DL, 1, AUX> ioA;
   MtgSlabOut<C, DL, -1, AUX> ioB;
-  ioA.init(my_slab, lane, t, d);
-  ioB.init(my_slab, lane, t, d);
+  ioA.init(my_slab, lane_io, t_io, d_io);
+  ioB.init(my_slab, lane_io, t_io, d_io);
   for (int it = blockIdx.x; it < nunits; it += nwg) {
     const int tile = tile_of(it);
     const long long b0 = (long long)tile * TPW;

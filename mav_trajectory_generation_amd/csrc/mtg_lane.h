@@ -129,10 +129,24 @@ MTG_HD double mtg_fma(double a, double b, double c) {
 #endif
 }
 
+// a * b.  (Measured and rejected: multiplying through v_fma_f64 with a zero addend -- a lone wave issues independent
+// v_mul_f64 every 5.5 cycles against 4.4 for v_fma_f64 in the microbenchmark, but in the kernels the three-operand
+// encoding costs more than it gains: B = 10k 7.46 -> 7.74 us.  MTG_MUL_AS_FMA re-enables it for A/B runs.)
+MTG_HD double mtg_mul(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MTG_MUL_AS_FMA)
+  return __builtin_fma(a, b, 0.0);
+#else
+  return a * b;
+#endif
+}
+
 // 1/x for the LDL^T pivots and segment times.  v_rcp_f64 seed + Newton steps (no IEEE
 // division sequence); accuracy is checked on the device by mtg_selftest_rcp().
 MTG_HD double mtg_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MTG_RCP_FAKE)   // measurement only: no reciprocal chain at all (wrong results)
+  return x * 0.37;
+#endif
   double r = __builtin_amdgcn_rcp(x);
 #ifndef MTG_RCP_NEWTON
 #define MTG_RCP_NEWTON 2
@@ -266,7 +280,7 @@ MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, int& flags)
 #pragma unroll
     for (int i = j + 1; i < H; ++i) {
       if ((fixed >> i) & 1) continue;
-      l[i] = A[i][j] * r;
+      l[i] = mtg_mul(A[i][j], r);
     }
 #pragma unroll
     for (int i = j + 1; i < H; ++i) {
@@ -309,7 +323,7 @@ MTG_HD void mtg_ldl_solve_multi(const double (&L)[H][H], const double (&dinv)[H]
 #pragma unroll
     for (int c = 0; c < NR; ++c) {
       if ((colskip >> c) & 1) continue;
-      x[i][c] *= dinv[i];
+      x[i][c] = mtg_mul(x[i][c], dinv[i]);
     }
   }
 #pragma unroll
@@ -334,8 +348,8 @@ MTG_HD double mtg_powi(double x, int e) {
   double r = 1.0, p = x;
 #pragma unroll
   for (int bit = 0; (1 << bit) <= EMAX; ++bit) {
-    if ((e >> bit) & 1) r *= p;
-    p *= p;
+    if ((e >> bit) & 1) r = mtg_mul(r, p);
+    p = mtg_mul(p, p);
   }
   return r;
 }
@@ -350,9 +364,9 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
   s[0] = 1.0;
   if constexpr (H > 1) s[1] = ts;
 #pragma unroll
-  for (int p = 2; p < H; ++p) s[p] = s[p / 2] * s[p - p / 2];   // depth log2(p)
+  for (int p = 2; p < H; ++p) s[p] = mtg_mul(s[p / 2], s[p - p / 2]);   // depth log2(p)
 #pragma unroll
-  for (int p = 0; p < H; ++p) bs[p] = base * s[p];
+  for (int p = 0; p < H; ++p) bs[p] = mtg_mul(base, s[p]);
 }
 
 // One forward elimination step (chain step j): completes the left vertex, produces
@@ -374,8 +388,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      val_l[dm][p] = fix_l[dm][p] * s[p];
-      val_r[dm][p] = fix_r[dm][p] * s[p];
+      val_l[dm][p] = mtg_mul(fix_l[dm][p], s[p]);
+      val_r[dm][p] = mtg_mul(fix_r[dm][p], s[p]);
     }
   }
 
@@ -426,7 +440,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
         rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[p][dm], ln.rc[dm][p]);
-        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -bs[p] * accr[p][dm];
+        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : mtg_mul(-bs[p], accr[p][dm]);
       }
     }
   }
@@ -443,8 +457,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         A[p][q] = 0.0;
         U[p][q] = 0.0;
         if (!((ml >> p) & 1)) {
-          if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(bs[p] * s[q], hc[p * N + q], ln.Sc[p][q]);
-          if (!((mr >> q) & 1)) U[p][q] = bs[p] * s[q] * hc[p * N + H + q];
+          if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(mtg_mul(bs[p], s[q]), hc[p * N + q], ln.Sc[p][q]);
+          if (!((mr >> q) & 1)) U[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hc[p * N + H + q]);
         }
       }
     }
@@ -478,7 +492,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       ln.Sc[p][q] = 0.0;
-      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = bs[p] * s[q] * hrr[(H + p) * N + H + q];
+      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
     }
   }
 #pragma unroll
@@ -552,11 +566,11 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     ti[0] = 1.0;
     if constexpr (H > 1) ti[1] = tinv;
 #pragma unroll
-    for (int p = 2; p < H; ++p) ti[p] = ti[p / 2] * ti[p - p / 2];
+    for (int p = 2; p < H; ++p) ti[p] = mtg_mul(ti[p / 2], ti[p - p / 2]);
     double th = tinv;   // tinv^H
-    if constexpr (H > 1) th = ti[H / 2] * ti[H - H / 2];
+    if constexpr (H > 1) th = mtg_mul(ti[H / 2], ti[H - H / 2]);
 #pragma unroll
-    for (int p = 0; p < H; ++p) tp[p] = th * ti[p];
+    for (int p = 0; p < H; ++p) tp[p] = mtg_mul(th, ti[p]);
   }
   double invfact[H];
   {
@@ -580,10 +594,10 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     double clo[H + 1];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      dl[dm][p] = s[p] * xS[dm][p];
-      dl[dm][H + p] = s[p] * xE[dm][p];
-      clo[p] = xS[dm][p] * invfact[p];
-      qs[dm][p] = dl[dm][p] * invfact[p];
+      dl[dm][p] = mtg_mul(s[p], xS[dm][p]);
+      dl[dm][H + p] = mtg_mul(s[p], xE[dm][p]);
+      clo[p] = mtg_mul(xS[dm][p], invfact[p]);
+      qs[dm][p] = mtg_mul(dl[dm][p], invfact[p]);
     }
     // low half of the coefficients: c_p = d_p / p!  (pairs that lie entirely in the low half)
     if constexpr (kStore) {
@@ -618,7 +632,7 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
         qs[dm][H + jj] = acc[jj][dm];
-        const double cj = acc[jj][dm] * tp[jj];
+        const double cj = mtg_mul(acc[jj][dm], tp[jj]);
         // coefficient index H + jj; store in aligned pairs (even index first)
         if constexpr (kStore) {
           if (((H + jj) & 1) != 0) mtg_store2(row + dm * N + H + jj - 1, prev[dm], cj);
