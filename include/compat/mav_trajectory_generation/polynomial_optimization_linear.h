@@ -374,6 +374,16 @@ class PolynomialOptimization {
     return col;
   }
 
+  // One trajectory per call is latency-bound: by default the library runs its host build of the kernels' lane code on
+  // this thread (MTG_FLAG_HOST_BACKEND; ~microseconds) instead of a launch plus a PCIe round trip (~25 us).  Define
+  // MTG_COMPAT_SINGLE_CALLS_ON_DEVICE to send even these calls through the GPU (what the veneer GPU tests do).
+  static uint32_t single_call_backend() {
+#if defined(MTG_COMPAT_SINGLE_CALLS_ON_DEVICE)
+    return 0u;
+#else
+    return (uint32_t)MTG_FLAG_HOST_BACKEND;
+#endif
+  }
   int run(bool solve) {
     CHECK(plan_ != nullptr) << "setupFromVertices() has to be called first";
     const size_t D = dimension_, K = n_segments_, nf = n_fixed_constraints_, np = n_free_constraints_;
@@ -387,10 +397,10 @@ class PolynomialOptimization {
     int rc;
     if (solve) {
       rc = mtg_solve_linear(plan_.get(), 1, &lay, segment_times_.data(), d_fixed.data(), coeffs.data(),
-                            np ? d_free.data() : nullptr, nullptr, MTG_FLAG_HOST_POINTERS);
+                            np ? d_free.data() : nullptr, nullptr, MTG_FLAG_HOST_POINTERS | single_call_backend());
     } else {
       rc = mtg_update_segments_from_free(plan_.get(), 1, &lay, segment_times_.data(), d_fixed.data(), d_free.data(),
-                                         coeffs.data(), nullptr, MTG_FLAG_HOST_POINTERS);
+                                         coeffs.data(), nullptr, MTG_FLAG_HOST_POINTERS | single_call_backend());
     }
     // host-pointer calls are synchronous and return the batch status themselves (on the plan's own context, whichever
     // thread created it)

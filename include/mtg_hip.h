@@ -87,10 +87,17 @@ enum {
                                      /* objective evaluations of the time optimisers          */
                                      /* (polynomial_optimization_nonlinear_impl.h:313-359,    */
                                      /* :569-571) need J = computeCost(), not the segments    */
-  MTG_FLAG_DIMLANE = 1u << 5         /* force the dimension-in-lane launch form where the     */
+  MTG_FLAG_DIMLANE = 1u << 5,        /* force the dimension-in-lane launch form where the     */
                                      /* plan and the call are eligible (SoA inputs, coeffs    */
                                      /* only); default: chosen from the batch size            */
+  MTG_FLAG_HOST_BACKEND = 1u << 6    /* with MTG_FLAG_HOST_POINTERS and batch <=               */
+                                     /* MTG_HOST_BACKEND_MAX_BATCH: solve on the calling      */
+                                     /* thread with the host build of the kernels' lane code  */
+                                     /* (no launch, no PCIe): the single-trajectory calls of  */
+                                     /* the reference's nlopt loops (polynomial_optimization_ */
+                                     /* nonlinear_impl.h:569-571).  Ignored otherwise.        */
 };
+#define MTG_HOST_BACKEND_MAX_BATCH 64
 
 /* ---- context ------------------------------------------------------------------------- */
 /* stream: a hipStream_t (as void*) to enqueue on, or NULL for the library's own stream.   */

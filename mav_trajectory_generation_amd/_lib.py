@@ -82,6 +82,7 @@ FLAG_FUSED_DIMS = 4
 FLAG_SPLIT_DIMS = 8
 FLAG_COST_ONLY = 16
 FLAG_DIMLANE = 32
+FLAG_HOST_BACKEND = 64
 
 _lib = None
 

@@ -263,7 +263,7 @@ class Plan:
         return coeffs, cost
 
     def solve_host(self, times: np.ndarray, d_fixed: np.ndarray, want_free=True, want_cost=True, generic=False,
-                   coeffs: Optional[np.ndarray] = None):
+                   coeffs: Optional[np.ndarray] = None, host_backend: bool = False):
         """Host-buffer convenience (AoS numpy in/out, staged through the device by the library).  Pass page-locked
         arrays (e.g. pinned torch tensors viewed as numpy, also for `coeffs`) to have them DMA'd directly."""
         times = np.ascontiguousarray(times, dtype=np.float64)
@@ -277,6 +277,8 @@ class Plan:
         lay = self.layout(batch, "aos")
         p = lambda a: ctypes.c_void_p(0) if a is None else ctypes.c_void_p(a.ctypes.data)
         flags = L.FLAG_HOST_POINTERS | (L.FLAG_GENERIC_KERNEL if generic else 0)
+        if host_backend:   # batch <= 64: the lane code's host build on this thread (latency path), no GPU involved
+            flags |= L.FLAG_HOST_BACKEND
         rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), p(times), p(d_fixed), p(coeffs),
                                        p(d_free), p(cost), flags)
         _check(self.lib, rc, self.ctx.handle)

@@ -24,6 +24,8 @@
 #include "../../include/mtg_hip.h"
 #include "mtg_kernels.h"
 
+int mtg_host_run(const MtgParams& P, int H, bool update);   // mtg_host.cpp: host build of the lane code
+
 namespace {
 
 __global__ void mtg_rcp_selftest_kernel(int n, double* out, int iters) {
@@ -425,6 +427,21 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   if (p->n_fixed > 0 && !d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_fixed is null");
   if (update_only && p->n_free > 0 && !d_free) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_free is null");
   if (batch == 0) return MTG_OK;
+  if ((flags & MTG_FLAG_HOST_POINTERS) && (flags & MTG_FLAG_HOST_BACKEND) && batch <= MTG_HOST_BACKEND_MAX_BATCH) {
+    // latency path: the lane code's host build on the calling thread (mtg_host.cpp); no device work, no lock
+    MtgParams P;
+    fill_common(p, P, batch, L);
+    P.times = times; P.dfix = d_fixed; P.coeffs = coeffs; P.dfree = p->n_free ? d_free : nullptr; P.cost = cost;
+    int st_word = 0;
+    P.status = &st_word;
+    P.tstatus = traj_status;
+    P.vmask = p->mask.data(); P.offF = p->offF.data(); P.offP = p->offP.data();
+    if (traj_status) std::memset(traj_status, 0, (size_t)batch * sizeof(int32_t));
+    if (mtg_host_run(P, p->H, update_only) != 0) return MTG_ERR_UNSUPPORTED;
+    if (st_word & MTG_FLAG_BAD_TIME) return MTG_ERR_BAD_SEGMENT_TIME;
+    if (st_word & MTG_FLAG_SINGULAR) return MTG_ERR_SINGULAR;
+    return MTG_OK;
+  }
   std::lock_guard<std::mutex> lock(ctx->mu);
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;

@@ -1,0 +1,109 @@
+"""The latency backend (MTG_FLAG_HOST_POINTERS | MTG_FLAG_HOST_BACKEND, csrc/mtg_host.cpp): the kernels' lane code built for
+the host and run on the calling thread for batches of at most 64 trajectories.  It must agree with the GPU path to
+rounding (same algorithm, same constants; only FMA contraction may differ), with the oracle to the north-star tolerance,
+and report the same status codes.  (A context needs a HIP device even for this path: these are GPU-box tests.)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import mav_trajectory_generation_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,d,k,dim,masks,bsz", [
+    (10, 4, 8, 3, None, 64), (10, 4, 2, 3, None, 1), (10, 4, 1, 3, None, 3),       # config 2 shape, README shape, n_free == 0
+    (10, 4, 16, 4, [31] + [7] * 15 + [31], 5),                                      # config 5 shape
+    (10, 4, 6, 3, [31, 1, 3, 1, 5, 9, 31], 7),                                      # ragged masks
+    (10, 4, 3, 2, [3, 1, 1, 7], 4),                                                 # free end-vertex derivatives
+    (12, 5, 7, 4, None, 2), (8, 3, 5, 5, None, 3), (6, 2, 4, 3, None, 2), (2, 0, 3, 2, None, 2),
+    (10, 2, 5, 3, None, 3),                                                         # derivative < N/2 - 1
+])
+def test_host_backend_matches_gpu_path_and_oracle(ctx, n, d, k, dim, masks, bsz):
+    import mav_trajectory_generation_amd as m
+    masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 9001 + k, masks)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    co_h, fr_h, j_h = plan.solve_host(times, d_fixed, host_backend=True)
+    co_g, fr_g, j_g = plan.solve_host(times, d_fixed, generic=True)            # same generic lane code on the device
+    assert helpers.poly_relerr(co_h, co_g) < 1e-12
+    assert np.allclose(j_h, j_g, rtol=1e-11)
+    if fr_g.size:
+        assert np.abs(fr_h - fr_g).max() <= 1e-11 * max(1.0, np.abs(fr_g).max())
+    c_lit, f_lit, j_lit = onp.solve_batch(n, d, masks, times, d_fixed)
+    tol = 1e-9 if (n <= 10 and d == n // 2 - 1) else 1e-5
+    assert helpers.poly_relerr(co_h, c_lit) < tol
+    assert helpers.check_path(masks, times, d_fixed, co_h) < 1e-6
+    plan.close()
+
+
+def test_host_backend_update_path_and_status(ctx):
+    import mav_trajectory_generation_amd as m
+    from mav_trajectory_generation_amd import _lib as L
+    masks, times, d_fixed = helpers.reference_batch(6, 8, 10, 3, 77)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    co, fr, cost = plan.solve_host(times, d_fixed, host_backend=True)
+    # setFreeConstraints path (LIN:500-508) with the optimum reproduces the solve
+    co2 = np.empty_like(co)
+    cost2 = np.empty(6)
+    lay = plan.layout(6, "aos")
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    rc = plan.lib.mtg_update_segments_from_free(plan.handle, 6, ctypes.byref(lay), p(times), p(d_fixed), p(fr), p(co2),
+                                                p(cost2), L.FLAG_HOST_POINTERS | L.FLAG_HOST_BACKEND)
+    assert rc == 0
+    assert helpers.poly_relerr(co2, co) < 1e-13 and np.allclose(cost2, cost, rtol=1e-12)
+    # status: returned by the call itself, per trajectory through mtg_solve_linear_status
+    bad = times.copy()
+    bad[4, 2] = 0.0
+    st = np.full(6, 99, dtype=np.int32)
+    rc = plan.lib.mtg_solve_linear_status(plan.handle, 6, ctypes.byref(lay), p(bad), p(d_fixed), p(co2), None, None, p(st),
+                                          L.FLAG_HOST_POINTERS | L.FLAG_HOST_BACKEND)
+    assert rc == -2
+    assert list(st & 1) == [0, 0, 0, 0, 1, 0]
+    ctx.sync()      # nothing pending on the device
+    # larger than the limit: the same flags go through the GPU
+    masks2, t2, f2 = helpers.reference_batch(65, 8, 10, 3, 78)
+    a, _, _ = plan.solve_host(t2, f2, host_backend=True)
+    b, _, _ = plan.solve_host(t2, f2)
+    assert np.array_equal(a, b)
+    plan.close()
+
+
+def test_host_backend_single_call_latency(ctx):
+    """The point of the backend: a 2-segment single-trajectory solve in microseconds, not a launch + PCIe round trip."""
+    import time
+    import mav_trajectory_generation_amd as m
+    from mav_trajectory_generation_amd import _lib as L
+    masks, times, d_fixed = helpers.reference_batch(1, 2, 10, 3, 5)
+    plan = m.Plan(ctx, 10, 3, 2, 4, masks)
+    co = np.empty((1, 2, 3, 10))
+    fr = np.empty((1, 3, plan.n_free))
+    lay = plan.layout(1, "aos")
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    args_h = (plan.handle, 1, ctypes.byref(lay), p(times), p(d_fixed), p(co), p(fr), None, L.FLAG_HOST_POINTERS | L.FLAG_HOST_BACKEND)
+    args_d = (plan.handle, 1, ctypes.byref(lay), p(times), p(d_fixed), p(co), p(fr), None, L.FLAG_HOST_POINTERS)
+    for args in (args_h, args_d):
+        for _ in range(200):
+            assert plan.lib.mtg_solve_linear(*args) == 0
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        plan.lib.mtg_solve_linear(*args_h)
+    us_h = (time.perf_counter() - t0) / 2000 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(500):
+        plan.lib.mtg_solve_linear(*args_d)
+    us_d = (time.perf_counter() - t0) / 500 * 1e6
+    print(f"single K=2 solve: host backend {us_h:.2f} us, device round trip {us_d:.2f} us (both incl. ctypes call overhead)")
+    assert us_h < 10.0 and us_h < us_d
+    plan.close()
