@@ -169,6 +169,22 @@ int mtg_update_segments_from_free(mtg_plan* plan, int64_t batch, const mtg_layou
                                   const double* d_free, double* coeffs, double* cost,
                                   uint32_t flags);
 
+/* ---- the time optimisers' cost / gradient step ------------------------------------------------
+ * Replaces, for a batch, PolynomialOptimizationNonLinear<N>::getCostAndGradientMellinger
+ * (impl/polynomial_optimization_nonlinear_impl.h:287-364): per trajectory the reference runs K + 1 updateSegmentTimes +
+ * solveLinear + computeCost -- the current times, and for each segment n the times with T_n += h and every other
+ * T_i -= h / (K - 1) (h = increment_time, 0.1 in the reference), clamped from below to time_lower_bound
+ * (kOptimizationTimeLowerBound = 0.1, polynomial_optimization_nonlinear.h:31) -- and returns J_d and the forward
+ * differences (J_n - J_d) / h.  Here all (K + 1) * batch solves are ONE cost-only launch; the perturbed times are formed
+ * in the kernel from `times` (nothing is materialised), a second small kernel forms the differences.
+ *   cost     out optional [batch]: J_d
+ *   gradient out [batch][K] with the strides of `times` in `layout` (gradient[b*times_stride_b + n*times_stride_k])
+ * K == 1: zero gradient (impl:295-302).  Device pointers; asynchronous on the context's stream; flags raised by any of
+ * the virtual problems surface at mtg_context_sync.                                                            */
+int mtg_mellinger_cost_gradient(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
+                                const double* d_fixed, double increment_time, double time_lower_bound, double* cost,
+                                double* gradient);
+
 /* ---- next step after the path: batched sampling ---------------------------------------- */
 /* Replaces, for a batch, Trajectory::evaluateRange (src/trajectory.cpp:81-141) / Polynomial::evaluate
  * (polynomial.h:137-149) as used by sampleTrajectoryInRange (src/trajectory_sampling.cpp:45-110):

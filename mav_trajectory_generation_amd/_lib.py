@@ -51,6 +51,8 @@ EXPORTS = {
                                                c_double_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_solve_linear_sequence": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "mtg_mellinger_cost_gradient": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
+                                                   c_double_p, ctypes.c_double, ctypes.c_double, c_double_p, c_double_p]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_device_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),

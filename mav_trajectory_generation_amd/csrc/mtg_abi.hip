@@ -133,6 +133,8 @@ struct mtg_plan {
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
   double* ws = nullptr;
   size_t ws_bytes = 0;
+  double* pert_cost = nullptr;      // [(K + 1)][batch] costs of mtg_mellinger_cost_gradient's virtual problems
+  size_t pert_cost_bytes = 0;
   double* user_ws = nullptr;       // caller-owned workspace (mtg_plan_set_workspace)
   size_t user_ws_bytes = 0;
   // staging for MTG_FLAG_HOST_POINTERS
@@ -366,6 +368,7 @@ int mtg_plan_destroy(mtg_plan* p) {
   hipStreamSynchronize(p->ctx->stream);
   if (p->d_tables) hipFree(p->d_tables);
   if (p->ws) hipFree(p->ws);
+  if (p->pert_cost) hipFree(p->pert_cost);
   if (p->stage) hipFree(p->stage);
   delete p;
   return MTG_OK;
@@ -415,9 +418,11 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   return units <= (int64_t)p->ctx->dl_max_units_per_cu * p->ctx->n_cu ? dl : nullptr;
 }
 
+struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradient: (K + 1) virtual problems per trajectory
+
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only,
-                      int32_t* traj_status = nullptr) {
+                      int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr) {
   const bool cost_only = !update_only && (flags & MTG_FLAG_COST_ONLY) != 0;
   if (!p || !L || !times || (!coeffs && !cost_only) || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
   if (cost_only && (!cost || (flags & MTG_FLAG_HOST_POINTERS))) return MTG_ERR_INVALID_ARGUMENT;
@@ -493,7 +498,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     dfr = (d_free && n_fre) ? s_p : nullptr;
     dcs = cost ? s_j : nullptr;
   }
-  if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, batch * sizeof(double), st));
+  if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, (pert ? (size_t)(p->K + 1) : (size_t)1) * batch * sizeof(double), st));
   if (dts) MTG_HIP_TRY(ctx, hipMemsetAsync(dts, 0, batch * sizeof(int32_t), st));
 
   MtgParams P;
@@ -501,7 +506,12 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   P.times = dt; P.dfix = dfx; P.coeffs = dco; P.dfree = (p->n_free ? dfr : nullptr); P.cost = dcs;
   P.tstatus = dts;
   const bool wc = dcs != nullptr || (!update_only && P.dfree != nullptr);
-  const int ntiles = (int)((batch + kWave - 1) / kWave);
+  int ntiles = (int)((batch + kWave - 1) / kWave);
+  if (pert) {   // cost-only launch over (K + 1) x batch virtual problems; cost = [(K + 1)][batch]
+    P.pert_on = 1; P.pert_seg = -1; P.pert_tpv = ntiles;
+    P.pert_h = pert->h; P.pert_corr = pert->h / (p->K - 1.0); P.pert_lo = pert->lower_bound;
+    ntiles *= p->K + 1;
+  }
   p->last.clear();
 
   if (update_only) {
@@ -669,6 +679,60 @@ int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mt
                               flags, false);
     if (rc != MTG_OK) return rc;
   }
+  return MTG_OK;
+}
+
+namespace {
+// J[b] = cost of the unperturbed problem; gradient[b][n] = (cost of variant n + 1 - J[b]) / h, written with the times' strides
+__global__ void mtg_mellinger_grad_kernel(const double* __restrict__ cost_all, long long B, int K, double inv_h,
+                                          double* __restrict__ J, double* __restrict__ grad, long long gs_b, long long gs_k) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (cost_all == nullptr) {   // one segment: zero gradient
+    for (int n = 0; n < K; ++n) grad[b * gs_b + n * gs_k] = 0.0;
+    return;
+  }
+  const double j0 = cost_all[b];
+  if (J) J[b] = j0;
+  for (int n = 0; n < K; ++n) grad[b * gs_b + n * gs_k] = (cost_all[(long long)(n + 1) * B + b] - j0) * inv_h;
+}
+}  // namespace
+
+int mtg_mellinger_cost_gradient(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
+                                const double* d_fixed, double increment_time, double time_lower_bound, double* cost,
+                                double* gradient) {
+  if (!plan || !layout || !times || !gradient || batch < 0 || !(increment_time > 0.0)) return MTG_ERR_INVALID_ARGUMENT;
+  if (batch == 0) return MTG_OK;
+  mtg_context* ctx = plan->ctx;
+  const int K = plan->K;
+  if (K == 1) {   // polynomial_optimization_nonlinear_impl.h:295-302: one segment -> zero gradient
+    int rc = MTG_OK;
+    if (cost) rc = solve_impl(plan, batch, layout, times, d_fixed, nullptr, nullptr, cost, MTG_FLAG_COST_ONLY, false);
+    if (rc != MTG_OK) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(mtg_mellinger_grad_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)nullptr, (long long)batch, 1, 0.0, (double*)nullptr, gradient,
+                       (long long)layout->times_stride_b, (long long)layout->times_stride_k);
+    MTG_HIP_TRY(ctx, hipGetLastError());
+    return MTG_OK;
+  }
+  double* all = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = ensure_buffer(ctx, &plan->pert_cost, &plan->pert_cost_bytes, (size_t)(K + 1) * batch * sizeof(double));
+    if (rc != MTG_OK) return rc;
+    all = plan->pert_cost;
+  }
+  const PerturbedTimes pt{increment_time, time_lower_bound};
+  const int rc = solve_impl(plan, batch, layout, times, d_fixed, nullptr, nullptr, all, MTG_FLAG_COST_ONLY, false, nullptr, &pt);
+  if (rc != MTG_OK) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  hipLaunchKernelGGL(mtg_mellinger_grad_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const double*)all, (long long)batch, K, 1.0 / increment_time, cost, gradient,
+                     (long long)layout->times_stride_b, (long long)layout->times_stride_k);
+  MTG_HIP_TRY(ctx, hipGetLastError());
   return MTG_OK;
 }
 

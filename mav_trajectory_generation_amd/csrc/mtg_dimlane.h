@@ -264,6 +264,7 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
   P.vmask = nullptr; P.offF = nullptr; P.offP = nullptr;
   P.B = B; P.K = C::KT; P.Dtot = DL; P.dim0 = d;   // dim0 is a per-lane value here
   P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
+  P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
 
   const int nunits = (ntiles + NP - 1) / NP;
   MtgLane<C> ln;

@@ -4,7 +4,7 @@
 SolveFn mtg_pick_generic_solve_h4(int d, int mode) {
 #define MTG_CASE(DD)                                                                                   \
   case DD:                                                                                             \
-    return mode == 2 ? (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 9>                                 \
+    return mode == 2 ? (SolveFn)mtg_solve_kernel<GenericCostCfg<4, DD>, 9>                                 \
                      : (mode == 1 ? (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 3>                    \
                                   : (SolveFn)mtg_solve_kernel<GenericCfg<4, DD>, 0>);
   switch (d) { MTG_CASE(1) MTG_CASE(2) MTG_CASE(3) MTG_CASE(4) }

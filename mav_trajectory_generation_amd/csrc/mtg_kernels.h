@@ -136,11 +136,24 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   // workspace slabs): at small batch every wave solves exactly one tile and the input round trip heads its serial
   // latency chain, so nothing may sit in front of the loads.
   MtgLane<C> ln;
+  // Perturbed-time launches (mtg_mellinger_cost_gradient): tile -> (variant n, tile of the real batch); the variant's
+  // perturbed segment and cost row are set in the tile's own copy of the parameters.  Everything else: identity.
+  auto view = [&](int tile_, MtgParams& Pt) -> int {
+    Pt = P;
+    if constexpr (!C::kPert) return tile_;
+    if (!P.pert_on) return tile_;
+    const int n = tile_ / P.pert_tpv;
+    Pt.pert_seg = n - 1;
+    if (P.cost != nullptr) Pt.cost = P.cost + (long long)n * P.B;
+    return tile_ - n * P.pert_tpv;
+  };
   auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
-    long long bb = (long long)tile_ * kWave + lane;
+    MtgParams Pt;
+    const int tr = view(tile_, Pt);
+    long long bb = (long long)tr * kWave + lane;
     if (bb >= P.B) bb = P.B - 1;
-    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
-    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
+    if (dir == 0) mtg_preload_into<C, 1>(Pt, bb, T_, fx_);
+    else mtg_preload_into<C, -1>(Pt, bb, T_, fx_);
   };
   if (C::kStatic && (int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
   const int K = mtg_nseg<C>(P);
@@ -173,21 +186,23 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   constexpr bool kPrefetch = C::kStatic && mtg_waves_per_simd<C>() == 1;
   double nT[C::KCS], nfx[C::D][C::NC];
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    io.b0 = (long long)tile * kWave;
+    MtgParams Pt;
+    const int tile_r = view(tile, Pt);
+    io.b0 = (long long)tile_r * kWave;
     const long long bl = io.b0 + lane;
     const bool active = bl < P.B;
     const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
     const bool has_next = kPrefetch && tile + (int)gridDim.x < ntiles;
     if (has_next) fetch(tile + gridDim.x, nT, nfx);
     const bool need_preload = !kPrefetch && !(C::kStatic && tile == (int)blockIdx.x);   // first tile: fetched at the top
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, need_preload);
-    else mtg_lane_forward<C, -1>(P, b, ln, wsl, need_preload);
+    if (dir == 0) mtg_lane_forward<C, 1>(Pt, b, ln, wsl, need_preload);
+    else mtg_lane_forward<C, -1>(Pt, b, ln, wsl, need_preload);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
     MTG_TSTAMP(1);
     __syncthreads();
     MTG_TSTAMP(2);
-    if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, io, active);
-    else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+    if (dir == 0) mtg_lane_finish<C, 1, OUT>(Pt, b, ln, wsl, other, kWave, io, active);
+    else mtg_lane_finish<C, -1, OUT>(Pt, b, ln, wsl, other, kWave, io, active);
     MTG_TSTAMP(3);
 #if defined(MTG_TIMING)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -274,6 +289,7 @@ using SolveFn = void (*)(MtgParams, int);
 using UpdateFn = void (*)(MtgParams, int);
 using SolveMultiFn = void (*)(const MtgParams*, const MtgTileRef*, int);
 template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
+template <int H, int D> using GenericCostCfg = MtgCfg<H, D, 0, 0, 0, 0, 0, 1>;   // cost-only launches: perturbed-time capable
 
 // per-TU pickers (mtg_generic_hN.hip, mtg_static.hip)
 SolveFn mtg_pick_generic_solve(int h, int d, int out_mode);   // out_mode: 0 plain, 1 extra outputs (OUT 3), 2 cost only (OUT 9)

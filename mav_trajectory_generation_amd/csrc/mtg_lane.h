@@ -49,7 +49,19 @@ struct MtgParams {
   const int* offP;                                  // [K+2] prefix of free slots
   long long B;
   int K, Dtot, dim0, deriv, h1off, ainvoff;
+  // Virtual batch of perturbed-time problems (mtg_mellinger_cost_gradient): variant n of trajectory b uses the times of b
+  // with T_(n-1) += pert_h and every other T_k -= pert_corr, clamped from below (variant 0: unperturbed).  The kernels map
+  // tile -> (variant, tile of the real batch); pert_seg is that tile's perturbed segment (-1: none).
+  int pert_on, pert_seg, pert_tpv;   // pert_tpv: tiles per variant
+  double pert_h, pert_corr, pert_lo;
 };
+
+// segment time as the virtual problem sees it (identity unless a perturbed-time launch)
+MTG_HD double mtg_perturb(const MtgParams& P, int seg, double T) {
+  if (!P.pert_on || P.pert_seg < 0) return T;
+  T += seg == P.pert_seg ? P.pert_h : -P.pert_corr;
+  return T < P.pert_lo ? P.pert_lo : T;
+}
 
 // offsets into the generated tables (same formulas as gen_tables.py)
 constexpr int mtg_h1_offset(int n, int d) {
@@ -63,8 +75,11 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
-template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0>
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0>
 struct MtgCfg {
+  // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
+  // instantiations carry that code
+  static constexpr bool kPert = PT_ != 0;
   static constexpr int H = H_, N = 2 * H_, D = D_, KT = KT_;
   // KT_ > 0: "static"  -- compile-time K, masks, derivative; chain loops unrolled, back-substitution data in registers
   // KT_ < 0: "rolled"  -- compile-time masks and derivative, run-time K >= 2 (uniform interior mask MI); the chain
@@ -226,6 +241,7 @@ MTG_HD void mtg_preload_into(const MtgParams& P, long long b, double (&T)[C::KCS
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
       T[j] = *pt;
+      if constexpr (C::kPert) T[j] = mtg_perturb(P, mtg_seg<DIR>(C::KT, j), T[j]);
       pt += tstep;
     }
     const double* pd = P.dfix + b * P.fs_b + (long long)P.dim0 * P.fs_d + (long long)c0 * P.fs_c;
@@ -521,7 +537,11 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 template <class C, int DIR>
 MTG_HD double mtg_step_time(const MtgParams& P, long long b, int j, const MtgLane<C>& ln) {
   if constexpr (C::kStatic) return ln.T[j];
-  else return P.times[b * P.ts_b + (long long)mtg_seg<DIR>(mtg_nseg<C>(P), j) * P.ts_k];
+  else {
+    const double T = P.times[b * P.ts_b + (long long)mtg_seg<DIR>(mtg_nseg<C>(P), j) * P.ts_k];
+    if constexpr (C::kPert) return mtg_perturb(P, mtg_seg<DIR>(mtg_nseg<C>(P), j), T);
+    else return T;
+  }
 }
 
 template <class C, int DIR>

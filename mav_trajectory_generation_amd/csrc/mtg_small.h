@@ -43,6 +43,7 @@ __global__ __launch_bounds__(kSmallBlock, MTG_SMALL_OCC) void mtg_solve_small_ke
   P.vmask = nullptr; P.offF = nullptr; P.offP = nullptr;
   P.B = B; P.K = C::KT; P.Dtot = (int)gridDim.y * C::D; P.dim0 = (int)blockIdx.y * C::D;
   P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
+  P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
 
   const int nunits = (ntiles + 1) >> 1;
   MtgLane<C> ln;

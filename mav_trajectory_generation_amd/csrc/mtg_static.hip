@@ -9,7 +9,7 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 3>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 4>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>,          \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 9>},         \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV, 1>, 9>},         \
    {nullptr, nullptr},                                                      \
    {nullptr, nullptr, nullptr, nullptr}},
 #define MTG_ROLLED(H, D, MS, MI, ME, DV)                                    \
@@ -18,7 +18,7 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 4>,         \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 7>,         \
-    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 9>},        \
+    (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV, 1>, 9>},        \
    {(UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,       \
     (UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1>},      \
    {(SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>, \

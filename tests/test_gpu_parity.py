@@ -251,7 +251,7 @@ def test_bench_contract_single_gpu():
 def test_bench_multi_process_path_on_one_gpu():
     """The N > 1 code path of bench.py (one process per rank, barrier + max-reduce of the timing) with two ranks
     sharing the only GPU of this box; gloo carries the two tiny collectives here, RCCL on a real multi-GPU node."""
-    d = _run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0"], nproc=2)
+    d = _run_bench(["--gpus", "2", "--backend", "gloo", "--same-device"], nproc=2)
     assert d["n_gpus"] == 2 and d["value"] > 1e8
 
 
@@ -502,3 +502,50 @@ def test_batched_sampling_vs_oracle(ctx):
         assert np.array_equal(nv.cpu().numpy(), want_nv)
         assert torch.equal(out, out_soa)
         plan.close()
+
+
+@pytest.mark.parametrize("n,d,k,dim,masks,bsz,layout", [
+    (10, 4, 8, 3, None, 70, "soa"),                              # static kernel, batch not a multiple of the tile
+    (10, 4, 16, 3, None, 9, "aos"),                              # rolled kernel (run-time K)
+    (10, 4, 6, 3, [31, 1, 3, 1, 5, 9, 31], 5, "aos"),            # ragged masks: generic kernel
+    (10, 4, 16, 4, [31] + [7] * 15 + [31], 6, "soa"),            # config 5 shape
+    (8, 3, 4, 3, None, 130, "aos"),
+    (10, 4, 1, 3, None, 4, "aos"),                               # one segment: zero gradient (impl:295-302)
+])
+def test_mellinger_cost_gradient_entry(ctx, n, d, k, dim, masks, bsz, layout):
+    """mtg_mellinger_cost_gradient (C ABI; perturbed times formed inside the kernel) against a literal restatement of
+    getCostAndGradientMellinger (polynomial_optimization_nonlinear_impl.h:287-364) on the oracle, incl. the lower clamp."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 424242, masks)
+    times[0, 0] = 0.12            # T - h/(K-1) falls below the bound 0.1 -> clamped (impl:338-340)
+    if k > 1:
+        times[1 % bsz, k - 1] = 0.05   # already below the bound: every variant clamps it
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
+    if layout == "soa":
+        t, f = t.t().contiguous(), f.permute(1, 2, 0).contiguous()
+    j0, grad = m.mellinger_cost_and_gradient(plan, t, f, layout=layout)
+    ctx.sync()
+    got = grad.cpu().numpy() if layout == "aos" else grad.t().cpu().numpy()
+    nchk = min(bsz, 6)
+    want = np.zeros((nchk, k))
+    jd = np.zeros(nchk)
+    for b in range(nchk):
+        def cost_of(tt):
+            _, _, j = onp.solve_batch(n, d, masks, tt[None], d_fixed[b][None])
+            return j[0]
+        jd[b] = cost_of(times[b])
+        if k == 1:
+            continue
+        for s in range(k):
+            tb = times[b].copy()
+            for i in range(k):
+                tb[i] += 0.1 if i == s else -0.1 / (k - 1.0)
+            want[b, s] = (cost_of(np.maximum(0.1, tb)) - jd[b]) / 0.1
+    assert np.allclose(j0.cpu().numpy()[:nchk], jd, rtol=1e-8)
+    scale = max(np.abs(want).max(), 1e-300)
+    assert np.abs(got[:nchk] - want).max() <= 1e-6 * scale
+    if k == 1:
+        assert np.all(got == 0.0)
+    plan.close()
