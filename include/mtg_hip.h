@@ -261,6 +261,28 @@ int mtg_multi_solve(mtg_multi* multi);              /* asynchronous on the conte
 int mtg_multi_launch_count(const mtg_multi* multi); /* kernel launches one mtg_multi_solve enqueues */
 int mtg_multi_destroy(mtg_multi* multi);
 
+/* ---- several GPUs from one host process -----------------------------------------------------
+ * The path shards by independent trajectories (LIN:339-379 touches only one optimiser's state): shard s of G is the
+ * contiguous range mtg_shard_range(batch, G, s), solved on device s by that device's own context / plan / stream, with
+ * no communication during the solve.  A device group = one context + one plan of the same description per device.
+ * mtg_device_group_solve_linear fans one call out (asynchronous: the shards run concurrently); the caller holds the
+ * per-device buffers (times[s], d_fixed[s], coeffs[s]: device pointers on device s, shard-local SoA (soa != 0) or AoS).
+ * mtg_device_group_gather_coeffs is the optional final gather into one [batch][K][D][N] buffer: host memory (root < 0)
+ * or memory of device `root` (peer copies over xGMI).  `devices` = NULL: devices 0 .. n-1.  The multi-process form
+ * (one rank per GPU, RCCL all_gather over xGMI) is mav_trajectory_generation_amd/dist.py; both split the batch alike. */
+typedef struct mtg_device_group mtg_device_group;
+void mtg_shard_range(int64_t batch, int32_t n_shards, int32_t shard, int64_t* lo, int64_t* hi);
+int mtg_device_group_create(int32_t n_devices, const int32_t* devices, const mtg_plan_desc* desc, mtg_device_group** out);
+int mtg_device_group_destroy(mtg_device_group* group);
+int mtg_device_group_size(const mtg_device_group* group);
+mtg_context* mtg_device_group_context(mtg_device_group* group, int32_t shard);
+mtg_plan* mtg_device_group_plan(mtg_device_group* group, int32_t shard);
+int mtg_device_group_solve_linear(mtg_device_group* group, int64_t batch, int32_t soa, const double* const* times,
+                                  const double* const* d_fixed, double* const* coeffs, uint32_t flags);
+int mtg_device_group_sync(mtg_device_group* group);
+int mtg_device_group_gather_coeffs(mtg_device_group* group, int64_t batch, const double* const* coeffs, int32_t root,
+                                   double* dst);
+
 /* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
 /* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the
  * context's stream, bracketed by hipEvents recorded on that same stream; returns the mean

@@ -53,6 +53,15 @@ EXPORTS = {
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_mellinger_cost_gradient": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                    c_double_p, ctypes.c_double, ctypes.c_double, c_double_p, c_double_p]),
+    "mtg_shard_range": (None, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "mtg_device_group_create": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_device_group_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_device_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_device_group_context": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int32]),
+    "mtg_device_group_plan": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int32]),
+    "mtg_device_group_solve_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "mtg_device_group_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_device_group_gather_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "mtg_update_segments_from_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                      c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_device_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
