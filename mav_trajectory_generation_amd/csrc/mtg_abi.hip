@@ -105,7 +105,8 @@ struct mtg_context {
   int knob_force_dg = 0;        // MTG_FORCE_DG: dimension-group size of the specialised kernels
   bool knob_prefer_rolled = false;   // MTG_PREFER_ROLLED: rolled variant even where a static one exists
   bool knob_no_dimlane = false;      // MTG_NO_DIMLANE: never pick the dimension-in-lane form
-  int dl_max_units_per_cu = 4;       // MTG_DL_MAX_UNITS: dimension-in-lane form while workgroups <= this x CUs
+  int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
+  int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
   std::string last_error;
   std::mutex mu;
@@ -238,6 +239,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_prefer_rolled = getenv("MTG_PREFER_ROLLED") != nullptr;
   ctx->knob_no_dimlane = getenv("MTG_NO_DIMLANE") != nullptr;
   if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
+  if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
   *out = ctx;
   return MTG_OK;
@@ -415,7 +417,10 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
   if (flags & MTG_FLAG_DIMLANE) return dl;
   const int64_t units = ((batch + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
-  return units <= (int64_t)p->ctx->dl_max_units_per_cu * p->ctx->n_cu ? dl : nullptr;
+  const int64_t cus = p->ctx->n_cu;
+  const int hi = p->ctx->dl_max_units_per_cu >= 0 ? p->ctx->dl_max_units_per_cu : dl->hi_per_cu;
+  if (units < (int64_t)dl->lo_per_cu * cus) return nullptr;
+  return (hi == 0 || units <= (int64_t)hi * cus) ? dl : nullptr;
 }
 
 struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradient: (K + 1) virtual problems per trajectory
@@ -593,7 +598,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         grid = std::min(ntiles, ctx->n_cu * 4);
       }
       if (needs_ws) {
-        if (var) grid = std::min(ntiles, std::max(1, ctx->n_cu * 4 / ngroups));
+        if (var) grid = std::min(ntiles, std::max(1, ctx->n_cu * ctx->rolled_wg_per_cu / ngroups));
         const int kc = (p->K + 1) / 2;
         const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
         const size_t need = (size_t)kc * E * (size_t)grid * ngroups * kBlock * sizeof(double);

@@ -40,7 +40,6 @@ struct MtgSlabOut {
   static constexpr int TPW = kWave / DL;
   static constexpr int PIECE = K * S;                // one trajectory's coefficients
   static constexpr int HALF_LO = DIR > 0 ? 0 : KA * S, HALF_HI = DIR > 0 ? KA * S : K * S;
-  static constexpr int ROWB = (((HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   char* slab;
@@ -77,7 +76,8 @@ struct MtgSlabOut {
   }
   // where this lane puts the N coefficients of its dimension of segment `seg`
   __device__ __forceinline__ double* row(int seg) {
-    return reinterpret_cast<double*>(slab + t * ROWB + (seg * S - HALF_LO) + d * (N * 8));
+    const int off = kRing ? (seg & 1) * S : seg * S - HALF_LO;
+    return reinterpret_cast<double*>(slab + t * ROWB + off + d * (N * 8));
   }
   // Chunk -> (trajectory, offset) mapping of a drained range.  A lone wave pays ~4 cycles for EVERY instruction, so the
   // index arithmetic matters: where the largest range has at most 16 chunks (256 bytes; BASELINE config 2: 192 / 256),
@@ -105,6 +105,13 @@ struct MtgSlabOut {
   }
   static constexpr int MAXCH = max_range_chunks();
   static constexpr int CHP = MAXCH <= 4 ? 4 : (MAXCH <= 8 ? 8 : (MAXCH <= 16 ? 16 : 0));   // 0: generic mapping
+  // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
+  // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
+  // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
+  // whatever the chain length.  Generic mapping: the direction's whole half.
+  static constexpr bool kRing = CHP != 0;
+  static_assert(!kRing || S >= 64, "ring slab: a range reaches into at most one neighbouring segment");
+  static constexpr int ROWB = (((kRing ? 2 * S : HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
   static constexpr int RPI = CHP ? kWave / CHP : 0;                                        // trajectories per store instruction
   static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
   u4 pv[MAXI];          // chunks of the previously committed range, read from the slab, not yet stored
@@ -137,6 +144,11 @@ struct MtgSlabOut {
       const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
       if constexpr (CHP != 0) {
         const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
+        // ring: the chunks of the range that belong to the neighbouring (earlier recovered) segment sit in the other slot
+        const int nb = DIR > 0 ? seg + 1 : seg - 1;                       // that neighbour
+        const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
+        const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
+        const unsigned sel = (DIR > 0 ? (rr < (unsigned)cut) : (rr >= (unsigned)(cut > 0 ? cut : 0))) ? in_cur : in_nb;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
           const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
@@ -148,7 +160,7 @@ struct MtgSlabOut {
             g = ok ? g : 0x7ffffff0u;
           }
           pg[i] = g;
-          pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + ll + (unsigned)(i * RPI * ROWB + (lo - HALF_LO))));
+          pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + (unsigned)(ll + sel + (unsigned)(i * RPI * ROWB))));   // 32-bit sum first: sel may be a wrapped negative
           pn = i + 1;
         }
       } else {
@@ -183,11 +195,10 @@ struct MtgSlabOut {
 };
 
 template <class C, int DL>
-__host__ __device__ constexpr size_t mtg_dl_slab_bytes() {   // one wave's slab (the larger half)
-  constexpr int S = DL * C::N * 8;
-  constexpr int ha = C::KA * S, hb = (C::KT - C::KA) * S;
-  constexpr int h = ha > hb ? ha : hb;
-  return (size_t)(kWave / DL) * ((h / 16) | 1) * 16;
+__host__ __device__ constexpr size_t mtg_dl_slab_bytes() {   // one wave's slab (the larger of the two directions')
+  constexpr size_t a = (size_t)MtgSlabOut<C, DL, 1, 0>::TPW * MtgSlabOut<C, DL, 1, 0>::ROWB;
+  constexpr size_t b = (size_t)MtgSlabOut<C, DL, -1, 0>::TPW * MtgSlabOut<C, DL, -1, 0>::ROWB;
+  return a > b ? a : b;
 }
 template <class C, int DL>
 __host__ __device__ constexpr size_t mtg_dl_pair_bytes() {

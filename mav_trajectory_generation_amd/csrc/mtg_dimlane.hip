@@ -24,8 +24,8 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
 }
 }  // namespace
 
-#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP) \
-  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>(), launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>},
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>(), launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>},
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include "mtg_dimlane_variants.inc"
 };

@@ -307,6 +307,7 @@ const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int*
 struct MtgDimlaneEntry {
   int h, k, ms, mi, me, dv, dl, np;
   int tpw;            // trajectories per wave (64 / dl)
+  int lo_per_cu, hi_per_cu;   // default form while lo * CUs <= workgroups <= hi * CUs (hi = 0: no upper limit)
   size_t lds;         // dynamic LDS per workgroup
   // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
   // cache policy (0 nt sc1, 1 sc1, 2 write-back); returns 0 or -1 (attribute / launch set-up failed)
