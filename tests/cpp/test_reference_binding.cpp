@@ -34,6 +34,10 @@
 
 using namespace mav_trajectory_generation;
 
+// MTG_FLAG_HOST_BACKEND (the library's host build of the lane code; what INTEGRATION.md section 1 uses for a single
+// trajectory) or 0 ("device" argument: the same call through the GPU)
+static uint32_t kSingleCallBackend = MTG_FLAG_HOST_BACKEND;
+
 // ---- INTEGRATION.md section 1, verbatim except `opt.` in front of the members ------------------------------------
 template <int N>
 bool solveLinearViaMtgHip(PolynomialOptimization<N>& opt) {
@@ -55,9 +59,8 @@ bool solveLinearViaMtgHip(PolynomialOptimization<N>& opt) {
   mtg_layout lay;
   mtg_layout_aos(plan, 1, &lay);
   const int rc = mtg_solve_linear(plan, 1, &lay, opt.segment_times_.data(), d_fixed.data(), coeffs.data(),
-                                  d_free.data(), nullptr, MTG_FLAG_HOST_POINTERS);
-  CHECK_EQ(rc, MTG_OK) << mtg_last_error_string(ctx);
-  CHECK_EQ(mtg_context_sync(ctx), MTG_OK) << mtg_last_error_string(ctx);   // LIN:297 etc. surface here
+                                  d_free.data(), nullptr, MTG_FLAG_HOST_POINTERS | kSingleCallBackend);
+  CHECK_EQ(rc, MTG_OK) << mtg_status_string(rc);   // host-pointer calls are synchronous: LIN:297 etc. surface here
 
   for (size_t d = 0; d < opt.dimension_; ++d) {
     opt.free_constraints_compact_[d] =
@@ -123,7 +126,8 @@ void run_case(const char* name, const Vertex::Vector& vertices, const std::vecto
   if (!ok) ++g_fail;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "device") kSingleCallBackend = 0;
   // README example (README.md:104-140)
   {
     Vertex::Vector vertices;

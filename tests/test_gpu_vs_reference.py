@@ -171,13 +171,15 @@ def test_extrema_and_time_scaling_vs_reference(ctx):
     assert n_scaled > 0
 
 
-def test_integration_binding_on_the_reference_class():
+@pytest.mark.parametrize("mode", ["host_backend", "device"])
+def test_integration_binding_on_the_reference_class(mode):
     """tests/cpp/test_reference_binding: the reference's own PolynomialOptimization<N> object (reference sources
     compiled where they lie) solved by its own solveLinear() and by the replacement body of INTEGRATION.md section 1
-    forwarding to libmtg_hip.so -- segments, free constraints, computeCost() and Trajectory::evaluate must agree."""
+    forwarding to libmtg_hip.so -- segments, free constraints, computeCost() and Trajectory::evaluate must agree.
+    Both ways a single-trajectory call can go: the library's host build of the lane code, and through the GPU."""
     import subprocess
     exe = os.path.join(HERE, "cpp", "test_reference_binding")
     if not os.path.exists(exe):
         pytest.skip("tests/cpp/test_reference_binding not built (needs /root/reference at build time)")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe] + (["device"] if mode == "device" else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REFERENCE BINDING OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
