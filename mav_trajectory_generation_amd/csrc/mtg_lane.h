@@ -159,16 +159,19 @@ MTG_HD double mtg_mul(double a, double b) {
 // division sequence); accuracy is checked on the device by mtg_selftest_rcp().
 MTG_HD double mtg_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#if defined(MTG_RCP_FAKE)   // measurement only: no reciprocal chain at all (wrong results)
-  return x * 0.37;
-#endif
-  double r = __builtin_amdgcn_rcp(x);
-#ifndef MTG_RCP_NEWTON
-#define MTG_RCP_NEWTON 2
-#endif
-#pragma unroll
-  for (int it = 0; it < MTG_RCP_NEWTON; ++it) r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
+  // v_rcp_f64 is good to ~4.6e-8 (24 bits; mtg_selftest_rcp with 0 steps).  One CUBIC correction
+  //   e = 1 - x r,  r <- r + r (e + e^2)        (error e^3 ~ 1e-22 before the final rounding)
+  // reaches the same result as two Newton steps (error e^4) with three dependent operations instead of four: the pivots
+  // sit on the kernels' longest dependency chain (8 cycles per dependent FP64 operation for a lone wave).
+  const double r0 = __builtin_amdgcn_rcp(x);
+#if defined(MTG_RCP_TWO_NEWTON)
+  double r = mtg_fma(mtg_fma(-x, r0, 1.0), r0, r0);
+  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
   return r;
+#else
+  const double e = mtg_fma(-x, r0, 1.0);
+  return mtg_fma(r0, mtg_fma(e, e, e), r0);
+#endif
 #else
   return 1.0 / x;
 #endif
