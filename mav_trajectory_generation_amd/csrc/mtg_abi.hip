@@ -106,6 +106,8 @@ struct mtg_context {
   bool knob_prefer_rolled = false;   // MTG_PREFER_ROLLED: rolled variant even where a static one exists
   bool knob_no_dimlane = false;      // MTG_NO_DIMLANE: never pick the dimension-in-lane form
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
+  bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
+  int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
   std::string last_error;
@@ -132,6 +134,7 @@ struct mtg_plan {
   const MtgStaticEntry* fast = nullptr;        // all dimensions in one workgroup
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
+  bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
   double* ws = nullptr;
   size_t ws_bytes = 0;
   double* pert_cost = nullptr;      // [(K + 1)][batch] costs of mtg_mellinger_cost_gradient's virtual problems
@@ -239,6 +242,8 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_prefer_rolled = getenv("MTG_PREFER_ROLLED") != nullptr;
   ctx->knob_no_dimlane = getenv("MTG_NO_DIMLANE") != nullptr;
   if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
+  ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
+  if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
   *out = ctx;
@@ -585,6 +590,23 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       SolveFn fn;
       int grid;
       const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
+      // fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
+      const MtgSlabEntry* slab = nullptr;
+      if (var && var->k > 0 && var->d == p->D && !wc && !cost_only && !pert && !ctx->knob_no_slab)
+        slab = mtg_find_slab(p->H, p->D, p->K, p->deriv, p->mask.data());
+      if (slab) {
+        const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
+        const int sgrid = std::min(ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
+        if (!p->slab_attr_set[pol]) {
+          MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->fn[pol], hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
+          p->slab_attr_set[pol] = true;
+        }
+        hipLaunchKernelGGL(slab->fn[pol], dim3(sgrid), dim3(kBlock), slab->lds, st, Q, ntiles);
+        LaunchRecord r;
+        r.valid = true; r.fn = slab->fn[pol]; r.params = Q; r.ntiles = ntiles; r.grid = sgrid; r.gridy = 1; r.lds = slab->lds;
+        p->last.push_back(r);
+        break;
+      }
       if (var) {
         Q.ws = p->user_ws;   // unused by the static kernels (measurement builds park timestamps here)
         // few tiles => every workgroup finishes at about the same time: write-through stores avoid the serial

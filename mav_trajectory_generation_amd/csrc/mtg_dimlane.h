@@ -20,179 +20,12 @@
 // input layout only (times[K][B], d_fixed[D][n_fixed][B]).
 #ifndef MTG_DIMLANE_H_
 #define MTG_DIMLANE_H_
-#include "mtg_kernels.h"
+#include "mtg_kernels.h"   // (brings in mtg_slab.h: MtgSlabOut)
 
 #ifndef MTG_DL_OCC
 #define MTG_DL_OCC 1   // waves per SIMD the register allocation is held to
 #endif
 
-
-// Coefficient output of one wave (one chain direction of TPW trajectories, all DL dimensions) through an LDS slab:
-// row t = the direction's contiguous half [half_lo, half_hi) of trajectory t's K*DL*N*8-byte output piece.
-// commit(seg) marks the 64-byte-aligned byte range that the segment just recovered has completed; the next drain() (one
-// back-substitution step later, so the LDS write -> read latency overlaps arithmetic) streams it out: 16-byte chunk o of
-// the range belongs to trajectory o / nch at offset o % nch, so 4 consecutive lanes write one whole sector and a store
-// instruction covers 64 consecutive chunks.
-template <class C, int DL, int DIR, int AUX>
-struct MtgSlabOut {
-  static constexpr int N = C::N, K = C::KT, KA = C::KA;
-  static constexpr int S = DL * N * 8;               // bytes of one segment (all dimensions)
-  static constexpr int TPW = kWave / DL;
-  static constexpr int PIECE = K * S;                // one trajectory's coefficients
-  static constexpr int HALF_LO = DIR > 0 ? 0 : KA * S, HALF_HI = DIR > 0 ? KA * S : K * S;
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  char* slab;
-  int lane, t, d;
-  __amdgpu_buffer_rsrc_t rsrc;
-
-  static constexpr int up64(int x) { return (x + 63) & ~63; }
-  static constexpr int dn64(int x) { return x & ~63; }
-
-  __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_) {
-    slab = slab_; lane = lane_; t = t_; d = d_;
-    pn = 0;
-    init_map();
-  }
-  // tile = TPW trajectories starting at b0; the descriptor ends at the last existing trajectory, the hardware range
-  // check drops the chunks of the tail tile's missing ones
-  __device__ __forceinline__ void begin_tile(double* coeffs, long long b0, long long B) {
-    char* gbase = reinterpret_cast<char*>(coeffs) + b0 * (long long)PIECE;
-    long long nvalid = B - b0;
-    if (nvalid > TPW) nvalid = TPW;
-    int nbytes = (int)nvalid * PIECE;
-    const unsigned long long g = reinterpret_cast<unsigned long long>(gbase);
-    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)g);
-    const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
-    gbase = reinterpret_cast<char*>(((unsigned long long)ghi << 32) | glo);
-    nbytes = __builtin_amdgcn_readfirstlane(nbytes);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
-    pn = 0;
-  }
-  __device__ __forceinline__ static void fence() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-  }
-  // where this lane puts the N coefficients of its dimension of segment `seg`
-  __device__ __forceinline__ double* row(int seg) {
-    const int off = kRing ? (seg & 1) * S : seg * S - HALF_LO;
-    return reinterpret_cast<double*>(slab + t * ROWB + off + d * (N * 8));
-  }
-  // Chunk -> (trajectory, offset) mapping of a drained range.  A lone wave pays ~4 cycles for EVERY instruction, so the
-  // index arithmetic matters: where the largest range has at most 16 chunks (256 bytes; BASELINE config 2: 192 / 256),
-  // a range is laid out as CHP = 4 / 8 / 16 chunks per trajectory (padded; surplus chunks are sent out of range), so that
-  // lane -> (trajectory, chunk) is a shift and a mask done ONCE per kernel (gl, ll below) and every chunk of every drain is
-  // that plus a compile-time constant.  Other shapes divide by the run-time-free chunk count (a multiply-high).
-  static constexpr int max_range_chunks() {
-    int m = 0;
-    for (int seg = (DIR > 0 ? 0 : KA); seg < (DIR > 0 ? KA : K); ++seg) {
-      int lo, hi;
-      range_of(seg, lo, hi);
-      if ((hi - lo) / 16 > m) m = (hi - lo) / 16;
-    }
-    return m;
-  }
-  static constexpr void range_of(int seg, int& lo, int& hi) {
-    if (DIR > 0) {   // segments arrive KA-1, ..., 0: the completed range grows downwards
-      lo = seg == 0 ? 0 : up64(seg * S);
-      hi = seg == KA - 1 ? KA * S : up64((seg + 1) * S);
-    } else {         // segments arrive KA, ..., K-1: upwards
-      lo = seg == KA ? KA * S : dn64(seg * S);
-      hi = seg == K - 1 ? K * S : dn64((seg + 1) * S);
-    }
-    if (hi < lo) hi = lo;
-  }
-  static constexpr int MAXCH = max_range_chunks();
-  static constexpr int CHP = MAXCH <= 4 ? 4 : (MAXCH <= 8 ? 8 : (MAXCH <= 16 ? 16 : 0));   // 0: generic mapping
-  // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
-  // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
-  // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
-  // whatever the chain length.  Generic mapping: the direction's whole half.
-  static constexpr bool kRing = CHP != 0;
-  static_assert(!kRing || S >= 64, "ring slab: a range reaches into at most one neighbouring segment");
-  static constexpr int ROWB = (((kRing ? 2 * S : HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
-  static constexpr int RPI = CHP ? kWave / CHP : 0;                                        // trajectories per store instruction
-  static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
-  u4 pv[MAXI];          // chunks of the previously committed range, read from the slab, not yet stored
-  unsigned pg[MAXI];    // their byte offsets in the tile's output
-  int pn;               // how many of them are in use
-  unsigned gl, ll;      // CHP mapping: this lane's (trajectory, chunk) part of the global / LDS byte offset
-  __device__ __forceinline__ void init_map() {
-    if constexpr (CHP != 0) {
-      const unsigned tr = (unsigned)lane / (unsigned)CHP, rr = (unsigned)lane % (unsigned)CHP;
-      gl = tr * (unsigned)PIECE + rr * 16u;
-      ll = tr * (unsigned)ROWB + rr * 16u;
-    }
-  }
-  __device__ __forceinline__ void store_pending() {
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      if (i < pn) __builtin_amdgcn_raw_buffer_store_b128(pv[i], rsrc, (int)pg[i], 0, AUX);
-    }
-    pn = 0;
-  }
-  // The segment's rows are in the slab: issue the LDS reads of the 64-byte-aligned range this segment completed; the
-  // next drain() (start of the next segment's recovery, after its back-substitution) stores them, so the LDS round trip
-  // overlaps arithmetic.
-  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
-    int lo = 0, hi = 0;
-    range_of(seg, lo, hi);
-    fence();
-    __builtin_amdgcn_sched_barrier(0);
-    if (hi > lo) {
-      const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
-      if constexpr (CHP != 0) {
-        const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
-        // ring: the chunks of the range that belong to the neighbouring (earlier recovered) segment sit in the other slot
-        const int nb = DIR > 0 ? seg + 1 : seg - 1;                       // that neighbour
-        const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
-        const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
-        const unsigned sel = (DIR > 0 ? (rr < (unsigned)cut) : (rr >= (unsigned)(cut > 0 ? cut : 0))) ? in_cur : in_nb;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-          const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
-          unsigned g = gl + (unsigned)(i * RPI * PIECE + lo);
-          if (!all_chunks || !all_rows) {
-            bool ok = true;
-            if (!all_chunks) ok = ok && rr < (unsigned)nch;
-            if (!all_rows) ok = ok && tr < (unsigned)(TPW - i * RPI);
-            g = ok ? g : 0x7ffffff0u;
-          }
-          pg[i] = g;
-          pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + (unsigned)(ll + sel + (unsigned)(i * RPI * ROWB))));   // 32-bit sum first: sel may be a wrapped negative
-          pn = i + 1;
-        }
-      } else {
-        const int total = TPW * nch;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-          if (i * 64 < total) {
-            const unsigned o = (unsigned)(i * 64 + lane);
-            const unsigned tt = o / (unsigned)nch, r = o - tt * (unsigned)nch;
-            const bool ok = o < (unsigned)total;
-            pg[i] = ok ? tt * (unsigned)PIECE + (unsigned)lo + r * 16u : 0x7ffffff0u;
-            const unsigned loff = ok ? tt * (unsigned)ROWB + (unsigned)(lo - HALF_LO) + r * 16u : 0u;
-            pv[i] = __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
-            pn = i + 1;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    fence();
-  }
-  __device__ __forceinline__ void drain(const MtgParams&) {
-    __builtin_amdgcn_sched_barrier(0);
-    store_pending();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ void flush(const MtgParams&) {
-    __builtin_amdgcn_sched_barrier(0);
-    store_pending();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-};
 
 template <class C, int DL>
 __host__ __device__ constexpr size_t mtg_dl_slab_bytes() {   // one wave's slab (the larger of the two directions')

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mtg_lane.h"
+#include "mtg_slab.h"
 
 #ifndef MTG_STORE_AUX
 #define MTG_STORE_AUX 0   // cache-policy bits of the coefficient stores (16 = sc1 write-through; A/B knob)
@@ -224,6 +225,78 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   }
 }
 
+// Slab-output form of the fused kernel (round 2): same lanes, same arithmetic as mtg_solve_kernel with all D dimensions
+// per lane, but the coefficients leave through MtgSlabOut (mtg_slab.h): a ring of two segment slots per trajectory in LDS,
+// and after every recovered segment the 64-byte-aligned range that has become complete is streamed out -- every store
+// instruction writes whole sectors, every sector is written once.  mtg_solve_kernel's 240-byte pieces complete most
+// sectors from two store instructions (read-modify-write at the memory side once the output is not cache-resident:
+// B = 125k 63-66 us resident, 80-83 us with rotating buffers).  Static configurations with K >= 2, all dimensions in one
+// workgroup (P.dim0 == 0, P.Dtot == C::D), coefficient output only.  Dynamic LDS = mtg_slab_lds_bytes<C>().
+template <class C>
+__host__ __device__ constexpr size_t mtg_slab_lds_bytes() {
+  constexpr size_t a = (size_t)MtgSlabOut<C, 1, 1, 0, false>::TPW * MtgSlabOut<C, 1, 1, 0, false>::ROWB;
+  constexpr size_t b = (size_t)MtgSlabOut<C, 1, -1, 0, false>::TPW * MtgSlabOut<C, 1, -1, 0, false>::ROWB;
+  return 2 * (a > b ? a : b);
+}
+
+template <class C, int AUX>
+__global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, int ntiles) {
+  static_assert(C::kStatic && C::KT >= 2 && !C::kPert, "slab-output form: static configurations, K >= 2");
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int dir = threadIdx.x >> 6;  // wave-uniform
+  MtgLane<C> ln;
+  auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
+    long long bb = (long long)tile_ * kWave + lane;
+    if (bb >= P.B) bb = P.B - 1;
+    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
+    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
+  constexpr int mm = C::MI;
+  constexpr int fmid = C::H - C::popc(mm);
+  constexpr int nslots = fmid * (fmid + 1) / 2 + C::D * fmid;
+  constexpr size_t half = mtg_slab_lds_bytes<C>() / 2;
+  static_assert((size_t)nslots * kWave * sizeof(double) <= half, "the exchange buffer lives in the other direction's slab");
+  char* my_slab = lds_raw + (size_t)dir * half;
+  double* mine = reinterpret_cast<double*>(lds_raw + (size_t)(1 - dir) * half) + lane;
+  const double* other = reinterpret_cast<const double*>(my_slab) + lane;
+  MtgSlabOut<C, 1, 1, AUX, false> ioA;
+  MtgSlabOut<C, 1, -1, AUX, false> ioB;
+  ioA.init(my_slab, lane, lane, 0);
+  ioB.init(my_slab, lane, lane, 0);
+  double nT[C::KCS], nfx[C::D][C::NC];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b0 = (long long)tile * kWave;
+    const long long bl = b0 + lane;
+    const bool active = bl < P.B;
+    const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
+    const bool has_next = tile + (int)gridDim.x < ntiles;
+    if (has_next) fetch(tile + gridDim.x, nT, nfx);   // the next tile's inputs land while this one is solved
+    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, nullptr, false);
+    else mtg_lane_forward<C, -1>(P, b, ln, nullptr, false);
+    mtg_pack_mid<C>(ln, mm, mine, kWave);
+    __syncthreads();
+    if (dir == 0) {
+      ioA.begin_tile(P.coeffs, b0, P.B);
+      mtg_lane_finish<C, 1, 0>(P, b, ln, nullptr, other, kWave, ioA, active);
+    } else {
+      ioB.begin_tile(P.coeffs, b0, P.B);
+      mtg_lane_finish<C, -1, 0>(P, b, ln, nullptr, other, kWave, ioB, active);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];
+#pragma unroll
+      for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) ln.fx[dm][c] = nfx[dm][c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Several plans in ONE launch (BASELINE config 4: a mixed request whose buckets share N, D, masks and derivative but not
 // K).  Rolled configurations only: K is a run-time field of MtgParams, so tiles of different buckets run the same code.
 // `table[bucket]` holds the bucket's parameters (pointers, strides, B, K; all buckets share one workspace sized for the
@@ -302,6 +375,12 @@ struct MtgStaticEntry {
   SolveMultiFn multi[4];            // rolled entries: several plans in one launch, [extra outputs] + 2 * [write-through]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
+struct MtgSlabEntry {
+  int h, d, k, ms, mi, me, dv;
+  size_t lds;
+  SolveFn fn[2];   // coefficient store policy: [0] write-back, [1] nt sc1
+};
+const MtgSlabEntry* mtg_find_slab(int h, int d, int k, int deriv, const int* mask);
 
 // dimension-in-lane launch form (mtg_dimlane.h / mtg_dimlane.hip): canonical SoA inputs, coefficient output (+ status)
 struct MtgDimlaneEntry {

@@ -1,0 +1,230 @@
+// mtg_slab.h -- whole-sector coefficient output through an LDS slab (shared by the dimension-in-lane kernel,
+// mtg_dimlane.h, and the slab-output instantiations of the fused kernel, mtg_kernels.h).
+#ifndef MTG_SLAB_H_
+#define MTG_SLAB_H_
+#include "mtg_lane.h"
+
+// Coefficient output of one wave (one chain direction of TPW trajectories, all dimensions) through an LDS slab.
+// LPT = lanes per trajectory (the dimension-in-lane kernel: one lane per dimension, C::D == 1; the fused kernel: LPT == 1,
+// a lane holds all C::D dimensions).  PEND: hold a range's chunks in registers across one back-substitution step (a lone
+// wave per SIMD hides the LDS round trip that way); false: read and store within commit(), in groups of four (register-
+// tight kernels).
+// Layout:
+// row t = the direction's contiguous half [half_lo, half_hi) of trajectory t's K*DL*N*8-byte output piece.
+// commit(seg) marks the 64-byte-aligned byte range that the segment just recovered has completed; the next drain() (one
+// back-substitution step later, so the LDS write -> read latency overlaps arithmetic) streams it out: 16-byte chunk o of
+// the range belongs to trajectory o / nch at offset o % nch, so 4 consecutive lanes write one whole sector and a store
+// instruction covers 64 consecutive chunks.
+template <class C, int LPT, int DIR, int AUX, bool PEND = true>
+struct MtgSlabOut {
+  static constexpr int N = C::N, K = C::KT, KA = C::KA;
+  static constexpr int LB = C::D * N * 8;            // bytes one lane contributes per segment (its C::D dimensions)
+  static constexpr int S = LPT * LB;                 // bytes of one segment (all dimensions of the trajectory)
+  static constexpr int TPW = 64 / LPT;
+  static constexpr int PIECE = K * S;                // one trajectory's coefficients
+  static constexpr int HALF_LO = DIR > 0 ? 0 : KA * S, HALF_HI = DIR > 0 ? KA * S : K * S;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  char* slab;
+  int lane, t, d;
+  __amdgpu_buffer_rsrc_t rsrc;
+
+  static constexpr int up64(int x) { return (x + 63) & ~63; }
+  static constexpr int dn64(int x) { return x & ~63; }
+
+  __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_) {
+    slab = slab_; lane = lane_; t = t_; d = d_;
+    pn = 0;
+    init_map();
+  }
+  // tile = TPW trajectories starting at b0; the descriptor ends at the last existing trajectory, the hardware range
+  // check drops the chunks of the tail tile's missing ones
+  __device__ __forceinline__ void begin_tile(double* coeffs, long long b0, long long B) {
+    char* gbase = reinterpret_cast<char*>(coeffs) + b0 * (long long)PIECE;
+    long long nvalid = B - b0;
+    if (nvalid > TPW) nvalid = TPW;
+    int nbytes = (int)nvalid * PIECE;
+    const unsigned long long g = reinterpret_cast<unsigned long long>(gbase);
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)g);
+    const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+    gbase = reinterpret_cast<char*>(((unsigned long long)ghi << 32) | glo);
+    nbytes = __builtin_amdgcn_readfirstlane(nbytes);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
+    pn = 0;
+  }
+  __device__ __forceinline__ static void fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // where this lane puts the N coefficients of its dimension of segment `seg`
+  __device__ __forceinline__ double* row(int seg) {
+    const int off = kRing ? (seg & 1) * S : seg * S - HALF_LO;
+    return reinterpret_cast<double*>(slab + t * ROWB + off + d * LB);
+  }
+  // Chunk -> (trajectory, offset) mapping of a drained range.  A lone wave pays ~4 cycles for EVERY instruction, so the
+  // index arithmetic matters: where the largest range has at most 16 chunks (256 bytes; BASELINE config 2: 192 / 256),
+  // a range is laid out as CHP = 4 / 8 / 16 chunks per trajectory (padded; surplus chunks are sent out of range), so that
+  // lane -> (trajectory, chunk) is a shift and a mask done ONCE per kernel (gl, ll below) and every chunk of every drain is
+  // that plus a compile-time constant.  Other shapes divide by the run-time-free chunk count (a multiply-high).
+  static constexpr int max_range_chunks() {
+    int m = 0;
+    for (int seg = (DIR > 0 ? 0 : KA); seg < (DIR > 0 ? KA : K); ++seg) {
+      int lo, hi;
+      range_of(seg, lo, hi);
+      if ((hi - lo) / 16 > m) m = (hi - lo) / 16;
+    }
+    return m;
+  }
+  static constexpr void range_of(int seg, int& lo, int& hi) {
+    if (DIR > 0) {   // segments arrive KA-1, ..., 0: the completed range grows downwards
+      lo = seg == 0 ? 0 : up64(seg * S);
+      hi = seg == KA - 1 ? KA * S : up64((seg + 1) * S);
+    } else {         // segments arrive KA, ..., K-1: upwards
+      lo = seg == KA ? KA * S : dn64(seg * S);
+      hi = seg == K - 1 ? K * S : dn64((seg + 1) * S);
+    }
+    if (hi < lo) hi = lo;
+  }
+  static constexpr int MAXCH = max_range_chunks();
+  static constexpr int CHP = MAXCH <= 4 ? 4 : (MAXCH <= 8 ? 8 : (MAXCH <= 16 ? 16 : 0));   // 0: generic mapping
+  // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
+  // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
+  // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
+  // whatever the chain length.  Generic mapping: the direction's whole half.
+  static constexpr bool kRing = CHP != 0;
+  static_assert(!kRing || S >= 64, "ring slab: a range reaches into at most one neighbouring segment");
+  static constexpr int ROWB = (((kRing ? 2 * S : HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
+  static constexpr int RPI = CHP ? 64 / CHP : 0;                                        // trajectories per store instruction
+  static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
+  static constexpr int NPV = PEND ? MAXI : 1;
+  u4 pv[NPV];           // PEND: chunks of the previously committed range, read from the slab, not yet stored
+  unsigned pg[NPV];     // their byte offsets in the tile's output
+  int pn;               // PEND: how many of them are in use; !PEND: the committed, not yet streamed segment + 1 (0: none)
+  unsigned gl, ll;      // CHP mapping: this lane's (trajectory, chunk) part of the global / LDS byte offset
+  __device__ __forceinline__ void init_map() {
+    if constexpr (CHP != 0) {
+      const unsigned tr = (unsigned)lane / (unsigned)CHP, rr = (unsigned)lane % (unsigned)CHP;
+      gl = tr * (unsigned)PIECE + rr * 16u;
+      ll = tr * (unsigned)ROWB + rr * 16u;
+    }
+  }
+  // ring (CHP mapping): LDS offset of this lane's chunk of range(seg) relative to (row, chunk) = ll -- the chunks that
+  // belong to the neighbouring (earlier recovered) segment sit in the other slot
+  __device__ __forceinline__ unsigned slot_select(int seg, int lo) const {
+    const unsigned rr = (unsigned)lane % (unsigned)(CHP ? CHP : 1);
+    const int nb = DIR > 0 ? seg + 1 : seg - 1;
+    const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
+    const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
+    return (DIR > 0 ? (rr < (unsigned)cut) : (rr >= (unsigned)(cut > 0 ? cut : 0))) ? in_cur : in_nb;
+  }
+  // chunk i of range(seg) = [lo, lo + 16 nch): global byte offset (out of range for surplus lanes) and LDS byte offset;
+  // false if store instruction i does not exist for this range
+  __device__ __forceinline__ bool chunk(int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
+    if constexpr (CHP != 0) {
+      if (i >= MAXI) return false;
+      const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
+      const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
+      g = gl + (unsigned)(i * RPI * PIECE + lo);
+      if (!all_chunks || !all_rows) {
+        bool ok = true;
+        if (!all_chunks) ok = ok && rr < (unsigned)nch;
+        if (!all_rows) ok = ok && tr < (unsigned)(TPW - i * RPI);
+        g = ok ? g : 0x7ffffff0u;
+      }
+      loff = ll + sel + (unsigned)(i * RPI * ROWB);   // 32-bit sum: sel may be a wrapped negative
+      return true;
+    } else {
+      const int total = TPW * nch;
+      if (i * 64 >= total) return false;
+      const unsigned o = (unsigned)(i * 64 + lane);
+      const unsigned tt = o / (unsigned)nch, r = o - tt * (unsigned)nch;
+      const bool ok = o < (unsigned)total;
+      g = ok ? tt * (unsigned)PIECE + (unsigned)lo + r * 16u : 0x7ffffff0u;
+      loff = ok ? tt * (unsigned)ROWB + (unsigned)(lo - HALF_LO) + r * 16u : 0u;
+      return true;
+    }
+  }
+  __device__ __forceinline__ u4 lds_chunk(unsigned loff) const {
+    return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
+  }
+  __device__ __forceinline__ void store_pending() {
+    if constexpr (PEND) {
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) {
+        if (i < pn) __builtin_amdgcn_raw_buffer_store_b128(pv[i], rsrc, (int)pg[i], 0, AUX);
+      }
+      pn = 0;
+    } else {
+      if (pn == 0) return;
+      const int seg = pn - 1;
+      pn = 0;
+      int lo = 0, hi = 0;
+      range_of(seg, lo, hi);
+      if (hi <= lo) return;
+      const int nch = (hi - lo) >> 4;
+      const unsigned sel = CHP != 0 ? slot_select(seg, lo) : 0u;
+      fence();
+      constexpr int G = 4;   // LDS reads in groups ahead of their stores: one lgkmcnt wait per group
+#pragma unroll
+      for (int i0 = 0; i0 < MAXI; i0 += G) {
+        u4 v[G];
+        unsigned g[G];
+        bool on[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          unsigned loff = 0;
+          g[i] = 0;
+          on[i] = chunk(lo, nch, sel, i0 + i, g[i], loff);
+          if (on[i]) v[i] = lds_chunk(loff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          if (on[i]) __builtin_amdgcn_raw_buffer_store_b128(v[i], rsrc, (int)g[i], 0, AUX);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fence();
+    }
+  }
+  // The segment's rows are in the slab.  PEND: issue the LDS reads of the 64-byte-aligned range this segment completed;
+  // the next drain() (start of the next segment's recovery, after its back-substitution) stores them, so the LDS round
+  // trip overlaps arithmetic.  !PEND: remember the segment; the next drain() reads and stores the range.
+  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
+    fence();
+    if constexpr (PEND) {
+      int lo = 0, hi = 0;
+      range_of(seg, lo, hi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (hi > lo) {
+        const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
+        const unsigned sel = CHP != 0 ? slot_select(seg, lo) : 0u;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+          unsigned loff = 0;
+          if (chunk(lo, nch, sel, i, pg[i], loff)) {
+            pv[i] = lds_chunk(loff);
+            pn = i + 1;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fence();
+    } else {
+      pn = seg + 1;
+    }
+  }
+  __device__ __forceinline__ void drain(const MtgParams&) {
+    __builtin_amdgcn_sched_barrier(0);
+    store_pending();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush(const MtgParams&) {
+    __builtin_amdgcn_sched_barrier(0);
+    store_pending();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+
+#endif  // MTG_SLAB_H_

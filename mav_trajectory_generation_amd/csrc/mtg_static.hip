@@ -44,3 +44,26 @@ const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int*
   }
   return nullptr;
 }
+
+// Slab-output instantiations of the fused form (mtg_solve_slab_kernel): the shapes that run large batches.
+#define MTG_SLAB(H, D, K, MS, MI, ME, DV)                                              \
+  {H, D, K, MS, MI, ME, DV, mtg_slab_lds_bytes<MtgCfg<H, D, K, MS, MI, ME, DV>>(),      \
+   {(SolveFn)mtg_solve_slab_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,                \
+    (SolveFn)mtg_solve_slab_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 18>}},
+static const MtgSlabEntry kSlabTable[] = {
+    MTG_SLAB(5, 3, 8, 31, 1, 31, 4)   // BASELINE configs 2/3
+    MTG_SLAB(4, 3, 8, 15, 1, 15, 3)
+    MTG_SLAB(5, 3, 4, 31, 1, 31, 4)
+    MTG_SLAB(4, 3, 4, 15, 1, 15, 3)
+};
+#undef MTG_SLAB
+
+const MtgSlabEntry* mtg_find_slab(int h, int d, int k, int deriv, const int* mask) {
+  for (const MtgSlabEntry& e : kSlabTable) {
+    if (e.h != h || e.d != d || e.k != k || e.dv != deriv) continue;
+    bool ok = mask[0] == e.ms && mask[k] == e.me;
+    for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
+    if (ok) return &e;
+  }
+  return nullptr;
+}

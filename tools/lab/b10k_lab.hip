@@ -155,6 +155,25 @@ int main(int argc, char** argv) {
   std::printf("production split (471 x 128)      : %7.2f us\n", time_us(st, prod_split));
   std::printf("production fused (157 x 128)      : %7.2f us\n", time_us(st, prod_fused));
   prod_fused(0); check("production fused");
+  {
+    auto run_slab = [&](auto kern, const char* name) {
+      CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mtg_slab_lds_bytes<C3>()));
+      auto go = [=, &dt, &df, &dc](int i) {
+        MtgParams P; std::memset(&P, 0, sizeof(P));
+        const int s2 = i % NSETS;
+        P.times = dt[s2]; P.ts_b = 1; P.ts_k = B; P.dfix = df[s2]; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)NF * B;
+        P.coeffs = dc[s2]; P.status = dstat; P.B = B; P.K = K; P.Dtot = D; P.deriv = 4; P.h1off = C1::H1OFF; P.ainvoff = C1::AINVOFF;
+        hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256 * 2)), dim3(kBlock), mtg_slab_lds_bytes<C3>(), st, P, ntiles);
+      };
+      CK(hipMemsetAsync(dc[0], 0, ncoef * 8, st));
+      go(0); check(name);
+      std::printf("%-34s: %7.2f %7.2f us\n", name, time_us(st, go), time_us(st, go));
+    };
+    run_slab((mtg_solve_slab_kernel<C3, 0>), "fused, slab output, write-back");
+    run_slab((mtg_solve_slab_kernel<C3, 18>), "fused, slab output, nt sc1");
+    run_slab((mtg_solve_slab_kernel<C3, 2>), "fused, slab output, nt");
+    std::printf("production fused (again)          : %7.2f us\n", time_us(st, prod_fused));
+  }
 
   {
     double* dcost; CK(hipMalloc(&dcost, (size_t)B * 8)); CK(hipMemset(dcost, 0, (size_t)B * 8));
