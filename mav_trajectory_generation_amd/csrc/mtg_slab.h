@@ -87,13 +87,15 @@ struct MtgSlabOut {
     if (hi < lo) hi = lo;
   }
   static constexpr int MAXCH = max_range_chunks();
-  static constexpr int CHP = MAXCH <= 4 ? 4 : (MAXCH <= 8 ? 8 : (MAXCH <= 16 ? 16 : 0));   // 0: generic mapping
+  // chunks per trajectory row of a store instruction: the next power of two where at most 1/8 of the lanes idle, else the
+  // generic mapping (N = 8: 192-byte ranges = 12 chunks; padded to 16 a quarter of every store instruction would be idle)
+  static constexpr int pow2_rows(int m) { return m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : 0)); }
+  static constexpr int CHP = (pow2_rows(MAXCH) != 0 && 8 * (pow2_rows(MAXCH) - MAXCH) <= pow2_rows(MAXCH)) ? pow2_rows(MAXCH) : 0;
   // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
   // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
   // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
   // whatever the chain length.  Generic mapping: the direction's whole half.
-  static constexpr bool kRing = CHP != 0;
-  static_assert(!kRing || S >= 64, "ring slab: a range reaches into at most one neighbouring segment");
+  static constexpr bool kRing = S >= 64;   // (tiny shapes: the direction's whole half; a range could span several segments)
   static constexpr int ROWB = (((kRing ? 2 * S : HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
   static constexpr int RPI = CHP ? 64 / CHP : 0;                                        // trajectories per store instruction
   static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
@@ -111,8 +113,8 @@ struct MtgSlabOut {
   }
   // ring (CHP mapping): LDS offset of this lane's chunk of range(seg) relative to (row, chunk) = ll -- the chunks that
   // belong to the neighbouring (earlier recovered) segment sit in the other slot
-  __device__ __forceinline__ unsigned slot_select(int seg, int lo) const {
-    const unsigned rr = (unsigned)lane % (unsigned)(CHP ? CHP : 1);
+  __device__ __forceinline__ unsigned slot_select(int seg, int lo, unsigned rr) const {
+    if constexpr (!kRing) return (unsigned)(lo - HALF_LO);
     const int nb = DIR > 0 ? seg + 1 : seg - 1;
     const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
     const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
@@ -120,7 +122,7 @@ struct MtgSlabOut {
   }
   // chunk i of range(seg) = [lo, lo + 16 nch): global byte offset (out of range for surplus lanes) and LDS byte offset;
   // false if store instruction i does not exist for this range
-  __device__ __forceinline__ bool chunk(int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
+  __device__ __forceinline__ bool chunk(int seg, int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
     if constexpr (CHP != 0) {
       if (i >= MAXI) return false;
       const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
@@ -141,7 +143,7 @@ struct MtgSlabOut {
       const unsigned tt = o / (unsigned)nch, r = o - tt * (unsigned)nch;
       const bool ok = o < (unsigned)total;
       g = ok ? tt * (unsigned)PIECE + (unsigned)lo + r * 16u : 0x7ffffff0u;
-      loff = ok ? tt * (unsigned)ROWB + (unsigned)(lo - HALF_LO) + r * 16u : 0u;
+      loff = ok ? (unsigned)(tt * (unsigned)ROWB + slot_select(seg, lo, r) + r * 16u) : 0u;
       return true;
     }
   }
@@ -163,7 +165,7 @@ struct MtgSlabOut {
       range_of(seg, lo, hi);
       if (hi <= lo) return;
       const int nch = (hi - lo) >> 4;
-      const unsigned sel = CHP != 0 ? slot_select(seg, lo) : 0u;
+      const unsigned sel = CHP != 0 ? slot_select(seg, lo, (unsigned)lane % (unsigned)(CHP ? CHP : 1)) : 0u;
       fence();
       constexpr int G = 4;   // LDS reads in groups ahead of their stores: one lgkmcnt wait per group
 #pragma unroll
@@ -175,7 +177,7 @@ struct MtgSlabOut {
         for (int i = 0; i < G; ++i) {
           unsigned loff = 0;
           g[i] = 0;
-          on[i] = chunk(lo, nch, sel, i0 + i, g[i], loff);
+          on[i] = chunk(seg, lo, nch, sel, i0 + i, g[i], loff);
           if (on[i]) v[i] = lds_chunk(loff);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -199,11 +201,11 @@ struct MtgSlabOut {
       __builtin_amdgcn_sched_barrier(0);
       if (hi > lo) {
         const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
-        const unsigned sel = CHP != 0 ? slot_select(seg, lo) : 0u;
+        const unsigned sel = CHP != 0 ? slot_select(seg, lo, (unsigned)lane % (unsigned)(CHP ? CHP : 1)) : 0u;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
           unsigned loff = 0;
-          if (chunk(lo, nch, sel, i, pg[i], loff)) {
+          if (chunk(seg, lo, nch, sel, i, pg[i], loff)) {
             pv[i] = lds_chunk(loff);
             pn = i + 1;
           }

@@ -20,6 +20,8 @@ tools/micro/launch_geometry > $OUT/launch_geometry_microbench.txt 2>&1
 tools/lab/b10k_lab 10000 1 > $OUT/lab_resident.txt 2>&1
 tools/lab/b10k_lab 10000 16 > $OUT/lab_rotating.txt 2>&1
 tools/lab/b10k_lab_t 10000 1 | tail -12 > $OUT/lab_phase_timing.txt 2>&1
+(for a in "125000 1" "125000 4" "1000000 1"; do echo "== B, buffer sets: $a"; tools/lab/b10k_lab $a | grep "fused\|slab"; done) > $OUT/lab_large_batch.txt 2>&1
 python tools/enqueue_probe.py 16 > $OUT/enqueue_probe.txt 2>&1
 tools/cpp/polynomial_timing_evaluation > $OUT/veneer_timing_evaluation.txt 2>&1
+bash tools/sweep_forms.sh > $OUT/sweep_forms.txt 2>&1
 ls $OUT

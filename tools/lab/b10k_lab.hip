@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
         const int s2 = i % NSETS;
         P.times = dt[s2]; P.ts_b = 1; P.ts_k = B; P.dfix = df[s2]; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)NF * B;
         P.coeffs = dc[s2]; P.status = dstat; P.B = B; P.K = K; P.Dtot = D; P.deriv = 4; P.h1off = C1::H1OFF; P.ainvoff = C1::AINVOFF;
-        hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256 * 2)), dim3(kBlock), mtg_slab_lds_bytes<C3>(), st, P, ntiles);
+        hipLaunchKernelGGL(kern, dim3(std::min(ntiles, getenv("LAB_SLAB_GRID") ? atoi(getenv("LAB_SLAB_GRID")) : 512)), dim3(kBlock), mtg_slab_lds_bytes<C3>(), st, P, ntiles);
       };
       CK(hipMemsetAsync(dc[0], 0, ncoef * 8, st));
       go(0); check(name);
