@@ -90,12 +90,16 @@ enum {
   MTG_FLAG_DIMLANE = 1u << 5,        /* force the dimension-in-lane launch form where the     */
                                      /* plan and the call are eligible (SoA inputs, coeffs    */
                                      /* only); default: chosen from the batch size            */
-  MTG_FLAG_HOST_BACKEND = 1u << 6    /* with MTG_FLAG_HOST_POINTERS and batch <=               */
+  MTG_FLAG_HOST_BACKEND = 1u << 6,   /* with MTG_FLAG_HOST_POINTERS and batch <=               */
                                      /* MTG_HOST_BACKEND_MAX_BATCH: solve on the calling      */
                                      /* thread with the host build of the kernels' lane code  */
                                      /* (no launch, no PCIe): the single-trajectory calls of  */
                                      /* the reference's nlopt loops (polynomial_optimization_ */
                                      /* nonlinear_impl.h:569-571).  Ignored otherwise.        */
+  MTG_FLAG_CONCURRENT_ITEMS = 1u << 7 /* mtg_multi_create: no merging -- every item runs as its */
+                                     /* own best launch, spread over the context's side       */
+                                     /* streams (longest chains first), forked from and       */
+                                     /* joined back onto the context's stream                 */
 };
 #define MTG_HOST_BACKEND_MAX_BATCH 64
 
@@ -255,7 +259,9 @@ typedef struct mtg_multi_item {
   double* cost;            /* device, optional */
 } mtg_multi_item;
 /* flags: 0, or MTG_FLAG_FUSED_DIMS / MTG_FLAG_SPLIT_DIMS to fix the launch geometry of the merged groups (a caller
- * that runs several mixed requests concurrently knows the total load; the default looks at this request only).    */
+ * that runs several mixed requests concurrently knows the total load; the default looks at this request only);
+ * or MTG_FLAG_CONCURRENT_ITEMS: one launch per item through the ordinary variant choice (static / dimension-in-lane
+ * kernels where the plan has them), the items overlapping on the device on up to 4 internal streams.               */
 int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* items, uint32_t flags, mtg_multi** out);
 int mtg_multi_solve(mtg_multi* multi);              /* asynchronous on the context's stream */
 int mtg_multi_launch_count(const mtg_multi* multi); /* kernel launches one mtg_multi_solve enqueues */

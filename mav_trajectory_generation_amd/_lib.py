@@ -94,6 +94,7 @@ FLAG_SPLIT_DIMS = 8
 FLAG_COST_ONLY = 16
 FLAG_DIMLANE = 32
 FLAG_HOST_BACKEND = 64
+FLAG_CONCURRENT_ITEMS = 128
 
 _lib = None
 

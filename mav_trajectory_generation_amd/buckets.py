@@ -90,10 +90,16 @@ class MixedBatchSolver:
             out = self.solve_device(buckets, want_cost, _capturing=True)
         return graph, out
 
-    def merged(self, buckets: List[dict], want_cost: bool = False) -> "MergedRequest":
+    def merged(self, buckets: List[dict], want_cost: bool = False, dims: str = "auto") -> "MergedRequest":
         """The same request with buckets that share N, D, the constraint pattern and the derivative merged into ONE
         kernel launch each (mtg_multi_*): see MergedRequest."""
-        return MergedRequest(self, buckets, want_cost)
+        return MergedRequest(self, buckets, want_cost, dims)
+
+    def concurrent(self, buckets: List[dict], want_cost: bool = False) -> "ConcurrentRequest":
+        """The same request as ONE library call (mtg_multi_* with MTG_FLAG_CONCURRENT_ITEMS): every bucket runs as its
+        own best launch (dimension-in-lane / static kernels), the launches spread over the context's side streams inside
+        the library -- no per-bucket Python or stream bookkeeping on the host: see ConcurrentRequest."""
+        return ConcurrentRequest(self, buckets, want_cost)
 
     def sync(self):
         for c in self.lanes:
@@ -138,45 +144,56 @@ class MixedBatchSolver:
         self.lanes = self.lanes[:1]
 
 
-class MergedRequest:
-    """A mixed request whose buckets of equal structure-up-to-K run as one launch (C ABI: mtg_multi_create / _solve):
-    BASELINE config 4 becomes 3 launches (N = 8, 10, 12) instead of 12, each on its own HIP stream, every tile of every
-    bucket in flight at once -- the request then takes about as long as its longest chain.  Created once for a set of
-    device tensors; `solve()` re-solves with whatever values those tensors hold; `capture()` wraps that in one hipGraph."""
+class ConcurrentRequest:
+    """A mixed request enqueued by one C call: per bucket the launch the single-plan path would choose, longest chains
+    first, on up to four streams owned by the library context (fork from / join onto the context's stream).  A bucket of
+    2500 trajectories occupies 60-120 of the 256 CUs, so the buckets overlap; the request takes about as long as its
+    longest bucket plus the host's enqueue time.  Created once for a set of device tensors; `solve()` re-solves with
+    whatever values those tensors hold."""
 
     def __init__(self, solver: MixedBatchSolver, buckets: List[dict], want_cost: bool = False):
         self.solver = solver
-        groups: Dict[Tuple, List[int]] = {}
-        for i, b in enumerate(buckets):
-            masks = [int(m) for m in b["masks"]]
-            layout = b.get("layout", "aos")
-            dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
-            key = (int(b["n_coeffs"]), dim, int(b["derivative"]), masks[0], masks[-1], tuple(sorted(set(masks[1:-1]))))
-            groups.setdefault(key, []).append(i)
-        self.multis: List[MultiSolve] = []
-        self.out: List = [None] * len(buckets)
-        # launch geometry from the load of the WHOLE request (its groups run concurrently): one dimension per workgroup
-        # only while every workgroup of every group is resident at once (4 x CUs)
-        import torch
-        n_cu = torch.cuda.get_device_properties(solver.ctx.device).multi_processor_count
-        wgs = 0
+        items = []
         for b in buckets:
             layout = b.get("layout", "aos")
-            batch = b["times"].shape[0] if layout == "aos" else b["times"].shape[1]
             dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
-            wgs += ((batch + 63) // 64) * dim
-        dims = "split" if wgs <= 4 * n_cu else "fused"
-        for lane, (key, idx) in enumerate(groups.items()):
-            items = []
-            for i in idx:
-                b = buckets[i]
-                plan = solver.plan_for(key[0], key[1], len(b["masks"]) - 1, key[2], b["masks"], lane)
-                items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=b.get("layout", "aos")))
-            ms = MultiSolve(solver._lane(lane), items, want_cost=want_cost, dims=dims)
-            self.multis.append(ms)
-            for i, it in zip(idx, ms.items):
-                self.out[i] = (it["coeffs"], it["cost"])
-        self.launch_count = sum(ms.launch_count for ms in self.multis)
+            plan = solver.plan_for(int(b["n_coeffs"]), dim, len(b["masks"]) - 1, int(b["derivative"]), b["masks"], 0)
+            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout))
+        self.multi = MultiSolve(solver.ctx, items, want_cost=want_cost, dims="concurrent")
+        self.out = [(it["coeffs"], it["cost"]) for it in self.multi.items]
+        self.launch_count = self.multi.launch_count
+
+    def solve(self):
+        """Asynchronous; results ordered on torch's current stream.  Returns [(coeffs, cost)] in bucket order."""
+        self.multi.solve()
+        return self.out
+
+    def close(self):
+        self.multi.close()
+
+
+class MergedRequest:
+    """A mixed request as merged launches (C ABI: mtg_multi_create / _solve): buckets of equal structure-up-to-K run as
+    one launch, and buckets whose structures differ only in N (the library's standard N = 8 / 10 / 12 shapes) join ONE
+    cross-structure launch -- BASELINE config 4 is a single launch instead of 12, every tile of every bucket in flight
+    at once, so the request takes about as long as its longest chain.  (Streams are no substitute on this runtime:
+    kernels of different streams overlap two at a time at best, profiles/r02_stream_overlap_microbench.txt.)  Created
+    once for a set of device tensors; `solve()` re-solves with whatever values those tensors hold; `capture()` wraps
+    that in one hipGraph."""
+
+    def __init__(self, solver: MixedBatchSolver, buckets: List[dict], want_cost: bool = False, dims: str = "auto"):
+        self.solver = solver
+        items = []
+        for b in buckets:
+            layout = b.get("layout", "aos")
+            dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
+            plan = solver.plan_for(int(b["n_coeffs"]), dim, len(b["masks"]) - 1, int(b["derivative"]), b["masks"], 0)
+            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout))
+        # launch geometry (dims = 'auto'): the library looks at the whole request
+        ms = MultiSolve(solver.ctx, items, want_cost=want_cost, dims=dims)
+        self.multis: List[MultiSolve] = [ms]
+        self.out: List = [(it["coeffs"], it["cost"]) for it in ms.items]
+        self.launch_count = ms.launch_count
 
     def solve(self):
         """Asynchronous; results ordered on torch's current stream.  Returns [(coeffs, cost)] in bucket order."""

@@ -339,7 +339,8 @@ class MultiSolve:
             arr[i].cost = cost.data_ptr() if cost is not None else None
             self.items.append(dict(plan=plan, times=t, d_fixed=f, coeffs=co, d_free=fr, cost=cost, layout=layout))
         h = ctypes.c_void_p()
-        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS}[dims]
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS,
+                 "concurrent": L.FLAG_CONCURRENT_ITEMS}[dims]   # concurrent: one launch per item on the context's side streams
         _check(self.lib, self.lib.mtg_multi_create(ctx.handle, len(items), arr, flags, ctypes.byref(h)), ctx.handle)
         self.handle = h
         self.launch_count = self.lib.mtg_multi_launch_count(h)

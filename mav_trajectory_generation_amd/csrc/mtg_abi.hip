@@ -110,6 +110,10 @@ struct mtg_context {
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
+  // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
+  std::vector<hipStream_t> side_streams;
+  hipEvent_t fork_event = nullptr;
+  std::vector<hipEvent_t> join_events;
   std::string last_error;
   std::mutex mu;
 };
@@ -122,6 +126,7 @@ struct LaunchRecord {
   size_t lds = 0;
   const MtgDimlaneEntry* dl = nullptr;   // dimension-in-lane launch (mtg_dimlane.h): uses params.{times,dfix,coeffs,status,tstatus,B}
   int dl_policy = 0;
+  double* dl_ws = nullptr;
 };
 
 struct mtg_plan {
@@ -258,6 +263,9 @@ int mtg_context_destroy(mtg_context* ctx) {
   if (ctx->h_status) hipHostFree(ctx->h_status);
   if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  for (hipStream_t q : ctx->side_streams) { hipStreamSynchronize(q); hipStreamDestroy(q); }
+  for (hipEvent_t e : ctx->join_events) hipEventDestroy(e);
+  if (ctx->fork_event) hipEventDestroy(ctx->fork_event);
   delete ctx;
   return MTG_OK;
 }
@@ -432,7 +440,8 @@ struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradie
 
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only,
-                      int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr) {
+                      int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr,
+                      hipStream_t on_stream = nullptr) {
   const bool cost_only = !update_only && (flags & MTG_FLAG_COST_ONLY) != 0;
   if (!p || !L || !times || (!coeffs && !cost_only) || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
   if (cost_only && (!cost || (flags & MTG_FLAG_HOST_POINTERS))) return MTG_ERR_INVALID_ARGUMENT;
@@ -459,7 +468,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   }
   std::lock_guard<std::mutex> lock(ctx->mu);
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
+  hipStream_t st = on_stream ? on_stream : ctx->stream;   // on_stream: a side stream of a concurrent mixed request
 
   const int64_t n_times = span(batch, L->times_stride_b, p->K, L->times_stride_k, 1, 0);
   const int64_t n_fix = p->n_fixed ? span(batch, L->fixed_stride_b, p->D, L->fixed_stride_d, p->n_fixed, L->fixed_stride_c) : 0;
@@ -543,12 +552,27 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
     const int nt = (int)((batch + dl->tpw - 1) / dl->tpw);
     const int units = (nt + dl->np - 1) / dl->np;
-    const int grid = std::min(units, ctx->n_cu * 8);
+    int grid = std::min(units, ctx->n_cu * 8);
     const int policy = ctx->knob_dl_policy >= 0 ? ctx->knob_dl_policy : 0;
-    if (dl->launch((void*)st, grid, dt, dfx, dco, ctx->d_status, dts, (int)batch, nt, policy) != 0)
+    double* dl_ws = nullptr;
+    if (dl->ws_per_lane) {
+      // long chains: part of the back-substitution data goes through the workspace; persistent workgroups only (two
+      // 2-wave workgroups per CU, one wave per SIMD), so the workspace stays small enough to live in the Infinity Cache
+      grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
+      const size_t need = dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave;
+      if (p->user_ws) {
+        if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
+        dl_ws = p->user_ws;
+      } else {
+        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+        if (rc != MTG_OK) return rc;
+        dl_ws = p->ws;
+      }
+    }
+    if (dl->launch((void*)st, grid, dt, dfx, dco, ctx->d_status, dts, (int)batch, nt, policy, dl_ws) != 0)
       return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
     LaunchRecord r;
-    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy;
+    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws;
     p->last.push_back(r);
   } else {
     // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
@@ -779,12 +803,19 @@ struct MtgMultiGroup {
   int ntiles = 0, grid = 0, ngroups = 1;    // ngroups: dimension groups (grid.y) of the launch
   size_t lds = 0;
   bool extra = false;                       // any item wants d_free / cost
+  bool any = false;                         // cross-structure launch (mtg_solve_multi_any_kernel): items of several configurations
+  int dg = 0;                               // dimensions per workgroup of the launch
+  bool attr_set[4] = {false, false, false, false};
+  int any_units = 1;                        // cross-structure launch: dimension groups per tile (units = ntiles * any_units)
 };
 struct mtg_multi {
   mtg_context* ctx = nullptr;
   std::vector<mtg_multi_item> items;
   std::vector<MtgMultiGroup> groups;
   std::vector<int> singles;                 // items launched through the ordinary path
+  bool concurrent = false;                  // MTG_FLAG_CONCURRENT_ITEMS: singles spread over the context's side streams
+  std::vector<int> lane_of;                 // [singles.size()] side stream of each single (longest-processing-time first)
+  int n_lanes = 0;
 };
 
 int mtg_multi_destroy(mtg_multi* m) {
@@ -815,6 +846,49 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
   if (!m) return MTG_ERR_DEVICE;
   m->ctx = ctx;
   m->items.assign(items, items + n_items);
+  if (flags & MTG_FLAG_CONCURRENT_ITEMS) {
+    // One launch per item, each through the ordinary variant choice, on up to kSideStreams side streams (the HIP runtime
+    // maps a process's streams onto 4 hardware queues: more streams add no overlap).  Longest-processing-time-first
+    // assignment; the work estimate is chain length x N^2 x rounds of tiles.
+    constexpr int kSideStreams = 4;
+    m->concurrent = true;
+    for (int i = 0; i < n_items; ++i)
+      if (items[i].batch > 0) m->singles.push_back(i);
+    auto est = [&](int i) {
+      const mtg_plan* p = items[i].plan;
+      const double rounds = std::max(1.0, (double)items[i].batch * p->D / (64.0 * 4.0 * ctx->n_cu));
+      return (double)p->K * p->N * p->N * rounds;
+    };
+    std::stable_sort(m->singles.begin(), m->singles.end(), [&](int a, int b) { return est(a) > est(b); });
+    m->n_lanes = std::min<int>(kSideStreams, (int)m->singles.size());
+    std::vector<double> load(std::max(1, m->n_lanes), 0.0);
+    for (size_t s = 0; s < m->singles.size(); ++s) {
+      const int i = m->singles[s];
+      int lane = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      for (size_t r = 0; r < s; ++r)   // items of one plan share its workspace: same stream, in order
+        if (items[m->singles[r]].plan == items[i].plan) lane = m->lane_of[r];
+      load[lane] += est(i);
+      m->lane_of.push_back(lane);
+    }
+    while ((int)ctx->side_streams.size() < m->n_lanes) {
+      hipStream_t q = nullptr;
+      hipEvent_t e = nullptr;
+      if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        if (q) hipStreamDestroy(q);
+        delete m;
+        return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: side stream creation failed");
+      }
+      ctx->side_streams.push_back(q);
+      ctx->join_events.push_back(e);
+    }
+    if (!ctx->fork_event && hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming) != hipSuccess) {
+      delete m;
+      return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: event creation failed");
+    }
+    *out = m;
+    return MTG_OK;
+  }
   // group by rolled configuration
   for (int i = 0; i < n_items; ++i) {
     mtg_plan* p = items[i].plan;
@@ -833,6 +907,21 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
     }
     g->items.push_back(i);
   }
+  // Cross-structure merge: groups whose (3-dimensional) rolled configurations are all covered by mtg_solve_multi_any_kernel
+  // become ONE launch (config 4: N = 8, 10 and 12 buckets together) -- streams would not overlap them (see the kernel).
+  {
+    std::vector<size_t> anyable;
+    for (size_t gi = 0; gi < m->groups.size(); ++gi)
+      if (m->groups[gi].entry->d == 3 && mtg_any_cfg_index(m->groups[gi].entry) >= 0) anyable.push_back(gi);
+    if (anyable.size() >= 2) {
+      MtgMultiGroup merged;
+      merged.any = true;
+      merged.entry = m->groups[anyable[0]].entry;
+      for (size_t gi : anyable) merged.items.insert(merged.items.end(), m->groups[gi].items.begin(), m->groups[gi].items.end());
+      for (size_t r = anyable.size(); r-- > 0;) m->groups.erase(m->groups.begin() + anyable[r]);
+      m->groups.push_back(merged);
+    }
+  }
   // a group of one gains nothing from the merged form: leave it to the ordinary path (static variants, heuristics)
   for (size_t gi = 0; gi < m->groups.size();) {
     if (m->groups[gi].items.size() < 2) {
@@ -846,43 +935,60 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
   for (const MtgMultiGroup& g : m->groups)
     for (int i : g.items) total_tiles += (items[i].batch + kWave - 1) / kWave;
   for (MtgMultiGroup& g : m->groups) {
-    const MtgStaticEntry* e = g.entry;
-    const int H = e->h, D = e->d;
-    // tiles, longest chain first
+    const int D = g.entry->d;
+    // tiles, longest chain first (work per tile ~ K N^2)
     std::vector<int> order(g.items.begin(), g.items.end());
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].plan->K > items[b].plan->K; });
+    auto work = [&](int a) { return (long long)items[a].plan->K * items[a].plan->N * items[a].plan->N; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work(a) > work(b); });
+    // few tiles: the one-dimension-per-workgroup form of the same configurations (D x the workgroups, lighter waves)
+    // while all of them are resident at once -- the same rule as for single-plan launches (flags override)
+    const bool want_split = D > 1 && ((flags & MTG_FLAG_SPLIT_DIMS) ||
+                                      (!(flags & MTG_FLAG_FUSED_DIMS) && total_tiles * D <= 4ll * ctx->n_cu));
+    std::vector<const MtgStaticEntry*> ent(order.size());
+    bool split_ok = want_split;
+    for (size_t bi = 0; bi < order.size(); ++bi) {
+      const mtg_plan* p = items[order[bi]].plan;
+      ent[bi] = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+      const MtgStaticEntry* es = want_split ? mtg_find_static(p->H, 1, p->K, p->deriv, p->mask.data(), true) : nullptr;
+      if (!es || !es->multi[0] || (g.any && mtg_any_cfg_index(es) < 0)) split_ok = false;
+    }
+    int Dw = D;
+    if (split_ok) {
+      for (size_t bi = 0; bi < order.size(); ++bi) {
+        const mtg_plan* p = items[order[bi]].plan;
+        ent[bi] = mtg_find_static(p->H, 1, p->K, p->deriv, p->mask.data(), true);
+      }
+      g.entry = ent[0];
+      g.ngroups = D;
+      Dw = 1;
+    }
+    g.dg = Dw;
     std::vector<MtgTileRef> tiles;
     std::vector<MtgParams> table(order.size());
     int kc_max = 1;
+    size_t E = 0;
+    g.lds = 0;
     for (size_t bi = 0; bi < order.size(); ++bi) {
       const mtg_multi_item& it = items[order[bi]];
+      const int H = it.plan->H;
       const int nt = (int)((it.batch + kWave - 1) / kWave);
-      for (int t = 0; t < nt; ++t) tiles.push_back(MtgTileRef{(int)bi, t});
+      const int cfg = g.any ? mtg_any_cfg_index(ent[bi]) : 0;
+      for (int t = 0; t < nt; ++t) tiles.push_back(MtgTileRef{(int)bi, t, cfg});
       kc_max = std::max(kc_max, (it.plan->K + 1) / 2);
       g.extra = g.extra || it.cost != nullptr || (it.d_free != nullptr && it.plan->n_free > 0);
+      E = std::max(E, (size_t)H * H + (size_t)Dw * H);
+      const int fm = H - __builtin_popcount((unsigned)ent[bi]->mi);
+      const size_t stage = (size_t)64 * ((size_t)(Dw * 2 * H / 2) | 1) * 2 * sizeof(double);
+      g.lds = std::max(g.lds, 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + Dw * fm) * kWave * sizeof(double));
     }
     g.ntiles = (int)tiles.size();
-    // few tiles: the one-dimension-per-workgroup form of the same configuration (D x the workgroups, lighter waves, two
-    // per SIMD) while all of them are resident at once -- the same rule as for single-plan launches
-    int Dw = D;
-    {
-      const mtg_plan* p0 = items[order[0]].plan;
-      const MtgStaticEntry* es = D > 1 ? mtg_find_static(H, 1, p0->K, p0->deriv, p0->mask.data(), true) : nullptr;
-      // the split form only while the request's workgroups are all resident at once (flags override)
-      const bool want = (flags & MTG_FLAG_SPLIT_DIMS) ||
-                        (!(flags & MTG_FLAG_FUSED_DIMS) && total_tiles * D <= 4ll * ctx->n_cu);
-      if (es && es->multi[0] && want) {
-        g.entry = es;
-        g.ngroups = D;
-        Dw = 1;
-      }
-    }
     g.grid = std::min(g.ntiles, std::max(1, ctx->n_cu * 4 / g.ngroups));
-    const size_t E = (size_t)H * H + (size_t)Dw * H;
+    if (g.any) {   // one-dimensional grid over (tile, dimension group) units: as many workgroups as are resident at once
+      g.grid = std::min(g.ntiles * g.ngroups, ctx->n_cu * 2);
+      g.any_units = g.ngroups;
+      g.ngroups = 1;
+    }
     const size_t ws_bytes = (size_t)kc_max * E * (size_t)g.grid * g.ngroups * kBlock * sizeof(double);
-    const int fm = H - __builtin_popcount((unsigned)e->mi);
-    const size_t stage = (size_t)64 * ((size_t)(Dw * 2 * H / 2) | 1) * 2 * sizeof(double);
-    g.lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + Dw * fm) * kWave * sizeof(double);
     if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
         hipMalloc((void**)&g.d_table, table.size() * sizeof(MtgParams)) != hipSuccess ||
         hipMalloc((void**)&g.d_tiles, tiles.size() * sizeof(MtgTileRef)) != hipSuccess) {
@@ -917,18 +1023,41 @@ int mtg_multi_solve(mtg_multi* m) {
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (const MtgMultiGroup& g : m->groups) {
+    for (MtgMultiGroup& g : m->groups) {
       for (int i : g.items) {
         const mtg_multi_item& it = m->items[i];
         if (it.cost) MTG_HIP_TRY(ctx, hipMemsetAsync(it.cost, 0, it.batch * sizeof(double), ctx->stream));
       }
       // few tiles: write-through stores (no serial end-of-kernel L2 write-back), as for single-plan launches
-      const bool write_through = (long long)g.ntiles * g.ngroups <= 4ll * ctx->n_cu;
-      SolveMultiFn fn = g.entry->multi[(g.extra ? 1 : 0) + (write_through ? 2 : 0)];
+      const bool write_through = (long long)g.ntiles * g.ngroups * g.any_units <= 4ll * ctx->n_cu;
+      const int variant = (g.extra ? 1 : 0) + (write_through ? 2 : 0);
+      SolveMultiFn fn = g.any ? mtg_multi_any_fn(g.dg, variant) : g.entry->multi[variant];
+      if (g.any && g.lds > 64 * 1024 && !g.attr_set[variant]) {
+        MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        g.attr_set[variant] = true;
+      }
       hipLaunchKernelGGL(fn, dim3(g.grid, g.ngroups), dim3(kBlock), g.lds, ctx->stream, (const MtgParams*)g.d_table,
                          (const MtgTileRef*)g.d_tiles, g.ntiles);
     }
     MTG_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (m->concurrent) {
+    // fork: the side streams start behind the work already queued on the context's stream
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MTG_HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+    for (int l = 0; l < m->n_lanes; ++l) MTG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_streams[l], ctx->fork_event, 0));
+    int rc_all = MTG_OK;
+    for (size_t s = 0; s < m->singles.size() && rc_all == MTG_OK; ++s) {
+      const mtg_multi_item& it = m->items[m->singles[s]];
+      rc_all = solve_impl(it.plan, it.batch, &it.layout, it.times, it.d_fixed, it.coeffs, it.d_free, it.cost, 0, false,
+                          nullptr, nullptr, ctx->side_streams[m->lane_of[s]]);
+    }
+    // join (also after a failed enqueue: the context's stream must not run ahead of what was launched)
+    for (int l = 0; l < m->n_lanes; ++l) {
+      MTG_HIP_TRY(ctx, hipEventRecord(ctx->join_events[l], ctx->side_streams[l]));
+      MTG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_events[l], 0));
+    }
+    return rc_all;
   }
   for (int i : m->singles) {
     const mtg_multi_item& it = m->items[i];
@@ -953,7 +1082,7 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
     for (const LaunchRecord& r : p->last) {
       if (r.dl) {
         r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
-                     r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy);
+                     r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws);
         continue;
       }
       // (the cost accumulators are not re-zeroed between the timed launches: values are irrelevant here, and a memset

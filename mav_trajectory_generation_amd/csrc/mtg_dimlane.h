@@ -79,7 +79,8 @@ template <class C, int DL, int NP, int OUT, int AUX>
 __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
                                                                             const double* __restrict__ dfix,
                                                                             double* __restrict__ coeffs, int* status,
-                                                                            int* traj_status, int B, int ntiles, int nwg
+                                                                            int* traj_status, int B, int ntiles, int nwg,
+                                                                            double* ws
 #if defined(MTG_LAB_TIMING)
                                                                             , long long* tdbg_base
 #endif
@@ -103,7 +104,9 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
   P.dfix = dfix; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)C::offFEnd * B;
   P.coeffs = coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
-  P.cost = nullptr; P.ws = nullptr; P.ws_stride = 0;
+  P.cost = nullptr; P.ws = ws; P.ws_stride = (long long)nwg * (NP * 2 * kWave);
+  double* wsl0 = C::WSJ > 0 ? ws + (size_t)blockIdx.x * (NP * 2 * kWave) + threadIdx.x : nullptr;   // long chains (C::WSJ): this lane's workspace column
+  P.ws_share = (long long)t - lane;   // (dup lanes: their clamped trajectory's columns)
   P.status = status; P.tstatus = traj_status;
   P.vmask = nullptr; P.offF = nullptr; P.offP = nullptr;
   P.B = B; P.K = C::KT; P.Dtot = DL; P.dim0 = d;   // dim0 is a per-lane value here
@@ -148,18 +151,23 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
     const long long b = bl < B ? bl : B - 1;
     const bool first = it == (int)blockIdx.x;
     if (!first) fetch(tile);
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, nullptr, false);
-    else mtg_lane_forward<C, -1>(P, b, ln, nullptr, false);
+    // the workspace column pointer is re-defined opaquely per tile: otherwise every one of the ~(f*f + f) * WSJ store and
+    // load addresses derived from it is loop-invariant, gets hoisted out of the tile loop and spills (measured: 233
+    // scratch stores in the prologue of the K = 32 kernel)
+    double* wsl = wsl0;
+    if constexpr (C::WSJ > 0) asm volatile("" : "+v"(wsl));
+    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, false);
+    else mtg_lane_forward<C, -1>(P, b, ln, wsl, false);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
     MTG_DL_STAMP(2);
     __syncthreads();
     MTG_DL_STAMP(3);
     if (dir == 0) {
       ioA.begin_tile(coeffs, b0, B);
-      mtg_lane_finish<C, 1, OUT>(P, b, ln, nullptr, other, kWave, ioA, active);
+      mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active);
     } else {
       ioB.begin_tile(coeffs, b0, B);
-      mtg_lane_finish<C, -1, OUT>(P, b, ln, nullptr, other, kWave, ioB, active);
+      mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active);
     }
 #if defined(MTG_LAB_TIMING)
     MTG_DL_STAMP(4);

@@ -5,7 +5,7 @@
 namespace {
 template <class C, int DL, int NP>
 int launch_dl(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
-              int* traj_status, int B, int ntiles, int policy) {
+              int* traj_status, int B, int ntiles, int policy, double* ws) {
   constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
   static bool attr_set[3] = {false, false, false};
   hipStream_t st = (hipStream_t)stream;
@@ -15,7 +15,7 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
       attr_set[slot] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid, ws);
     return 0;
   };
   if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
@@ -24,12 +24,16 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
 }
 }  // namespace
 
-#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) \
-  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>(), launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV>, DL, NP>},
+#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS)                                                     \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>, DL, NP>(), \
+   (size_t)MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>::WSJ * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>::WSE * sizeof(double),  \
+   launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>, DL, NP>},
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include "mtg_dimlane_variants.inc"
 };
 #undef MTG_DL
+#undef MTG_DLW
 
 const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask) {
   for (const MtgDimlaneEntry& e : kDimlaneTable) {

@@ -303,40 +303,72 @@ __global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, 
 // longest chain), `tiles[t]` names the bucket and the tile inside it; the host sorts tiles longest-chain-first so that
 // the short ones fill in behind the long ones.  One launch instead of one per bucket: a 2500-trajectory bucket is 40
 // tiles, far too few to fill 256 CUs, and back-to-back launches each pay their own latency chain.
-struct MtgTileRef { int bucket, tile; };
+struct MtgTileRef { int bucket, tile, cfg; };   // cfg: configuration index inside a cross-structure launch (mtg_solve_multi_any_kernel)
 
+// one tile of a multi-plan launch (both waves of the workgroup; ends with a workgroup barrier: the LDS is free again)
 template <class C, int OUT>
-__global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_multi_kernel(const MtgParams* __restrict__ table,
-                                                                                         const MtgTileRef* __restrict__ tiles,
-                                                                                         int ntiles) {
+__device__ __forceinline__ void mtg_multi_tile(const MtgParams* __restrict__ table, const MtgTileRef ref, double* lds,
+                                               int lane, int dir, int dimgroup, long long wg_linear) {
   static_assert(C::kRolled, "multi-plan launches use the rolled (run-time K) configurations");
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int dir = threadIdx.x >> 6;  // wave-uniform
   constexpr int kFreeMid = C::H - C::popc(C::MI);                     // the middle vertex is an interior one
   constexpr int nslots = kFreeMid * (kFreeMid + 1) / 2 + C::D * kFreeMid;
   double* xch = lds + 2 * mtg_stage_doubles<C>();
   double* mine = xch + (size_t)dir * nslots * kWave + lane;
   const double* other = xch + (size_t)(1 - dir) * nslots * kWave + lane;
   MtgLane<C> ln;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const MtgTileRef ref = tiles[t];
-    MtgParams P = table[ref.bucket];
-    P.dim0 += (int)blockIdx.y * C::D;   // grid.y = dimension groups, as in mtg_solve_kernel
-    double* wsl = P.ws + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x);
-    MtgLdsOut<C, (OUT & 4) != 0> io;
-    io.init(P, lds + (size_t)dir * mtg_stage_doubles<C>(), lane);
-    io.b0 = (long long)ref.tile * kWave;
-    const long long bl = io.b0 + lane;
-    const bool active = bl < P.B;
-    const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, true);
-    else mtg_lane_forward<C, -1>(P, b, ln, wsl, true);
-    mtg_pack_mid<C>(ln, C::MI, mine, kWave);
-    __syncthreads();
-    if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, io, active);
-    else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, io, active);
-    __syncthreads();
+  MtgParams P = table[ref.bucket];
+  P.dim0 += dimgroup * C::D;
+  double* wsl = P.ws + (wg_linear * kBlock + threadIdx.x);
+  MtgLdsOut<C, (OUT & 4) != 0> io;
+  io.init(P, lds + (size_t)dir * mtg_stage_doubles<C>(), lane);
+  io.b0 = (long long)ref.tile * kWave;
+  const long long bl = io.b0 + lane;
+  const bool active = bl < P.B;
+  const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
+  if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, true);
+  else mtg_lane_forward<C, -1>(P, b, ln, wsl, true);
+  mtg_pack_mid<C>(ln, C::MI, mine, kWave);
+  __syncthreads();
+  if (dir == 0) mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+  else mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, io, active);
+  __syncthreads();
+}
+
+template <class C, int OUT>
+__global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_multi_kernel(const MtgParams* __restrict__ table,
+                                                                                         const MtgTileRef* __restrict__ tiles,
+                                                                                         int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int dir = threadIdx.x >> 6;  // wave-uniform
+  // grid.y = dimension groups, as in mtg_solve_kernel
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x)
+    mtg_multi_tile<C, OUT>(table, tiles[t], lds, lane, dir, (int)blockIdx.y, (long long)blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// Cross-structure launch: the buckets of a mixed request differ in N as well (BASELINE config 4: N in {8, 10, 12}).  Streams
+// do not help here -- measured on this runtime (tools/micro/stream_overlap.hip): kernels on different HIP streams overlap
+// two at a time at best, a fork/join over events costs ~23 us of device time and ~10 us of host time per stream -- so
+// the whole request is ONE launch: every tile carries the index of its (rolled) configuration and the workgroup
+// branches (wave-uniformly) into that configuration's code.  DG = dimensions per workgroup (3: fused, 1: split form).
+// One-dimensional grid of persistent workgroups over the (tile, dimension group) units, dimension fastest: the units are
+// sorted longest-chain-first, so every workgroup's first unit is a long one and the short ones fill in behind (with
+// dimension groups in grid.y the second round of workgroups would start with long chains again).
+template <int DG, int OUT>
+__global__ __launch_bounds__(kBlock, 1) void mtg_solve_multi_any_kernel(const MtgParams* __restrict__ table,
+                                                                        const MtgTileRef* __restrict__ tiles, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int dir = threadIdx.x >> 6;  // wave-uniform
+  constexpr int NG = 3 / DG;         // dimension groups of a 3-dimensional plan
+  for (int u = blockIdx.x; u < ntiles * NG; u += gridDim.x) {
+    const MtgTileRef ref = tiles[u / NG];
+    const int dg = u % NG;
+    switch (__builtin_amdgcn_readfirstlane(ref.cfg)) {   // the configurations of mtg_any_cfg_index, same order
+      case 0: mtg_multi_tile<MtgCfg<4, DG, -1, 15, 1, 15, 3>, OUT>(table, ref, lds, lane, dir, dg, blockIdx.x); break;
+      case 1: mtg_multi_tile<MtgCfg<5, DG, -1, 31, 1, 31, 4>, OUT>(table, ref, lds, lane, dir, dg, blockIdx.x); break;
+      default: mtg_multi_tile<MtgCfg<6, DG, -1, 63, 1, 63, 5>, OUT>(table, ref, lds, lane, dir, dg, blockIdx.x); break;
+    }
   }
 }
 
@@ -388,11 +420,16 @@ struct MtgDimlaneEntry {
   int tpw;            // trajectories per wave (64 / dl)
   int lo_per_cu, hi_per_cu;   // default form while lo * CUs <= workgroups <= hi * CUs (hi = 0: no upper limit)
   size_t lds;         // dynamic LDS per workgroup
+  size_t ws_per_lane; // long-chain variants (MtgCfg::WSJ > 0): workspace bytes per resident lane (grid * np * 128 lanes), else 0
   // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
   // cache policy (0 nt sc1, 1 sc1, 2 write-back); returns 0 or -1 (attribute / launch set-up failed)
   int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
-                int* traj_status, int B, int ntiles, int policy);
+                int* traj_status, int B, int ntiles, int policy, double* ws);
 };
+// cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
+// dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])
+int mtg_any_cfg_index(const MtgStaticEntry* e);
+SolveMultiFn mtg_multi_any_fn(int dg, int variant);
 const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask);
 
 #endif  // MTG_KERNELS_H_

@@ -42,6 +42,8 @@ struct MtgParams {
   double* dfree;        long long ps_b, ps_d, ps_c; // optional output (solve) / input (update)
   double* cost;                                     // optional, pre-zeroed, atomically accumulated
   double* ws;           long long ws_stride;        // generic mode back-substitution store
+  long long ws_share;   // dimension-in-lane long chains (MtgCfg::DLW): element offset from a lane's own workspace column to
+                        // the column of its trajectory's dimension-0 lane
   int* status;                                      // OR of MTG_FLAG_* over the batch
   int* tstatus;                                     // optional [B]: OR of MTG_FLAG_* per trajectory (pre-zeroed)
   const int* vmask;                                 // [K+1] fixed masks        (generic mode)
@@ -75,7 +77,7 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
-template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0>
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0>
 struct MtgCfg {
   // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
   // instantiations carry that code
@@ -92,10 +94,23 @@ struct MtgCfg {
   static constexpr int H1OFF = mtg_h1_offset(2 * H_, DV_), AINVOFF = mtg_ainv_offset(2 * H_);
   static constexpr int MS = MS_, MI = MI_, ME = ME_;
   static constexpr int KA = (KT_ + 1) / 2, KB = KT_ / 2;
+  static constexpr int popc(int x) { int c = 0; for (; x; x &= x - 1) ++c; return c; }
   static constexpr int KCS = kStatic ? ((KT_ + 1) / 2) : 1;
+  // WS_ > 0 (static mode, long chains): the back-substitution data of the first WS_ steps of each half-chain (the ones
+  // consumed LAST) go through the lane-coalesced global workspace, the remaining steps' stay in registers -- a K = 32
+  // half-chain (16 steps x (f*f + D*f) doubles) does not fit the 512-register budget, its second half does.
+  static constexpr int WSJ = kStatic ? WS_ : 0;
+  static constexpr int KREG = (KCS - WSJ) > 0 ? KCS - WSJ : 1;
+  static constexpr int FMAXW = H_ - (popc(MS_) < popc(MI_) ? (popc(MS_) < popc(ME_) ? popc(MS_) : popc(ME_))
+                                                           : (popc(MI_) < popc(ME_) ? popc(MI_) : popc(ME_)));
+  // DLW_ > 0 (dimension-in-lane form, D_ == 1): the DLW_ dimension lanes of a trajectory compute identical G; each stores
+  // every DLW_-th element (one row of the workspace holds DLW_ consecutive elements, one per dimension lane) and reads
+  // the others from its sibling lanes' columns: 1/DLW_ of the G traffic.  g stays per lane.
+  static constexpr int DLW = kStatic ? DLW_ : 0;
+  static constexpr int WSE = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW + FMAXW
+                                     : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
   static constexpr int FULL = (1 << H_) - 1;
   // static mode: fixed-slot column prefix and the column range each direction touches
-  static constexpr int popc(int x) { int c = 0; for (; x; x &= x - 1) ++c; return c; }
   static constexpr int offF(int v) { return v == 0 ? 0 : popc(MS_) + (v - 1) * popc(MI_); }
   static constexpr int offFEnd = kStatic ? offF(KT_) + popc(ME_) : 0;
   static constexpr int colBeginA = 0, colEndA = kStatic ? offF(KA + 1 > KT_ ? KT_ : KA + 1) + (KA + 1 > KT_ ? popc(ME_) : 0) : 0;
@@ -214,8 +229,8 @@ template <int DIR> MTG_HD int mtg_vr(int K, int j) { return DIR > 0 ? j + 1 : K 
 
 template <class C>
 struct MtgLane {
-  double G[C::KCS][C::H][C::H];   // G_v = Dtilde_v^-1 U_v          (static mode: registers)
-  double g[C::KCS][C::D][C::H];   // g_v = Dtilde_v^-1 rtilde_v
+  double G[C::KREG][C::H][C::H];  // G_v = Dtilde_v^-1 U_v          (static mode: registers; steps >= C::WSJ)
+  double g[C::KREG][C::D][C::H];  // g_v = Dtilde_v^-1 rtilde_v
   double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
   double rc[C::D][C::H];          // its right-hand side
   double T[C::KCS];               // static mode: this lane's segment times, chain order
@@ -919,6 +934,87 @@ MTG_HD void mtg_ws_load(const double* w, long long stride, double (&G)[C::H][C::
   }
 }
 
+// Shared-G workspace layout (MtgCfg::DLW lanes per trajectory, lane = dim * TPW + trajectory; C::D == 1): row r of a step
+// holds G's free elements DLW*r .. DLW*r + DLW-1 (traversal order), element DLW*r + k in the column of dimension lane k.
+template <int DL>
+MTG_HD double mtg_pick(int d, const double (&c)[DL]) {
+  double v = c[0];
+#pragma unroll
+  for (int k = 1; k < DL; ++k) {
+    int hit = d == k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque flag: otherwise the select chain is canonicalised into a dynamically indexed load from a private array of
+    // the candidates (scratch store + load per workspace row)
+    asm volatile("" : "+v"(hit));
+#endif
+    v = hit ? c[k] : v;
+  }
+  return v;
+}
+template <class C>
+MTG_HD void mtg_ws_store_shared(double* w, long long stride, int d, const double (&G)[C::H][C::H],
+                                const double (&g)[C::D][C::H], int ml, int mr) {
+  constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1;
+  double cand[DL];
+  int cnt = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    if ((ml >> p) & 1) continue;
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      if ((mr >> q) & 1) continue;
+      cand[cnt % DL] = G[p][q];
+      ++cnt;
+      if (cnt % DL == 0) {
+        *w = mtg_pick<DL>(d, cand);
+        w += stride;
+      }
+    }
+  }
+  if (cnt % DL != 0) {   // last, partial row: the lanes beyond it store a duplicate that is never read
+#pragma unroll
+    for (int k = 1; k < DL; ++k)
+      if (k >= cnt % DL) cand[k] = cand[0];
+    *w = mtg_pick<DL>(d, cand);
+    w += stride;
+  }
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    if ((ml >> p) & 1) continue;
+    *w = g[0][p];
+    w += stride;
+  }
+}
+// w: this lane's own column; share: element offset to the trajectory's dimension-0 column; TPW lanes between dimension columns
+template <class C>
+MTG_HD void mtg_ws_load_shared(const double* w, long long stride, long long share, double (&G)[C::H][C::H],
+                               double (&g)[C::D][C::H], int ml, int mr) {
+  constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1, TPW = 64 / DL;
+  const double* col[DL];
+#pragma unroll
+  for (int k = 0; k < DL; ++k) col[k] = w + share + k * TPW;
+  int cnt = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      G[p][q] = 0.0;
+      if (((ml >> p) & 1) || ((mr >> q) & 1)) continue;
+      G[p][q] = *col[cnt % DL];
+      col[cnt % DL] += stride;
+      ++cnt;
+    }
+  }
+  const double* wg = w + (long long)((cnt + DL - 1) / DL) * stride;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    g[0][p] = 0.0;
+    if ((ml >> p) & 1) continue;
+    g[0][p] = *wg;
+    wg += stride;
+  }
+}
+
 // ---- whole-lane phases -----------------------------------------------------------------
 // wsl: this lane's slab of the generic-mode workspace (element stride P.ws_stride)
 // do_preload = false: the caller already filled ln.T / ln.fx (the kernel prefetches the next tile's inputs
@@ -955,8 +1051,16 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
       // being hoisted in front of all chains.
       if (j + 1 < KC) asm("" : "+v"(ln.T[j + 1]) : "v"(ln.Sc[H - 1][H - 1]));
 #endif
-      mtg_fwd_step<C, DIR>(P, b, j, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)), ln,
-                           ln.G[j], ln.g[j]);
+      const int ml = mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j));
+      if (j < C::WSJ) {
+        double G[H][H], g[D][H];
+        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
+        if constexpr (C::DLW > 0) mtg_ws_store_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.dim0, G, g, ml, mr);
+        else mtg_ws_store<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, G, g, ml, mr);
+      } else {
+        constexpr int JR0 = C::WSJ;
+        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, ln.G[j < JR0 ? 0 : j - JR0], ln.g[j < JR0 ? 0 : j - JR0]);
+      }
     }
   } else {
     const int K = P.K;
@@ -1026,10 +1130,31 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   double cost = 0.0;
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
+    // steps below C::WSJ: (G, g) come back from the workspace, requested one step ahead -- right after the previous
+    // step's back-substitution and BEFORE its coefficient stores (loads and stores retire through one in-order counter)
+    double Gw[H][H], gw[D][H];
+    auto request = [&](int j) {
+      if constexpr (C::DLW > 0)
+        mtg_ws_load_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.ws_share, Gw, gw,
+                              mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
+      else
+        mtg_ws_load<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
+                       mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
+    };
+    if (C::WSJ > 0 && KC <= C::WSJ) request(KC - 1);
 #pragma unroll
     for (int j = KC - 1; j >= 0; --j) {
-      cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)),
-                                        ln, ln.G[j], ln.g[j], xr, io, active);
+      const int ml = mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j));
+      if constexpr (C::WSJ > 0) {
+        double fix_l[D][H], xl[D][H];
+        mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(C::KT, j), ml, ln, fix_l);
+        if (j < C::WSJ) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, gw, xr, xl);
+        else mtg_bwd_backsub<C>(ml, mr, fix_l, ln.G[j - C::WSJ < 0 ? 0 : j - C::WSJ], ln.g[j - C::WSJ < 0 ? 0 : j - C::WSJ], xr, xl);
+        if (j >= 1 && j - 1 < C::WSJ) request(j - 1);
+        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
+      } else {
+        cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);
+      }
 #if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
       if (tdo && j < 8) tdbg[7 + j] = clock64();
 #endif

@@ -45,6 +45,21 @@ const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int*
   return nullptr;
 }
 
+int mtg_any_cfg_index(const MtgStaticEntry* e) {
+  if (!e || e->k >= 0 || (e->d != 1 && e->d != 3) || e->mi != 1) return -1;
+  if (e->h == 4 && e->ms == 15 && e->me == 15 && e->dv == 3) return 0;
+  if (e->h == 5 && e->ms == 31 && e->me == 31 && e->dv == 4) return 1;
+  if (e->h == 6 && e->ms == 63 && e->me == 63 && e->dv == 5) return 2;
+  return -1;
+}
+SolveMultiFn mtg_multi_any_fn(int dg, int variant) {
+  static const SolveMultiFn fused[4] = {mtg_solve_multi_any_kernel<3, 0>, mtg_solve_multi_any_kernel<3, 3>,
+                                        mtg_solve_multi_any_kernel<3, 4>, mtg_solve_multi_any_kernel<3, 7>};
+  static const SolveMultiFn split[4] = {mtg_solve_multi_any_kernel<1, 0>, mtg_solve_multi_any_kernel<1, 3>,
+                                        mtg_solve_multi_any_kernel<1, 4>, mtg_solve_multi_any_kernel<1, 7>};
+  return dg == 3 ? fused[variant & 3] : dg == 1 ? split[variant & 3] : nullptr;
+}
+
 // Slab-output instantiations of the fused form (mtg_solve_slab_kernel): the shapes that run large batches.
 #define MTG_SLAB(H, D, K, MS, MI, ME, DV)                                              \
   {H, D, K, MS, MI, ME, DV, mtg_slab_lds_bytes<MtgCfg<H, D, K, MS, MI, ME, DV>>(),      \
@@ -55,6 +70,7 @@ static const MtgSlabEntry kSlabTable[] = {
     MTG_SLAB(4, 3, 8, 15, 1, 15, 3)
     MTG_SLAB(5, 3, 4, 31, 1, 31, 4)
     MTG_SLAB(4, 3, 4, 15, 1, 15, 3)
+    MTG_SLAB(6, 3, 4, 63, 1, 63, 5)
 };
 #undef MTG_SLAB
 

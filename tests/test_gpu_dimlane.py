@@ -41,7 +41,8 @@ def to_soa(times, d_fixed):
 # (N, K, D, derivative, interior mask): the shapes of csrc/mtg_dimlane_variants.inc
 SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 4, 3, 4, 1), (10, 2, 3, 4, 1), (8, 4, 3, 3, 1),
           (8, 8, 3, 3, 1), (12, 4, 3, 5, 1), (12, 8, 3, 5, 1), (10, 16, 4, 4, 7),
-          (8, 16, 3, 3, 1), (10, 16, 3, 4, 1)]     # register-resident K = 16 chains
+          (8, 16, 3, 3, 1), (10, 16, 3, 4, 1),     # register-resident K = 16 chains
+          (10, 32, 3, 4, 1), (8, 32, 3, 3, 1), (12, 16, 3, 5, 1), (12, 32, 3, 5, 1)]   # long chains: registers + workspace (MtgCfg::WSJ)
 
 
 # shapes that also have a one-dimension-per-workgroup static variant (csrc/mtg_variants.inc): same instruction stream per lane

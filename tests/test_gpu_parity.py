@@ -337,8 +337,8 @@ def test_mixed_batch_streams_and_graph_replay(ctx):
 
 
 def test_merged_mixed_request(ctx):
-    """mtg_multi_*: buckets that share N, D, masks pattern and derivative run as ONE launch (config 4: 3 launches instead
-    of 12).  Results must equal the per-bucket launches bit for bit -- eager, replayed from a hipGraph, with cost and d_P
+    """mtg_multi_*: buckets that share N, D, masks pattern and derivative run as ONE launch, and the N = 8 / 10 / 12 groups
+    join one cross-structure launch (config 4: 1 launch instead of 12).  Results must equal the per-bucket launches bit for bit -- eager, replayed from a hipGraph, with cost and d_P
     outputs, with an un-mergeable item (ragged masks -> ordinary path) and a single-item group in the same request."""
     import torch
     import mav_trajectory_generation_amd as m
@@ -359,7 +359,7 @@ def test_merged_mixed_request(ctx):
     one.sync()
     solver = m.MixedBatchSolver(ctx, n_streams=3)
     req = solver.merged(buckets, want_cost=True)
-    assert req.launch_count == 3 + 2            # three merged groups + the two ordinary launches
+    assert req.launch_count == 1 + 2            # one cross-structure launch (N = 8, 10, 12) + the two ordinary launches
     got = req.solve()
     torch.cuda.synchronize()
     solver.sync()
@@ -549,3 +549,48 @@ def test_mellinger_cost_gradient_entry(ctx, n, d, k, dim, masks, bsz, layout):
     if k == 1:
         assert np.all(got == 0.0)
     plan.close()
+
+
+def test_concurrent_mixed_request(ctx):
+    """mtg_multi_* with MTG_FLAG_CONCURRENT_ITEMS: one C call enqueues every bucket as its own best launch on the
+    context's side streams (fork / join on the context's stream).  Results equal the per-bucket launches bit for bit --
+    eager, repeated back to back, with cost outputs, two items of one plan, and after new values in the input buffers."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    buckets = []
+    for (n, d) in ((8, 3), (10, 4), (12, 5)):
+        for k in (4, 8, 16, 32):
+            masks = m.ends_full_masks(n, k)
+            t, f = m.random_waypoint_batch(700, k, 3, n, masks, seed=100 * n + k, device="cuda", layout="soa")
+            buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
+    masks = m.ends_full_masks(10, 8)      # a second bucket of an existing structure: shares the plan (and its workspace)
+    t, f = m.random_waypoint_batch(300, 8, 3, 10, masks, seed=5, device="cuda", layout="soa")
+    buckets.append(dict(n_coeffs=10, derivative=4, masks=masks, times=t, d_fixed=f, layout="soa"))
+    one = m.MixedBatchSolver(ctx, n_streams=1)
+    for want_cost in (False, True):
+        ref = [(c.clone(), None if j is None else j.clone()) for c, j in one.solve_device(buckets, want_cost=want_cost)]
+        torch.cuda.synchronize()
+        one.sync()
+        solver = m.MixedBatchSolver(ctx, n_streams=1)
+        req = solver.concurrent(buckets, want_cost=want_cost)
+        assert req.launch_count == len(buckets)
+        for _ in range(3):
+            got = req.solve()
+        torch.cuda.synchronize()
+        solver.sync()
+        for (c, j), (c0, j0) in zip(got, ref):
+            assert torch.equal(c, c0)
+            if want_cost:
+                assert torch.allclose(j, j0, rtol=1e-12)
+        for c, _ in req.out:
+            c.zero_()
+        for b in buckets:
+            b["times"].mul_(1.07)
+        req.solve()
+        fresh = one.solve_device(buckets, want_cost=want_cost)
+        torch.cuda.synchronize()
+        for (c, j), (c1, j1) in zip(req.out, fresh):
+            assert torch.equal(c, c1)
+        req.close()
+        solver.close()
+    one.close()

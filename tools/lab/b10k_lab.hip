@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
     auto go = [=, &dt, &df, &dc](int i) {
       const int s = i % NSETS;
       hipLaunchKernelGGL(kern, dim3(nwg_dl), dim3(256), lds_dl, st, (const double*)dt[s], (const double*)df[s], dc[s],
-                         dstat, (int*)nullptr, B, ntiles_dl, nwg_dl
+                         dstat, (int*)nullptr, B, ntiles_dl, nwg_dl, (double*)nullptr
 #if defined(MTG_LAB_TIMING)
                          , dbg
 #endif
