@@ -808,8 +808,16 @@ struct MtgMultiGroup {
   bool attr_set[4] = {false, false, false, false};
   int any_units = 1;                        // cross-structure launch: dimension groups per tile (units = ntiles * any_units)
 };
+struct MtgDlAnyGroup {                      // cross-structure dimension-in-lane launch (mtg_solve_dl_any_kernel)
+  std::vector<int> items;
+  MtgDlAnyItem* d_items = nullptr;
+  MtgDlAnyUnit* d_units = nullptr;
+  double* d_ws = nullptr;
+  int nunits = 0, grid = 0;
+};
 struct mtg_multi {
   mtg_context* ctx = nullptr;
+  MtgDlAnyGroup dl_any;
   std::vector<mtg_multi_item> items;
   std::vector<MtgMultiGroup> groups;
   std::vector<int> singles;                 // items launched through the ordinary path
@@ -822,6 +830,9 @@ int mtg_multi_destroy(mtg_multi* m) {
   if (!m) return MTG_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
+  if (m->dl_any.d_items) hipFree(m->dl_any.d_items);
+  if (m->dl_any.d_units) hipFree(m->dl_any.d_units);
+  if (m->dl_any.d_ws) hipFree(m->dl_any.d_ws);
   for (MtgMultiGroup& g : m->groups) {
     if (g.d_table) hipFree(g.d_table);
     if (g.d_tiles) hipFree(g.d_tiles);
@@ -889,8 +900,59 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
     *out = m;
     return MTG_OK;
   }
-  // group by rolled configuration
+  // Items that can run their static dimension-in-lane configuration (canonical SoA inputs, coefficient output only) join
+  // ONE cross-structure launch (mtg_solve_dl_any_kernel), whatever their N and K: back-substitution data in registers
+  // instead of the rolled kernels' workspace traffic.
+  std::vector<char> taken(n_items, 0);
+  if (!(flags & (MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_GENERIC_KERNEL)) && !ctx->knob_no_dimlane) {
+    std::vector<int> cand;
+    for (int i = 0; i < n_items; ++i) {
+      const mtg_multi_item& it = items[i];
+      const mtg_plan* p = it.plan;
+      if (it.batch <= 0 || it.cost || (it.d_free && p->n_free > 0) || mtg_dl_any_index(p->dimlane) < 0) continue;
+      const mtg_layout& L = it.layout;
+      if (L.times_stride_b != 1 || L.times_stride_k != it.batch) continue;
+      if (L.fixed_stride_b != 1 || L.fixed_stride_c != it.batch || L.fixed_stride_d != (int64_t)p->n_fixed * it.batch) continue;
+      if (it.batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) continue;
+      cand.push_back(i);
+    }
+    if (cand.size() >= 2) {
+      MtgDlAnyGroup& g = m->dl_any;
+      auto work = [&](int a) { return (long long)items[a].plan->K * items[a].plan->N * items[a].plan->N; };
+      std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return work(a) > work(b); });
+      g.items = cand;
+      std::vector<MtgDlAnyItem> table(cand.size());
+      std::vector<MtgDlAnyUnit> units;
+      for (size_t bi = 0; bi < cand.size(); ++bi) {
+        const mtg_multi_item& it = items[cand[bi]];
+        taken[cand[bi]] = 1;
+        const int tpw = it.plan->dimlane->tpw;
+        table[bi] = MtgDlAnyItem{it.times, it.d_fixed, it.coeffs, (int)it.batch, mtg_dl_any_index(it.plan->dimlane)};
+        const int nt = (int)((it.batch + tpw - 1) / tpw);
+        for (int t = 0; t < nt; ++t) units.push_back(MtgDlAnyUnit{(int)bi, t});
+      }
+      g.nunits = (int)units.size();
+      g.grid = std::min(g.nunits, ctx->n_cu * 2);      // two 2-wave workgroups per CU: one wave per SIMD
+      // workgroup w takes units w, w + grid, w + 2 grid, ...: every second round is reversed, so the workgroups that started
+      // with the longest chains continue with the shortest ones of the next round
+      for (size_t r = 1; r * (size_t)g.grid < units.size(); r += 2) {
+        const size_t lo = r * (size_t)g.grid, hi = std::min(units.size(), lo + (size_t)g.grid);
+        if (hi - lo == (size_t)g.grid) std::reverse(units.begin() + lo, units.begin() + hi);
+      }
+      const size_t ws_bytes = std::max<size_t>(16, mtg_dl_any_ws_per_lane() * (size_t)g.grid * 2 * kWave);
+      if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
+          hipMalloc((void**)&g.d_items, table.size() * sizeof(MtgDlAnyItem)) != hipSuccess ||
+          hipMalloc((void**)&g.d_units, units.size() * sizeof(MtgDlAnyUnit)) != hipSuccess ||
+          hipMemcpy(g.d_items, table.data(), table.size() * sizeof(MtgDlAnyItem), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(g.d_units, units.data(), units.size() * sizeof(MtgDlAnyUnit), hipMemcpyHostToDevice) != hipSuccess) {
+        mtg_multi_destroy(m);
+        return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: device allocation failed");
+      }
+    }
+  }
+  // group the others by rolled configuration
   for (int i = 0; i < n_items; ++i) {
+    if (taken[i]) continue;
     mtg_plan* p = items[i].plan;
     const MtgStaticEntry* e = (items[i].batch > 0 && p->K >= 2)
                                   ? mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true) : nullptr;
@@ -1015,7 +1077,9 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
   return MTG_OK;
 }
 
-int mtg_multi_launch_count(const mtg_multi* m) { return m ? (int)(m->groups.size() + m->singles.size()) : 0; }
+int mtg_multi_launch_count(const mtg_multi* m) {
+  return m ? (int)(m->groups.size() + m->singles.size() + (m->dl_any.nunits > 0 ? 1 : 0)) : 0;
+}
 
 int mtg_multi_solve(mtg_multi* m) {
   if (!m) return MTG_ERR_INVALID_ARGUMENT;
@@ -1023,6 +1087,11 @@ int mtg_multi_solve(mtg_multi* m) {
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (m->dl_any.nunits > 0) {
+      const MtgDlAnyGroup& g = m->dl_any;
+      if (mtg_dl_any_launch((void*)ctx->stream, g.grid, g.d_items, g.d_units, g.nunits, ctx->d_status, g.d_ws) != 0)
+        return set_err(ctx, MTG_ERR_DEVICE, "cross-structure dimension-in-lane launch set-up failed");
+    }
     for (MtgMultiGroup& g : m->groups) {
       for (int i : g.items) {
         const mtg_multi_item& it = m->items[i];

@@ -177,4 +177,108 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
     __syncthreads();
   }
 }
+
+// ---- cross-structure launch: the buckets of a mixed request (BASELINE config 4: N in {8, 10, 12} x K in {4, 8, 16, 32}) in ONE
+// launch, each unit (one tile = 64 / DL trajectories, both chain directions) running its own static configuration.  The
+// rolled (run-time K) merged launches stream every step's back-substitution data through the workspace and are bound by
+// that traffic (30k trajectories: ~310 MB at ~3.5 TB/s); the static bodies keep it in registers.  Streams are no
+// alternative on this runtime (tools/micro/stream_overlap.hip: two kernels overlap at best).
+// one unit; workgroup = 2 waves (direction A / B) of one tile.  lds: the workgroup's dynamic LDS (>= mtg_dl_pair_bytes<C, DL>()).
+template <class C, int DL, int AUX>
+__device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile, int* status, double* wsl0, long long ws_stride,
+                                                char* lds_raw) {
+  constexpr int TPW = kWave / DL;
+  // the lane index is re-defined opaquely per unit: everything derived from it (lane -> (dimension, trajectory), the slab's
+  // address maps) would otherwise be loop-invariant, hoisted in front of the unit loop for all twelve bodies at once and
+  // spilled (measured: 855 spilled registers)
+  int lane = threadIdx.x & (kWave - 1);
+  asm volatile("" : "+v"(lane));
+  const int dir = threadIdx.x >> 6;    // wave-uniform
+  int d = lane / TPW, t = lane - d * TPW;
+  const bool dup = d >= DL;
+  if (dup) { d = DL - 1; t = TPW - 1; }
+  const int B = it.B;
+  MtgParams P;
+  P.times = it.times; P.ts_b = 1; P.ts_k = B;
+  P.dfix = it.dfix; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)C::offFEnd * B;
+  P.coeffs = it.coeffs;
+  P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
+  P.cost = nullptr; P.ws = nullptr; P.ws_stride = ws_stride;
+  P.ws_share = (long long)t - lane;
+  P.status = status; P.tstatus = nullptr;
+  P.vmask = nullptr; P.offF = nullptr; P.offP = nullptr;
+  P.B = B; P.K = C::KT; P.Dtot = DL; P.dim0 = d;
+  P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
+  P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
+  MtgLane<C> ln;
+  const long long b0 = (long long)tile * TPW;
+  const long long bl = b0 + t;
+  const bool active = bl < B && !dup;
+  const long long b = bl < B ? bl : B - 1;
+  if (dir == 0) mtg_dl_preload<C, 1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
+  else mtg_dl_preload<C, -1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
+  constexpr int mm = C::MI;
+  constexpr size_t half = mtg_dl_pair_bytes<C, DL>() / 2;
+  char* my_slab = lds_raw + (size_t)dir * half;
+  double* mine = reinterpret_cast<double*>(lds_raw + (size_t)(1 - dir) * half) + lane;
+  const double* other = reinterpret_cast<const double*>(my_slab) + lane;
+  double* wsl = wsl0;
+  if constexpr (C::WSJ > 0) asm volatile("" : "+v"(wsl));
+  if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, false);
+  else mtg_lane_forward<C, -1>(P, b, ln, wsl, false);
+  mtg_pack_mid<C>(ln, mm, mine, kWave);
+  __syncthreads();
+  if (dir == 0) {
+    MtgSlabOut<C, DL, 1, AUX> io;
+    io.init(my_slab, lane, t, d);
+    io.begin_tile(it.coeffs, b0, B);
+    mtg_lane_finish<C, 1, 0>(P, b, ln, wsl, other, kWave, io, active);
+  } else {
+    MtgSlabOut<C, DL, -1, AUX> io;
+    io.init(my_slab, lane, t, d);
+    io.begin_tile(it.coeffs, b0, B);
+    mtg_lane_finish<C, -1, 0>(P, b, ln, wsl, other, kWave, io, active);
+  }
+  // (the caller's end-of-unit barrier frees the LDS)
+}
+
+// The configurations a cross-structure launch can hold (index = MtgDlAnyItem::cfg): X(index, H, K, MS, MI, ME, DV, WS), DL = 3
+#define MTG_DL_ANY_LIST(X)          \
+  X(0, 4, 4, 15, 1, 15, 3, 0)       \
+  X(1, 4, 8, 15, 1, 15, 3, 0)       \
+  X(2, 4, 16, 15, 1, 15, 3, 0)      \
+  X(3, 4, 32, 15, 1, 15, 3, 8)      \
+  X(4, 5, 4, 31, 1, 31, 4, 0)       \
+  X(5, 5, 8, 31, 1, 31, 4, 0)       \
+  X(6, 5, 16, 31, 1, 31, 4, 0)      \
+  X(7, 5, 32, 31, 1, 31, 4, 11)     \
+  X(8, 6, 4, 63, 1, 63, 5, 0)       \
+  X(9, 6, 8, 63, 1, 63, 5, 0)       \
+  X(10, 6, 16, 63, 1, 63, 5, 5)     \
+  X(11, 6, 32, 63, 1, 63, 5, 15)
+
+// Units are sorted longest-chain-first by the host; persistent workgroups take them with stride gridDim.x, so neighbouring
+// workgroups (same CU, same instruction cache) run the same configuration's code at about the same time.  (Measured and
+// rejected: a global unit counter, i.e. dynamic longest-first scheduling -- 81 us against 71 us for config 4 at 30k: the
+// bodies are straight-line code of 100-300 KB each, and workgroups that drift apart stop sharing instruction fetches.)
+template <int AUX>
+__global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_any_kernel(const MtgDlAnyItem* __restrict__ items,
+                                                                      const MtgDlAnyUnit* __restrict__ units, int nunits,
+                                                                      int* status, double* ws) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  double* wsl0 = ws + (size_t)blockIdx.x * (2 * kWave) + threadIdx.x;
+  const long long ws_stride = (long long)gridDim.x * (2 * kWave);
+  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+    const MtgDlAnyUnit un = units[u];
+    const MtgDlAnyItem it = items[un.item];
+    switch (__builtin_amdgcn_readfirstlane(it.cfg)) {
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
+      case I: mtg_dl_any_unit<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>, 3, AUX>(it, un.tile, status, wsl0, ws_stride, lds_raw); break;
+      MTG_DL_ANY_LIST(MTG_X)
+#undef MTG_X
+      default: break;
+    }
+    __syncthreads();           // the unit's LDS is free again
+  }
+}
 #endif  // MTG_DIMLANE_H_

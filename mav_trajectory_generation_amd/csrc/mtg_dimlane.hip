@@ -1,5 +1,6 @@
 // Dimension-in-lane kernel instantiations (mtg_dimlane.h, mtg_dimlane_variants.inc).  This translation unit is
 // compiled with -mllvm -amdgpu-kernarg-preload-count=14: the kernels' arguments arrive in user SGPRs at wave launch.
+#include <algorithm>
 #include "mtg_dimlane.h"
 
 namespace {
@@ -43,4 +44,42 @@ const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const i
     if (ok) return &e;
   }
   return nullptr;
+}
+
+// ---- cross-structure launches (mtg_solve_dl_any_kernel) ----
+int mtg_dl_any_index(const MtgDimlaneEntry* e) {
+  if (!e || e->dl != 3) return -1;
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
+  if (e->h == H && e->k == K && e->ms == MS && e->mi == MI && e->me == ME && e->dv == DV) return I;
+  MTG_DL_ANY_LIST(MTG_X)
+#undef MTG_X
+  return -1;
+}
+size_t mtg_dl_any_lds_bytes() {
+  size_t m = 0;
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
+  m = std::max(m, mtg_dl_pair_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>, 3>());
+  MTG_DL_ANY_LIST(MTG_X)
+#undef MTG_X
+  return m;
+}
+size_t mtg_dl_any_ws_per_lane() {
+  size_t m = 0;
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
+  m = std::max(m, (size_t)MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>::WSJ * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>::WSE * sizeof(double));
+  MTG_DL_ANY_LIST(MTG_X)
+#undef MTG_X
+  return m;
+}
+int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, int nunits, int* status,
+                      double* ws) {
+  static bool attr_set = false;
+  const size_t lds = mtg_dl_any_lds_bytes();
+  auto kern = mtg_solve_dl_any_kernel<18>;   // nt sc1 coefficient stores, as for single-plan launches
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, items, units, nunits, status, ws);
+  return 0;
 }

@@ -432,4 +432,18 @@ int mtg_any_cfg_index(const MtgStaticEntry* e);
 SolveMultiFn mtg_multi_any_fn(int dg, int variant);
 const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask);
 
+// cross-structure dimension-in-lane launches (mtg_dimlane.h: mtg_solve_dl_any_kernel)
+struct MtgDlAnyItem {     // one bucket
+  const double* times;    // [K][B]
+  const double* dfix;     // [DL][n_fixed][B]
+  double* coeffs;         // [B][K][DL][N]
+  int B, cfg;
+};
+struct MtgDlAnyUnit { int item, tile; };
+int mtg_dl_any_index(const MtgDimlaneEntry* e);     // configuration index of a 3-dimensional variant, or -1
+size_t mtg_dl_any_lds_bytes();
+size_t mtg_dl_any_ws_per_lane();
+int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, int nunits, int* status,
+                      double* ws);
+
 #endif  // MTG_KERNELS_H_

@@ -594,3 +594,60 @@ def test_concurrent_mixed_request(ctx):
         req.close()
         solver.close()
     one.close()
+
+
+def test_cross_structure_dimlane_request(ctx):
+    """mtg_multi_*: items with canonical SoA inputs whose plans have a static dimension-in-lane configuration join ONE
+    cross-structure launch (mtg_solve_dl_any_kernel), whatever their N and K -- BASELINE config 4's twelve buckets in one
+    launch, back-substitution data in registers.  Bit-for-bit equal to the per-bucket dimension-in-lane launches; ragged
+    bucket sizes (tile tails), two buckets of one plan, an AoS bucket (-> the rolled merged path) in the same request,
+    re-solve with new values, bad segment time reported through the context status."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    buckets, sizes = [], [700, 21, 1, 64, 333, 2500, 43, 700, 700, 22, 640, 100]
+    i = 0
+    for (n, d) in ((8, 3), (10, 4), (12, 5)):
+        for k in (4, 8, 16, 32):
+            masks = m.ends_full_masks(n, k)
+            t, f = m.random_waypoint_batch(sizes[i], k, 3, n, masks, seed=100 * n + k, device="cuda", layout="soa")
+            buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
+            i += 1
+    masks = m.ends_full_masks(10, 8)
+    t, f = m.random_waypoint_batch(300, 8, 3, 10, masks, seed=5, device="cuda", layout="soa")
+    buckets.append(dict(n_coeffs=10, derivative=4, masks=masks, times=t, d_fixed=f, layout="soa"))
+    n_dl = len(buckets)
+    masks, times, d_fixed = helpers.reference_batch(50, 16, 10, 3, 4321)
+    buckets.append(dict(n_coeffs=10, derivative=4, masks=masks, times=torch.from_numpy(times).cuda(),
+                        d_fixed=torch.from_numpy(d_fixed).cuda()))
+    solver = m.MixedBatchSolver(ctx, n_streams=1)
+    req = solver.merged(buckets)
+    assert req.launch_count == 2        # the cross-structure launch + the AoS bucket's ordinary launch
+
+    def reference():
+        out = []
+        for b in buckets:
+            plan = solver.plan_for(b["n_coeffs"], 3, len(b["masks"]) - 1, b["derivative"], b["masks"], 0)
+            lay = b.get("layout", "aos")
+            co, _, _ = plan.solve(b["times"], b["d_fixed"], layout=lay, dims="dimlane" if lay == "soa" else "auto")
+            out.append(co.clone())
+        return out
+
+    for round_ in range(2):
+        for c, _ in req.out:
+            c.fill_(7.0)
+        got = req.solve()
+        torch.cuda.synchronize()
+        solver.sync()
+        ref = reference()
+        torch.cuda.synchronize()
+        for j, ((c, _), c0) in enumerate(zip(got, ref)):
+            assert torch.equal(c, c0), f"bucket {j}"
+        for b in buckets[:n_dl]:
+            b["times"].mul_(1.13)
+    buckets[3]["times"][5, 17] = -1.0      # a bad segment time inside the cross-structure launch
+    req.solve()
+    with pytest.raises(m.MtgError) as e:
+        solver.sync()
+    assert e.value.code == -2
+    req.close()
+    solver.close()

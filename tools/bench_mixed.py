@@ -103,19 +103,25 @@ if "merged" not in modes:
     sys.exit(0)
 solver = m.MixedBatchSolver(ctx, n_streams=3)
 req = solver.merged(buckets, dims=os.environ.get("MIXED_DIMS", "auto"))
-for mode in ("eager", "graph"):
+for mode in ("eager", "eager-library-stream", "graph"):
     graph = req.capture() if mode == "graph" else None
     run = (lambda: graph.replay()) if graph is not None else (lambda: req.solve())
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 50
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
+    # "eager": called from torch's default stream -- every call forks onto and joins back from the library's stream (two
+    # cross-stream event waits, ~10 us of device time each on this runtime); "eager-library-stream": the caller works on
+    # the library's stream (what a C caller of mtg_multi_solve does), no cross-stream waits
+    import contextlib
+    scope = torch.cuda.stream(ctx.stream) if mode == "eager-library-stream" else contextlib.nullcontext()
+    with scope:
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
     solver.sync()
     us = e0.elapsed_time(e1) * 1e3 / reps
     one = m.MixedBatchSolver(ctx, n_streams=1)
