@@ -205,9 +205,10 @@ int main(int argc, char** argv) {
   const size_t lds_dl = mtg_dl_lds_bytes<C1, 3, 2>();
   auto run_dl = [&](auto kern, const char* name) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dl));
+    const bool rot_in = !getenv("LAB_FIX_IN"), rot_out = !getenv("LAB_FIX_OUT");   // rotate inputs / outputs separately
     auto go = [=, &dt, &df, &dc](int i) {
-      const int s = i % NSETS;
-      hipLaunchKernelGGL(kern, dim3(nwg_dl), dim3(256), lds_dl, st, (const double*)dt[s], (const double*)df[s], dc[s],
+      const int s = rot_in ? i % NSETS : 0, so = rot_out ? i % NSETS : 0;
+      hipLaunchKernelGGL(kern, dim3(nwg_dl), dim3(256), lds_dl, st, (const double*)dt[s], (const double*)df[s], dc[so],
                          dstat, (int*)nullptr, B, ntiles_dl, nwg_dl, (double*)nullptr
 #if defined(MTG_LAB_TIMING)
                          , dbg
