@@ -273,6 +273,37 @@ def main():
                 extra["rotating_buffers_2000_steps"] = {"buffer_sets": nsets, "steps": 2000, "launch_us": us_l,
                                                         "traj_per_s": B * 2000 / dt_l,
                                                         "frac_of_8TBps": B * plan.bytes_per_trajectory / us_l * 1e-3 / HBM_PEAK_GBS}
+            # steady state of a pipeline that feeds TWO streams (independent batches: nothing orders them): the launches of
+            # one stream fill the gap between dependent launches of the other (~1.0-1.3 us) and overlap its store tail.
+            # Reported beside the one-stream numbers, never as `value`.
+            if args.config == 2 and nsets >= 4:
+                ctx2 = m.Context(device_index)
+                plan2 = m.Plan(ctx2, N, D, K, d, masks)
+                la = SolveLoop(plan, sets[0::2], args.layout, args.dims)
+                lb = SolveLoop(plan2, sets[1::2], args.layout, args.dims)
+                chunk, rounds = 8, 125
+                for _ in range(3):
+                    la.run(chunk)
+                    lb.run(chunk)
+                torch.cuda.synchronize()
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(ctx.stream)
+                for _ in range(rounds):
+                    la.run(chunk)
+                    lb.run(chunk)
+                ea.record(ctx.stream)
+                eb.record(ctx2.stream)
+                torch.cuda.synchronize()
+                dt_2 = time.perf_counter() - t0
+                n2 = 2 * chunk * rounds
+                us_2 = max(e0.elapsed_time(ea), e0.elapsed_time(eb)) * 1e3 / n2
+                ctx2.sync()
+                extra["two_streams_steady_state"] = {"buffer_sets": nsets, "launches": n2, "us_per_launch": us_2,
+                                                     "traj_per_s": B * n2 / dt_2,
+                                                     "frac_of_8TBps": B * plan.bytes_per_trajectory / us_2 * 1e-3 / HBM_PEAK_GBS}
+                plan2.close()
+                ctx2.close()
             # context for small launches: a write-only fill of the same coefficient buffer (zero compute, zero reads)
             co0 = sets[0][2]
             co0_copy = co0.clone()

@@ -65,3 +65,5 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and rf["traffic"] is None and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["bytes_per_launch"] == 10_000 * 2392
     assert "resident_buffers" in out["extra"]
+    two = out["extra"]["two_streams_steady_state"]      # pipeline over two streams: reported beside, never as `value`
+    assert two["launches"] == 2000 and 0 < two["us_per_launch"] < rf["kernel_us"] * 1.2
