@@ -34,11 +34,19 @@ __host__ __device__ constexpr size_t mtg_dl_slab_bytes() {   // one wave's slab 
   return a > b ? a : b;
 }
 template <class C, int DL>
-__host__ __device__ constexpr size_t mtg_dl_pair_bytes() {
+__host__ __device__ constexpr size_t mtg_dl_half_bytes() {   // one direction's slab (the exchange buffer aliases the other's)
   constexpr int fmid = C::H - C::popc(C::MI);
   constexpr size_t xch = (size_t)(fmid * (fmid + 1) / 2 + fmid) * kWave * sizeof(double);
   constexpr size_t slab = (mtg_dl_slab_bytes<C, DL>() + 15) / 16 * 16;
-  return 2 * (slab > xch ? slab : xch);
+  return slab > xch ? slab : xch;
+}
+template <class C>
+__host__ __device__ constexpr size_t mtg_dl_steps_bytes() {  // one wave's LDS step area (MtgCfg::LSJ workspace steps)
+  return (size_t)C::LSJ * C::WSE * kWave * sizeof(double);
+}
+template <class C, int DL>
+__host__ __device__ constexpr size_t mtg_dl_pair_bytes() {   // [slab A][slab B][steps A][steps B]
+  return 2 * mtg_dl_half_bytes<C, DL>() + 2 * mtg_dl_steps_bytes<C>();
 }
 template <class C, int DL, int NP>
 constexpr size_t mtg_dl_lds_bytes() { return NP * mtg_dl_pair_bytes<C, DL>(); }
@@ -135,8 +143,9 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
   // LDS per pair: [slab A][slab B]; the exchange buffer a direction publishes lives in the OTHER direction's slab
   // (read by that direction before it writes its first coefficient row; the end-of-tile barrier orders reuse)
   char* base = lds_raw + (size_t)pair * mtg_dl_pair_bytes<C, DL>();
-  constexpr size_t half = mtg_dl_pair_bytes<C, DL>() / 2;
+  constexpr size_t half = mtg_dl_half_bytes<C, DL>();
   char* my_slab = base + (size_t)dir * half;
+  P.lds_steps = (unsigned)(size_t)(base + 2 * half + (size_t)dir * mtg_dl_steps_bytes<C>()) + (unsigned)lane * 8u;
   double* mine = reinterpret_cast<double*>(base + (size_t)(1 - dir) * half) + lane_io;
   const double* other = reinterpret_cast<const double*>(my_slab) + lane_io;
   MtgSlabOut<C, DL, 1, AUX> ioA;
@@ -218,8 +227,9 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   if (dir == 0) mtg_dl_preload<C, 1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
   else mtg_dl_preload<C, -1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
   constexpr int mm = C::MI;
-  constexpr size_t half = mtg_dl_pair_bytes<C, DL>() / 2;
+  constexpr size_t half = mtg_dl_half_bytes<C, DL>();
   char* my_slab = lds_raw + (size_t)dir * half;
+  P.lds_steps = (unsigned)(size_t)(lds_raw + 2 * half + (size_t)dir * mtg_dl_steps_bytes<C>()) + (unsigned)lane * 8u;
   double* mine = reinterpret_cast<double*>(lds_raw + (size_t)(1 - dir) * half) + lane;
   const double* other = reinterpret_cast<const double*>(my_slab) + lane;
   double* wsl = wsl0;
@@ -242,20 +252,21 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   // (the caller's end-of-unit barrier frees the LDS)
 }
 
-// The configurations a cross-structure launch can hold (index = MtgDlAnyItem::cfg): X(index, H, K, MS, MI, ME, DV, WS), DL = 3
-#define MTG_DL_ANY_LIST(X)          \
-  X(0, 4, 4, 15, 1, 15, 3, 0)       \
-  X(1, 4, 8, 15, 1, 15, 3, 0)       \
-  X(2, 4, 16, 15, 1, 15, 3, 0)      \
-  X(3, 4, 32, 15, 1, 15, 3, 8)      \
-  X(4, 5, 4, 31, 1, 31, 4, 0)       \
-  X(5, 5, 8, 31, 1, 31, 4, 0)       \
-  X(6, 5, 16, 31, 1, 31, 4, 0)      \
-  X(7, 5, 32, 31, 1, 31, 4, 11)     \
-  X(8, 6, 4, 63, 1, 63, 5, 0)       \
-  X(9, 6, 8, 63, 1, 63, 5, 0)       \
-  X(10, 6, 16, 63, 1, 63, 5, 5)     \
-  X(11, 6, 32, 63, 1, 63, 5, 15)
+// The configurations a cross-structure launch can hold (index = MtgDlAnyItem::cfg): X(index, H, K, MS, MI, ME, DV, WS, LS),
+// DL = 3; (WS, LS) as in mtg_dimlane_variants.inc
+#define MTG_DL_ANY_LIST(X)             \
+  X(0, 4, 4, 15, 1, 15, 3, 0, 0)       \
+  X(1, 4, 8, 15, 1, 15, 3, 0, 0)       \
+  X(2, 4, 16, 15, 1, 15, 3, 0, 0)      \
+  X(3, 4, 32, 15, 1, 15, 3, 8, 7)      \
+  X(4, 5, 4, 31, 1, 31, 4, 0, 0)       \
+  X(5, 5, 8, 31, 1, 31, 4, 0, 0)       \
+  X(6, 5, 16, 31, 1, 31, 4, 0, 0)      \
+  X(7, 5, 32, 31, 1, 31, 4, 11, 5)     \
+  X(8, 6, 4, 63, 1, 63, 5, 0, 0)       \
+  X(9, 6, 8, 63, 1, 63, 5, 0, 0)       \
+  X(10, 6, 16, 63, 1, 63, 5, 6, 3)     \
+  X(11, 6, 32, 63, 1, 63, 5, 15, 3)
 
 // Units are sorted longest-chain-first by the host; persistent workgroups take them with stride gridDim.x, so neighbouring
 // workgroups (same CU, same instruction cache) run the same configuration's code at about the same time.  (Measured and
@@ -272,8 +283,8 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_any_kernel(const Mt
     const MtgDlAnyUnit un = units[u];
     const MtgDlAnyItem it = items[un.item];
     switch (__builtin_amdgcn_readfirstlane(it.cfg)) {
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
-      case I: mtg_dl_any_unit<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>, 3, AUX>(it, un.tile, status, wsl0, ws_stride, lds_raw); break;
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
+      case I: mtg_dl_any_unit<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>, 3, AUX>(it, un.tile, status, wsl0, ws_stride, lds_raw); break;
       MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
       default: break;

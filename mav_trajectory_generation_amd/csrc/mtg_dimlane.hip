@@ -25,16 +25,19 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
 }
 }  // namespace
 
-#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS)                                                     \
-  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>, DL, NP>(), \
-   (size_t)MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>::WSJ * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>::WSE * sizeof(double),  \
-   launch_dl<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0)>, DL, NP>},
-#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0)
+#define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0), LS>
+#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS)                                                              \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>(),    \
+   (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::LSJ) *           \
+       MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSE * sizeof(double),                                                   \
+   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>},
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include "mtg_dimlane_variants.inc"
 };
 #undef MTG_DL
 #undef MTG_DLW
+#undef MTG_DLCFG
 
 const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask) {
   for (const MtgDimlaneEntry& e : kDimlaneTable) {
@@ -49,7 +52,7 @@ const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const i
 // ---- cross-structure launches (mtg_solve_dl_any_kernel) ----
 int mtg_dl_any_index(const MtgDimlaneEntry* e) {
   if (!e || e->dl != 3) return -1;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
   if (e->h == H && e->k == K && e->ms == MS && e->mi == MI && e->me == ME && e->dv == DV) return I;
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
@@ -57,16 +60,16 @@ int mtg_dl_any_index(const MtgDimlaneEntry* e) {
 }
 size_t mtg_dl_any_lds_bytes() {
   size_t m = 0;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
-  m = std::max(m, mtg_dl_pair_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>, 3>());
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
+  m = std::max(m, mtg_dl_pair_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>, 3>());
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
   return m;
 }
 size_t mtg_dl_any_ws_per_lane() {
   size_t m = 0;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS) \
-  m = std::max(m, (size_t)MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>::WSJ * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0)>::WSE * sizeof(double));
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
+  m = std::max(m, (size_t)(WS - LS) * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>::WSE * sizeof(double));
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
   return m;

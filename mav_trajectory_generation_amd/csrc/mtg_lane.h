@@ -44,6 +44,7 @@ struct MtgParams {
   double* ws;           long long ws_stride;        // generic mode back-substitution store
   long long ws_share;   // dimension-in-lane long chains (MtgCfg::DLW): element offset from a lane's own workspace column to
                         // the column of its trajectory's dimension-0 lane
+  unsigned lds_steps;   // MtgCfg::LSJ: LDS byte address of this lane's column in its wave's step area (row stride 64 doubles)
   int* status;                                      // OR of MTG_FLAG_* over the batch
   int* tstatus;                                     // optional [B]: OR of MTG_FLAG_* per trajectory (pre-zeroed)
   const int* vmask;                                 // [K+1] fixed masks        (generic mode)
@@ -77,7 +78,7 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
-template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0>
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0>
 struct MtgCfg {
   // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
   // instantiations carry that code
@@ -107,6 +108,9 @@ struct MtgCfg {
   // every DLW_-th element (one row of the workspace holds DLW_ consecutive elements, one per dimension lane) and reads
   // the others from its sibling lanes' columns: 1/DLW_ of the G traffic.  g stays per lane.
   static constexpr int DLW = kStatic ? DLW_ : 0;
+  // LS_ > 0 (with DLW_): the LAST LS_ of the WS_ workspace steps (the ones next to the register steps) are kept in the
+  // wave's LDS instead of global memory -- same row layout, row stride 64 lanes (MtgParams::lds_steps).
+  static constexpr int LSJ = (kStatic && DLW_ > 0) ? LS_ : 0;
   static constexpr int WSE = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
   static constexpr int FULL = (1 << H_) - 1;
@@ -936,6 +940,14 @@ MTG_HD void mtg_ws_load(const double* w, long long stride, double (&G)[C::H][C::
 
 // Shared-G workspace layout (MtgCfg::DLW lanes per trajectory, lane = dim * TPW + trajectory; C::D == 1): row r of a step
 // holds G's free elements DLW*r .. DLW*r + DLW-1 (traversal order), element DLW*r + k in the column of dimension lane k.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double mtg_lds_double;
+// this lane's column of workspace step j in the wave's LDS step area (steps WSJ - LSJ .. WSJ - 1, WSE rows of 64 doubles each)
+template <class C>
+__device__ __forceinline__ mtg_lds_double* mtg_lds_step(const MtgParams& P, int j) {
+  return (mtg_lds_double*)(size_t)(P.lds_steps + (unsigned)(j - (C::WSJ - C::LSJ)) * (unsigned)(C::WSE * 64 * sizeof(double)));
+}
+#endif
 template <int DL>
 MTG_HD double mtg_pick(int d, const double (&c)[DL]) {
   double v = c[0];
@@ -951,8 +963,8 @@ MTG_HD double mtg_pick(int d, const double (&c)[DL]) {
   }
   return v;
 }
-template <class C>
-MTG_HD void mtg_ws_store_shared(double* w, long long stride, int d, const double (&G)[C::H][C::H],
+template <class C, class PTR>
+MTG_HD void mtg_ws_store_shared(PTR w, long long stride, int d, const double (&G)[C::H][C::H],
                                 const double (&g)[C::D][C::H], int ml, int mr) {
   constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1;
   double cand[DL];
@@ -986,11 +998,11 @@ MTG_HD void mtg_ws_store_shared(double* w, long long stride, int d, const double
   }
 }
 // w: this lane's own column; share: element offset to the trajectory's dimension-0 column; TPW lanes between dimension columns
-template <class C>
-MTG_HD void mtg_ws_load_shared(const double* w, long long stride, long long share, double (&G)[C::H][C::H],
+template <class C, class PTR>
+MTG_HD void mtg_ws_load_shared(PTR w, long long stride, long long share, double (&G)[C::H][C::H],
                                double (&g)[C::D][C::H], int ml, int mr) {
   constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1, TPW = 64 / DL;
-  const double* col[DL];
+  PTR col[DL];
 #pragma unroll
   for (int k = 0; k < DL; ++k) col[k] = w + share + k * TPW;
   int cnt = 0;
@@ -1005,7 +1017,7 @@ MTG_HD void mtg_ws_load_shared(const double* w, long long stride, long long shar
       ++cnt;
     }
   }
-  const double* wg = w + (long long)((cnt + DL - 1) / DL) * stride;
+  PTR wg = w + (long long)((cnt + DL - 1) / DL) * stride;
 #pragma unroll
   for (int p = 0; p < H; ++p) {
     g[0][p] = 0.0;
@@ -1055,8 +1067,17 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
       if (j < C::WSJ) {
         double G[H][H], g[D][H];
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
-        if constexpr (C::DLW > 0) mtg_ws_store_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.dim0, G, g, ml, mr);
-        else mtg_ws_store<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, G, g, ml, mr);
+        if constexpr (C::DLW > 0) {
+          if (j >= C::WSJ - C::LSJ) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            mtg_ws_store_shared<C>(mtg_lds_step<C>(P, j), 64, P.dim0, G, g, ml, mr);
+#endif
+          } else {
+            mtg_ws_store_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.dim0, G, g, ml, mr);
+          }
+        } else {
+          mtg_ws_store<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, G, g, ml, mr);
+        }
       } else {
         constexpr int JR0 = C::WSJ;
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, ln.G[j < JR0 ? 0 : j - JR0], ln.g[j < JR0 ? 0 : j - JR0]);
@@ -1134,10 +1155,17 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
     // step's back-substitution and BEFORE its coefficient stores (loads and stores retire through one in-order counter)
     double Gw[H][H], gw[D][H];
     auto request = [&](int j) {
-      if constexpr (C::DLW > 0)
-        mtg_ws_load_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.ws_share, Gw, gw,
-                              mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
-      else
+      if constexpr (C::DLW > 0) {
+        if (j >= C::WSJ - C::LSJ) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          mtg_ws_load_shared<C>(mtg_lds_step<C>(P, j), 64, P.ws_share, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
+                                mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
+#endif
+        } else {
+          mtg_ws_load_shared<C>((const double*)(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, P.ws_share, Gw, gw,
+                                mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
+        }
+      } else
         mtg_ws_load<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
                        mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
     };
