@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument("--same-device", action="store_true", help="all ranks on HIP device 0 (multi-process tests on a 1-GPU box)")
     ap.add_argument("--plumbing-only", action="store_true", help="spawn / rendezvous / reduce only, no GPU work (CPU test)")
     ap.add_argument("--extra", action="store_true", help="also time the 1M per-launch batch and the host-pointer paths")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (profiling runs: the kernel statistics then cover the same launches as the metric)")
     return ap.parse_args(argv)
 
 
@@ -243,7 +245,7 @@ def main():
             assert torch.isfinite(co).all()
 
         extra = {}
-        if rank == 0:
+        if rank == 0 and not args.no_extras:
             # the same loop over ONE resident buffer set (inputs and outputs stay in the 256 MiB Infinity Cache)
             res = SolveLoop(plan, sets[:1], args.layout, args.dims)
             steps_r = max(args.steps, 200)

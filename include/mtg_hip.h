@@ -239,9 +239,13 @@ int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coef
 /* ---- mixed requests: several plans in one launch ------------------------------------------
  * What a caller of the reference does with a list of independent PolynomialOptimization<N>
  * problems of different structure (BASELINE config 4: N in {8, 10, 12}, 4..32 segments): each
- * structure is a plan + a batch.  A mixed request is created once -- items that share N, D, the
- * start / interior / end constraint pattern and the derivative (any K >= 2) are merged into ONE
- * kernel launch whose tiles are ordered longest-chain-first -- and solved as often as wanted
+ * structure is a plan + a batch.  A mixed request is created once -- items with canonical SoA
+ * inputs (times[K][B], d_fixed[D][n_fixed][B]) and coefficient output only whose plan has a
+ * static dimension-in-lane configuration (the config-4 shapes: N = 8 / 10 / 12, K = 4 / 8 / 16 /
+ * 32, D = 3) join ONE cross-structure launch whatever their N and K; of the others, items that
+ * share D, the start / interior / end constraint pattern and the derivative (any K >= 2; N = 8 /
+ * 10 / 12 standard shapes also across N) are merged into ONE launch of the run-time-K kernels
+ * whose tiles are ordered longest-chain-first -- and solved as often as wanted
  * with new values in the same device buffers (same structure, new segment times: every
  * iteration of a time optimiser).  mtg_multi_solve only enqueues kernels (and memsets of the
  * cost outputs) on the context's stream: it can be stream-captured into a hipGraph.
