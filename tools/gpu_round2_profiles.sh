@@ -16,10 +16,13 @@ cp $R/gpurun_out/r02_rotating_b10000_kernel_stats.csv $R/gpurun_out/r02_rotating
 python tools/bench_configs.py 2>&1 | grep "^{" > $OUT/configs.jsonl
 python tools/bench_configs.py long 2>&1 | grep "^{" >> $OUT/configs.jsonl
 python tools/bench_mixed.py 2500 merged 2>&1 | grep "^{" > $OUT/mixed_config4.jsonl
+python tools/bench_mixed.py 10000 merged 2>&1 | grep "^{" >> $OUT/mixed_config4.jsonl
+tools/micro/stream_overlap.bin > $OUT/stream_overlap_microbench.txt 2>&1
 tools/micro/launch_geometry > $OUT/launch_geometry_microbench.txt 2>&1
 tools/lab/b10k_lab 10000 1 > $OUT/lab_resident.txt 2>&1
 tools/lab/b10k_lab 10000 16 > $OUT/lab_rotating.txt 2>&1
 tools/lab/b10k_lab_t 10000 1 | tail -12 > $OUT/lab_phase_timing.txt 2>&1
+(for v in "" "LAB_FIX_IN=1" "LAB_FIX_OUT=1" "LAB_FIX_IN=1 LAB_FIX_OUT=1"; do echo "== 16 buffer sets $v"; env $v tools/lab/b10k_lab 10000 16 | grep "dim-in-lane, nt sc1 stores  \|dim-in-lane, sc1 stores  " | grep -v "max poly"; done) > $OUT/lab_rotation_sides.txt 2>&1
 (for a in "125000 1" "125000 4" "1000000 1"; do echo "== B, buffer sets: $a"; tools/lab/b10k_lab $a | grep "fused\|slab"; done) > $OUT/lab_large_batch.txt 2>&1
 python tools/enqueue_probe.py 16 > $OUT/enqueue_probe.txt 2>&1
 tools/cpp/polynomial_timing_evaluation > $OUT/veneer_timing_evaluation.txt 2>&1

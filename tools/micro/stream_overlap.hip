@@ -3,6 +3,7 @@
 // stream); wall time from events on the main stream + host time of the enqueue.
 // build: hipcc --offload-arch=gfx950 -O2 tools/micro/stream_overlap.hip -o /tmp/stream_overlap
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <vector>
@@ -31,7 +32,7 @@ int main() {
   const long long cyc = 4000;   // wall_clock64 ticks at 100 MHz: 40 us
   for (int wgs : {64, 256}) {
     for (int n : {1, 2, 4, 8, 12}) {
-      for (int mode = 0; mode < 2; ++mode) {   // 0: one stream, 1: n streams
+      for (int mode = 0; mode < 3; ++mode) {   // 0: one stream, 1: n streams, 2: one stream, hipExtAnyOrderLaunch
         double best = 1e30, host_best = 1e30;
         for (int rep = 0; rep < 6; ++rep) {
           CK(hipDeviceSynchronize());
@@ -39,6 +40,9 @@ int main() {
           CK(hipEventRecord(e0, main_s));
           if (mode == 0) {
             for (int i = 0; i < n; ++i) hipLaunchKernelGGL(spin, dim3(wgs), dim3(256), 0, main_s, cyc, (int*)nullptr);
+          } else if (mode == 2) {
+            for (int i = 0; i < n; ++i)
+              hipExtLaunchKernelGGL(spin, dim3(wgs), dim3(256), 0, main_s, nullptr, nullptr, hipExtAnyOrderLaunch, cyc, (int*)nullptr);
           } else {
             CK(hipEventRecord(fork, main_s));
             for (int i = 0; i < n; ++i) CK(hipStreamWaitEvent(side[i], fork, 0));
@@ -52,7 +56,7 @@ int main() {
           CK(hipEventElapsedTime(&ms, e0, e1));
           if (rep > 0) { best = std::min(best, (double)ms * 1e3); host_best = std::min(host_best, std::chrono::duration<double, std::micro>(h1 - h0).count()); }
         }
-        printf("wgs=%3d n=%2d %-10s device %7.1f us   host enqueue %6.1f us\n", wgs, n, mode ? "n streams" : "one stream", best, host_best);
+        printf("wgs=%3d n=%2d %-10s device %7.1f us   host enqueue %6.1f us\n", wgs, n, mode == 0 ? "one stream" : mode == 1 ? "n streams" : "any-order", best, host_best);
       }
     }
   }
