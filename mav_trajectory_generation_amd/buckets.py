@@ -1,12 +1,14 @@
 """Mixed batches (BASELINE config 4): trajectories with different N / K / constraint structure are bucketed on the
-host by plan key (N, D, K, d, masks); each bucket is one launch of the matching kernel variant.  Mirrors what a
-caller of the reference would do with a list of independent PolynomialOptimization<N> problems.
+host by plan key (N, D, K, d, masks).  Mirrors what a caller of the reference would do with a list of independent
+PolynomialOptimization<N> problems.
 
-Buckets are independent, and a bucket of a few thousand trajectories fills only a fraction of the 256 CUs (a
-2500-trajectory bucket is 40 tiles), so the buckets are spread over `n_streams` HIP streams -- one library context
-per stream (include/mtg_hip.h: a context is (device, stream, scratch)) -- forked from the caller's stream and joined
-back onto it: the launches overlap on the device instead of queueing behind each other.  Longest chains first, so
-the short buckets fill in behind the long ones."""
+A bucket of a few thousand trajectories fills only a fraction of the 256 CUs, and twelve back-to-back launches each pay
+their own latency chain.  The fast path is `MixedBatchSolver.merged(buckets)`: ONE library call per request
+(mtg_multi_*), which runs every bucket with canonical SoA inputs inside one cross-structure kernel launch (config 4, 30k
+trajectories: 63-65 us against ~320 us for per-bucket launches from Python).  `solve_device` / `capture` spread per-bucket
+launches over `n_streams` HIP streams (one library context per stream, forked from / joined onto the caller's stream,
+longest chains first) -- kept for requests the merged path does not cover, but on this runtime kernels of different
+streams overlap two at a time at best and every fork-join costs ~23 us (profiles/r02_stream_overlap_microbench.txt)."""
 from __future__ import annotations
 
 from typing import Dict, List, Sequence, Tuple

@@ -61,16 +61,28 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
   constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
   const unsigned step = B * 8u;
   unsigned ot = ((DIR > 0 ? 0u : (unsigned)(C::KT - 1)) * B + b) * 8u;
+  // Both directions write EVERY element of T and fx (zeros beyond their own count): with different store counts in the two
+  // instantiations (odd K: KA = KB + 1, NCA = NCB + 1) the optimiser sinks the common tail of the two branches into one
+  // block that stores through a phi of element POINTERS, and the arrays can no longer be promoted to registers (odd-K
+  // kernels ran with T / fx in scratch).
 #pragma unroll
-  for (int j = 0; j < KC; ++j) {
-    T[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(times) + ot);
-    ot = DIR > 0 ? ot + step : ot - step;
+  for (int j = 0; j < C::KCS; ++j) {
+    if (j < KC) {
+      T[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(times) + ot);
+      ot = DIR > 0 ? ot + step : ot - step;
+    } else {
+      T[j] = 0.0;
+    }
   }
   unsigned of = ((d * (unsigned)C::offFEnd + (unsigned)c0) * B + b) * 8u;
 #pragma unroll
-  for (int c = 0; c < nc; ++c) {
-    fx[0][c] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(dfix) + of);
-    of += step;
+  for (int c = 0; c < C::NC; ++c) {
+    if (c < nc) {
+      fx[0][c] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(dfix) + of);
+      of += step;
+    } else {
+      fx[0][c] = 0.0;
+    }
   }
 }
 

@@ -1,0 +1,53 @@
+// mtg_dimlane_table.h -- launcher + table boilerplate shared by the dimension-in-lane translation units.  The including
+// file defines MTG_DL_TABLE_INC (the variant list), MTG_DL_TABLE_FN (name of the function that returns the table) and,
+// for the secondary units, MTG_DL_SINGLE_POLICY (only the nt sc1 store policy is instantiated).
+#include <algorithm>
+#include "mtg_dimlane.h"
+
+namespace {
+constexpr int kMaxDevices = 64;
+template <class C, int DL, int NP>
+int launch_dl(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
+              int* traj_status, int B, int ntiles, int policy, double* ws) {
+  constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
+  // (the attribute is a property of the function ON A DEVICE: one flag per device for processes that drive several GPUs)
+  static bool attr_set[3][kMaxDevices] = {};
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+  // store policy: 0 = nt sc1 (small launches, resident or not), 1 = sc1, 2 = plain write-back
+  auto go = [&](auto kern, int slot) -> int {
+    if (!attr_set[slot][dev]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      attr_set[slot][dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid, ws);
+    return 0;
+  };
+#if !defined(MTG_DL_SINGLE_POLICY)
+  if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
+  if (policy == 2) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 0>, 2);
+#endif
+  (void)policy;
+  return go(mtg_solve_dl_kernel<C, DL, NP, 0, 18>, 0);
+}
+}  // namespace
+
+#define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0), LS>
+#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS)                                                              \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>(),    \
+   (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::LSJ) *           \
+       MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSE * sizeof(double),                                                   \
+   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>},
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0)
+static const MtgDimlaneEntry kDimlaneTable[] = {
+#include MTG_DL_TABLE_INC
+};
+#undef MTG_DL
+#undef MTG_DLW
+#undef MTG_DLCFG
+
+const MtgDimlaneEntry* MTG_DL_TABLE_FN(int* count) {
+  *count = (int)(sizeof(kDimlaneTable) / sizeof(kDimlaneTable[0]));
+  return kDimlaneTable;
+}

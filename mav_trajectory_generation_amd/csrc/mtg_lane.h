@@ -260,20 +260,29 @@ MTG_HD void mtg_preload_into(const MtgParams& P, long long b, double (&T)[C::KCS
     constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
     const double* pt = P.times + b * P.ts_b + (long long)(DIR > 0 ? 0 : C::KT - 1) * P.ts_k;
     const long long tstep = DIR > 0 ? P.ts_k : -P.ts_k;
+    // (both directions write every element, zeros beyond their own count: see mtg_dl_preload)
 #pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      T[j] = *pt;
-      if constexpr (C::kPert) T[j] = mtg_perturb(P, mtg_seg<DIR>(C::KT, j), T[j]);
-      pt += tstep;
+    for (int j = 0; j < C::KCS; ++j) {
+      if (j < KC) {
+        T[j] = *pt;
+        if constexpr (C::kPert) T[j] = mtg_perturb(P, mtg_seg<DIR>(C::KT, j), T[j]);
+        pt += tstep;
+      } else {
+        T[j] = 0.0;
+      }
     }
     const double* pd = P.dfix + b * P.fs_b + (long long)P.dim0 * P.fs_d + (long long)c0 * P.fs_c;
 #pragma unroll
     for (int dm = 0; dm < C::D; ++dm) {
       const double* pc = pd;
 #pragma unroll
-      for (int c = 0; c < nc; ++c) {
-        fx[dm][c] = *pc;
-        pc += P.fs_c;
+      for (int c = 0; c < C::NC; ++c) {
+        if (c < nc) {
+          fx[dm][c] = *pc;
+          pc += P.fs_c;
+        } else {
+          fx[dm][c] = 0.0;
+        }
       }
       pd += P.fs_d;
     }

@@ -51,6 +51,8 @@ struct MtgSlabOut {
     nbytes = __builtin_amdgcn_readfirstlane(nbytes);
     rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
     pn = 0;
+    ph0 = (unsigned)(b0 & 3);
+    if constexpr (kPhaseChp) phi_l = (int)(((ph0 + (unsigned)lane / (unsigned)CHP) * (unsigned)PMOD) & 63u);
   }
   __device__ __forceinline__ static void fence() {
     asm volatile("" ::: "memory");
@@ -86,11 +88,25 @@ struct MtgSlabOut {
     }
     if (hi < lo) hi = lo;
   }
+  // PIECE not a multiple of 64 (N = 10 with K % 4 != 0, N = 12 with odd K): consecutive trajectories' pieces shift against
+  // the 64-byte grid by PMOD bytes, so "64-byte aligned relative to the trajectory's start" is aligned in memory for every
+  // 64 / gcd-th trajectory only (measured, N = 10 at B = 100k: 11.4 us per segment for K = 10 against 8.1 for K = 12 --
+  // partial sectors again).  Phase mapping: every row's ranges are aligned in MEMORY, i.e. shifted by the row's phase
+  // phi = ((b0 + row) * PMOD) mod 64 (a multiple of 16); rows have up to MAXCH_P chunks per range, addressed with a fixed
+  // row stride of MAXCH_P chunk slots per store pass (division by a compile-time constant).
+  static constexpr int PMOD = PIECE & 63;
+  static constexpr bool kPhase = PMOD != 0 && S >= 64;
+  static constexpr int MAXCH_P = (S + 63) / 16;
+  // Segments of at most 256 bytes (N = 10, D = 3: S = 240): memory-aligned ranges are at most 16 chunks once the misaligned
+  // head (direction A, segment 0) and tail (direction B, last segment) of the piece -- up to 48 bytes each -- go out in a
+  // pass of their own; the ranges then use the cheap power-of-two mapping with a per-lane phase (the phase of row
+  // tr + 4 i does not depend on the pass i: 4 * PMOD is a multiple of 64).
+  static constexpr bool kPhaseChp = kPhase && ((S + 63) / 64) * 64 <= 256;
   static constexpr int MAXCH = max_range_chunks();
   // chunks per trajectory row of a store instruction: the next power of two where at most 1/8 of the lanes idle, else the
   // generic mapping (N = 8: 192-byte ranges = 12 chunks; padded to 16 a quarter of every store instruction would be idle)
   static constexpr int pow2_rows(int m) { return m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : 0)); }
-  static constexpr int CHP = (pow2_rows(MAXCH) != 0 && 8 * (pow2_rows(MAXCH) - MAXCH) <= pow2_rows(MAXCH)) ? pow2_rows(MAXCH) : 0;
+  static constexpr int CHP = kPhaseChp ? 16 : ((!kPhase && pow2_rows(MAXCH) != 0 && 8 * (pow2_rows(MAXCH) - MAXCH) <= pow2_rows(MAXCH)) ? pow2_rows(MAXCH) : 0);
   // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
   // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
   // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
@@ -98,12 +114,16 @@ struct MtgSlabOut {
   static constexpr bool kRing = S >= 64;   // (tiny shapes: the direction's whole half; a range could span several segments)
   static constexpr int ROWB = (((kRing ? 2 * S : HALF_HI - HALF_LO) / 16) | 1) * 16;   // odd number of 16-byte units: conflict-free b128 rows
   static constexpr int RPI = CHP ? 64 / CHP : 0;                                        // trajectories per store instruction
-  static constexpr int MAXI = CHP ? (TPW + RPI - 1) / RPI : (TPW * MAXCH + 63) / 64;       // store instructions per range
+  static constexpr int MAXI_MAIN = CHP ? (TPW + RPI - 1) / RPI : (kPhase ? (TPW * MAXCH_P + 63) / 64 : (TPW * MAXCH + 63) / 64);
+  static constexpr int MINI = kPhaseChp ? (TPW * 3 + 63) / 64 : 0;   // passes for the head / tail pieces (3 chunks per row)
+  static constexpr int MAXI = MAXI_MAIN + MINI;                      // store instructions per range
   static constexpr int NPV = PEND ? MAXI : 1;
   u4 pv[NPV];           // PEND: chunks of the previously committed range, read from the slab, not yet stored
   unsigned pg[NPV];     // their byte offsets in the tile's output
   int pn;               // PEND: how many of them are in use; !PEND: the committed, not yet streamed segment + 1 (0: none)
   unsigned gl, ll;      // CHP mapping: this lane's (trajectory, chunk) part of the global / LDS byte offset
+  unsigned ph0;         // phase mapping: (first trajectory of the tile) mod 4
+  int phi_l;            // kPhaseChp: phase of this lane's rows (row = lane / 16 + 4 i)
   __device__ __forceinline__ void init_map() {
     if constexpr (CHP != 0) {
       const unsigned tr = (unsigned)lane / (unsigned)CHP, rr = (unsigned)lane % (unsigned)CHP;
@@ -122,8 +142,54 @@ struct MtgSlabOut {
   }
   // chunk i of range(seg) = [lo, lo + 16 nch): global byte offset (out of range for surplus lanes) and LDS byte offset;
   // false if store instruction i does not exist for this range
+  // this row's memory-aligned range of segment seg (phase mapping): [lo, hi) relative to the trajectory's piece
+  // (kPhaseChp: the piece's misaligned head / tail are not part of the first / last range -- they have their own pass)
+  __device__ __forceinline__ static void range_of_phase(int seg, int phi, int& lo, int& hi) {
+    if (DIR > 0) {
+      lo = (seg == 0 && !kPhaseChp) ? 0 : ((seg * S + phi + 63) & ~63) - phi;
+      hi = seg == KA - 1 ? KA * S : (((seg + 1) * S + phi + 63) & ~63) - phi;
+    } else {
+      lo = seg == KA ? KA * S : ((seg * S + phi) & ~63) - phi;
+      hi = (seg == K - 1 && !kPhaseChp) ? K * S : (((seg + 1) * S + phi) & ~63) - phi;
+    }
+    if (hi < lo) hi = lo;
+  }
   __device__ __forceinline__ bool chunk(int seg, int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
-    if constexpr (CHP != 0) {
+    if constexpr (kPhaseChp) {
+      if (i >= MAXI) return false;
+      if (i >= MAXI_MAIN) {   // head (direction A, segment 0) / tail (direction B, last segment) of every row's piece
+        if (!(DIR > 0 ? seg == 0 : seg == K - 1)) return false;
+        const unsigned o = (unsigned)((i - MAXI_MAIN) * 64 + lane);
+        const unsigned tt = o / 3u, c = o - tt * 3u;
+        const int ph = (int)(((ph0 + tt) * (unsigned)PMOD) & 63u);
+        const int start = DIR > 0 ? 0 : ((K * S + ph) & ~63) - ph;
+        const int end = DIR > 0 ? ((64 - ph) & 63) : K * S;
+        const int at = start + (int)(c * 16u);
+        const bool ok = tt < (unsigned)TPW && at < end;
+        g = ok ? tt * (unsigned)PIECE + (unsigned)at : 0x7ffffff0u;
+        loff = ok ? tt * (unsigned)ROWB + (unsigned)((seg & 1) * S + at - seg * S) : 0u;
+        return true;
+      }
+      const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
+      int lo_l, hi_l;
+      range_of_phase(seg, phi_l, lo_l, hi_l);
+      bool ok = (int)(rr * 16u) < hi_l - lo_l;
+      if ((i + 1) * RPI > TPW) ok = ok && tr < (unsigned)(TPW - i * RPI);
+      g = ok ? gl + (unsigned)(i * RPI * PIECE) + (unsigned)lo_l : 0x7ffffff0u;
+      loff = ll + slot_select(seg, lo_l, rr) + (unsigned)(i * RPI * ROWB);
+      return true;
+    } else if constexpr (kPhase) {
+      if (i >= MAXI) return false;
+      const unsigned o = (unsigned)(i * 64 + lane);
+      const unsigned tt = o / (unsigned)MAXCH_P, r = o - tt * (unsigned)MAXCH_P;
+      const int phi = (int)(((ph0 + tt) * (unsigned)PMOD) & 63u);
+      int lo_l, hi_l;
+      range_of_phase(seg, phi, lo_l, hi_l);
+      const bool ok = tt < (unsigned)TPW && (int)(r * 16u) < hi_l - lo_l;
+      g = ok ? tt * (unsigned)PIECE + (unsigned)lo_l + r * 16u : 0x7ffffff0u;
+      loff = ok ? (unsigned)(tt * (unsigned)ROWB + slot_select(seg, lo_l, r) + r * 16u) : 0u;
+      return true;
+    } else if constexpr (CHP != 0) {
       if (i >= MAXI) return false;
       const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
       const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
@@ -163,7 +229,7 @@ struct MtgSlabOut {
       pn = 0;
       int lo = 0, hi = 0;
       range_of(seg, lo, hi);
-      if (hi <= lo) return;
+      if (!kPhase && hi <= lo) return;
       const int nch = (hi - lo) >> 4;
       const unsigned sel = CHP != 0 ? slot_select(seg, lo, (unsigned)lane % (unsigned)(CHP ? CHP : 1)) : 0u;
       fence();
@@ -199,7 +265,7 @@ struct MtgSlabOut {
       int lo = 0, hi = 0;
       range_of(seg, lo, hi);
       __builtin_amdgcn_sched_barrier(0);
-      if (hi > lo) {
+      if (kPhase || hi > lo) {
         const int nch = (hi - lo) >> 4;      // 16-byte chunks per trajectory
         const unsigned sel = CHP != 0 ? slot_select(seg, lo, (unsigned)lane % (unsigned)(CHP ? CHP : 1)) : 0u;
 #pragma unroll
