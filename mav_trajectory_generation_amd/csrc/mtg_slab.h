@@ -97,16 +97,19 @@ struct MtgSlabOut {
   static constexpr int PMOD = PIECE & 63;
   static constexpr bool kPhase = PMOD != 0 && S >= 64;
   static constexpr int MAXCH_P = (S + 63) / 16;
-  // Segments of at most 256 bytes (N = 10, D = 3: S = 240): memory-aligned ranges are at most 16 chunks once the misaligned
-  // head (direction A, segment 0) and tail (direction B, last segment) of the piece -- up to 48 bytes each -- go out in a
-  // pass of their own; the ranges then use the cheap power-of-two mapping with a per-lane phase (the phase of row
-  // tr + 4 i does not depend on the pass i: 4 * PMOD is a multiple of 64).
-  static constexpr bool kPhaseChp = kPhase && ((S + 63) / 64) * 64 <= 256;
   static constexpr int MAXCH = max_range_chunks();
-  // chunks per trajectory row of a store instruction: the next power of two where at most 1/8 of the lanes idle, else the
-  // generic mapping (N = 8: 192-byte ranges = 12 chunks; padded to 16 a quarter of every store instruction would be idle)
-  static constexpr int pow2_rows(int m) { return m <= 4 ? 4 : (m <= 8 ? 8 : (m <= 16 ? 16 : 0)); }
-  static constexpr int CHP = kPhaseChp ? 16 : ((!kPhase && pow2_rows(MAXCH) != 0 && 8 * (pow2_rows(MAXCH) - MAXCH) <= pow2_rows(MAXCH)) ? pow2_rows(MAXCH) : 0);
+  // Row mapping: a store instruction covers RPI = 64 / CHP whole rows of CHP chunk slots each (CHP = the largest range, in
+  // chunks); lane -> (row, chunk) is computed ONCE per kernel (gl, ll below), every chunk of every drain is that plus a
+  // compile-time constant.  Used whenever at most 8 of the 64 lanes idle (CHP = 16: none; 12 or 20: four); otherwise the
+  // generic mapping (chunk o of a range -> row o / nch: a multiply-high and a slot selection per chunk).
+  static constexpr int row_width() { return kPhase ? ((S + 63) / 64) * 4 : MAXCH; }
+  static constexpr bool row_ok(int w) { return w >= 4 && w <= 32 && 64 - (64 / w) * w <= 8; }
+  // (rows that are not a power of two wide only up to K = 16: the register-tight K = 32 hybrids of N = 8 / 12 spill to scratch
+  // with them -- 13 -> 27 us and 38 -> 54 us per 2500-trajectory bucket -- and keep the generic mapping)
+  static constexpr bool pow2(int w) { return (w & (w - 1)) == 0; }
+  static constexpr int CHP = (row_ok(row_width()) && (pow2(row_width()) || K <= 16)) ? row_width() : 0;
+  static constexpr bool kPhaseChp = kPhase && CHP != 0;   // phase mapping with rows: the piece's misaligned head / tail (up to 48
+                                                          // bytes each) go out in a pass of their own, ranges stay <= CHP chunks
   // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
   // slab when its segment is committed, the < 64-byte tail it leaves behind is read with the next range, i.e. before the
   // segment after that overwrites the slot (LDS operations of a wave execute in order) -- 2 * S bytes per trajectory
@@ -171,9 +174,12 @@ struct MtgSlabOut {
         return true;
       }
       const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
+      // phase of row tr + i RPI (independent of the pass where RPI * PMOD is a multiple of 64, e.g. RPI = 4)
+      const int phi = (RPI * PMOD) % 64 == 0 ? phi_l : (int)(((unsigned)phi_l + (unsigned)(i * RPI * PMOD)) & 63u);
       int lo_l, hi_l;
-      range_of_phase(seg, phi_l, lo_l, hi_l);
+      range_of_phase(seg, phi, lo_l, hi_l);
       bool ok = (int)(rr * 16u) < hi_l - lo_l;
+      if (RPI * CHP < 64) ok = ok && tr < (unsigned)RPI;
       if ((i + 1) * RPI > TPW) ok = ok && tr < (unsigned)(TPW - i * RPI);
       g = ok ? gl + (unsigned)(i * RPI * PIECE) + (unsigned)lo_l : 0x7ffffff0u;
       loff = ll + slot_select(seg, lo_l, rr) + (unsigned)(i * RPI * ROWB);
@@ -192,11 +198,12 @@ struct MtgSlabOut {
     } else if constexpr (CHP != 0) {
       if (i >= MAXI) return false;
       const unsigned rr = (unsigned)lane % (unsigned)CHP, tr = (unsigned)lane / (unsigned)CHP;
-      const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP;
+      const bool all_rows = (i + 1) * RPI <= TPW, all_chunks = nch == CHP, all_lanes = RPI * CHP == 64;
       g = gl + (unsigned)(i * RPI * PIECE + lo);
-      if (!all_chunks || !all_rows) {
+      if (!all_chunks || !all_rows || !all_lanes) {
         bool ok = true;
         if (!all_chunks) ok = ok && rr < (unsigned)nch;
+        if (!all_lanes) ok = ok && tr < (unsigned)RPI;
         if (!all_rows) ok = ok && tr < (unsigned)(TPW - i * RPI);
         g = ok ? g : 0x7ffffff0u;
       }
