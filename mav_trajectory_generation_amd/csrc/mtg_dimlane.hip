@@ -1,5 +1,5 @@
 // Dimension-in-lane kernel instantiations (mtg_dimlane.h, mtg_dimlane_variants.inc; further chain lengths in
-// mtg_dimlane_h4 / h5 / h6.hip).  These translation units are compiled with -mllvm -amdgpu-kernarg-preload-count=14: the
+// mtg_dimlane_h4 / h5 / h6.hip (K <= 15) and mtg_dimlane_h4b / h5b / h6b.hip (K = 17 .. 31)).  These translation units are compiled with -mllvm -amdgpu-kernarg-preload-count=14: the
 // kernels' arguments arrive in user SGPRs at wave launch.
 #define MTG_DL_TABLE_FN mtg_dimlane_main
 #define MTG_DL_TABLE_INC "mtg_dimlane_variants.inc"
@@ -8,10 +8,14 @@
 const MtgDimlaneEntry* mtg_dimlane_more_h4(int* count);
 const MtgDimlaneEntry* mtg_dimlane_more_h5(int* count);
 const MtgDimlaneEntry* mtg_dimlane_more_h6(int* count);
+const MtgDimlaneEntry* mtg_dimlane_more_h4b(int* count);
+const MtgDimlaneEntry* mtg_dimlane_more_h5b(int* count);
+const MtgDimlaneEntry* mtg_dimlane_more_h6b(int* count);
 
 const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask) {
   typedef const MtgDimlaneEntry* (*TableFn)(int*);
-  static const TableFn tables[] = {mtg_dimlane_main, mtg_dimlane_more_h4, mtg_dimlane_more_h5, mtg_dimlane_more_h6};
+  static const TableFn tables[] = {mtg_dimlane_main,    mtg_dimlane_more_h4,  mtg_dimlane_more_h5, mtg_dimlane_more_h6,
+                                   mtg_dimlane_more_h4b, mtg_dimlane_more_h5b, mtg_dimlane_more_h6b};
   for (TableFn fn : tables) {
     int n = 0;
     const MtgDimlaneEntry* tab = fn(&n);

@@ -45,6 +45,7 @@ SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 4, 3, 4, 1)
           (10, 32, 3, 4, 1), (8, 32, 3, 3, 1), (12, 16, 3, 5, 1), (12, 32, 3, 5, 1)]   # long chains: registers + workspace (MtgCfg::WSJ)
 # every other chain length up to 15 of the three standard shapes (mtg_dimlane_more_h*.inc), odd ones included
 SHAPES += [(n, k, 3, n // 2 - 1, 1) for n in (8, 10, 12) for k in (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15)]
+SHAPES += [(n, k, 3, n // 2 - 1, 1) for n in (8, 10, 12) for k in range(17, 32)]   # mtg_dimlane_more_h*b.inc
 
 
 # shapes that also have a one-dimension-per-workgroup static variant (csrc/mtg_variants.inc): same instruction stream per lane

@@ -6,7 +6,7 @@ import torch
 import mav_trajectory_generation_amd as m
 ctx = m.Context(0)
 NN = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for K in (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 20, 50, 100):
+for K in (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 20, 24, 27, 31, 50, 100):
     masks = m.ends_full_masks(NN, K, 1)
     plan = m.Plan(ctx, NN, 3, K, NN // 2 - 1, masks)
     for B in (2500, 100_000):
