@@ -15,6 +15,7 @@ bash tools/gpu_profile2.sh r02_resident --buffer-sets 1
 cp $R/gpurun_out/r02_rotating_b10000_kernel_stats.csv $R/gpurun_out/r02_rotating_b10000_pmc_traffic.json $R/gpurun_out/r02_resident_b10000_kernel_stats.csv $R/gpurun_out/r02_resident_b10000_pmc_traffic.json $OUT/ 2>/dev/null
 python tools/bench_configs.py 2>&1 | grep "^{" > $OUT/configs.jsonl
 python tools/bench_configs.py long 2>&1 | grep "^{" >> $OUT/configs.jsonl
+(for n in 10 8 12; do python tools/bench_other_k.py $n 2>&1 | grep "^{"; done) > $OUT/other_chain_lengths.jsonl
 python tools/bench_mixed.py 2500 merged 2>&1 | grep "^{" > $OUT/mixed_config4.jsonl
 python tools/bench_mixed.py 10000 merged 2>&1 | grep "^{" >> $OUT/mixed_config4.jsonl
 tools/micro/stream_overlap.bin > $OUT/stream_overlap_microbench.txt 2>&1
