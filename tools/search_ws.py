@@ -1,26 +1,57 @@
-import subprocess, sys, re, json, concurrent.futures as cf
-CSRC='/root/repo/mav_trajectory_generation_amd/csrc'
-SHAPES={4:(15,1,15,3), 5:(31,1,31,4), 6:(63,1,63,5)}
-LDSMAX={4:8,5:5,6:3}
-def res(H,K,WS,LS):
-    ms,mi,me,dv=SHAPES[H]
-    cfg=f"MtgCfg<{H},1,{K},{ms},{mi},{me},{dv},0,{WS},{3 if WS>0 else 0},{LS}>"
-    src=f"/tmp/s_{H}_{K}_{WS}.hip"
-    open(src,'w').write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<'+cfg+', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, double*);\n')
-    p=subprocess.run(['/opt/rocm/bin/hipcc','--offload-arch=gfx950','-O3','-std=c++17','-I'+CSRC,'-I/root/repo/include','-mllvm','-disable-machine-licm','-mllvm','-amdgpu-kernarg-preload-count=14','-mllvm','-pragma-unroll-threshold=1000000','--cuda-device-only','-c',src,'-o',src+'.o','-Rpass-analysis=kernel-resource-usage'],capture_output=True,text=True)
-    t=p.stderr
-    if 'error' in t: return None
-    sc=int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)',t).group(1)); sp=int(re.search(r'VGPRs Spill: (\d+)',t).group(1))
-    return sc,sp
-def best(H,K):
-    kc=(K+1)//2
-    for WS in range(0,kc+1):
-        LS=min(WS,LDSMAX[H])
-        r=res(H,K,WS,LS)
-        if r is None: return (H,K,None,None,'compile error')
-        if r[0]==0 and r[1]<=16: return (H,K,WS,LS,r)
-    return (H,K,None,None,'no fit')
-jobs=[(H,K) for H in (4,5,6) for K in range(3,17) if K % 2 == 1]
-with cf.ThreadPoolExecutor(7) as ex:
-    for r in ex.map(lambda a: best(*a), jobs):
-        print(r, flush=True)
+"""Pick the workspace / LDS step counts (MtgCfg::WSJ, ::LSJ) of a dimension-in-lane variant: the smallest number of
+workspace steps whose kernel compiles without scratch spills (hipcc -Rpass-analysis=kernel-resource-usage), the last
+LS of them in LDS (as many as fit with two 2-wave workgroups per CU).  Prints one line per shape in the form used by
+csrc/mtg_dimlane_more_h*.inc.  CPU only (cross-compiles for gfx950).
+
+usage: python tools/search_ws.py K_FIRST K_LAST [H ...]      (H = N / 2 in {4, 5, 6}; default all three)"""
+import concurrent.futures as cf
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
+SHAPES = {4: (15, 1, 15, 3), 5: (31, 1, 31, 4), 6: (63, 1, 63, 5)}      # (start mask, interior mask, end mask, derivative)
+LDS_STEPS = {4: 8, 5: 5, 6: 3}                                          # steps that fit the LDS next to the output slabs
+REG_STEPS = {4: 9, 5: 6, 6: 2}                                          # where the search starts (steps the registers hold)
+
+
+def resources(H, K, WS, LS):
+    ms, mi, me, dv = SHAPES[H]
+    cfg = f"MtgCfg<{H},1,{K},{ms},{mi},{me},{dv},0,{WS},{3 if WS > 0 else 0},{LS}>"
+    src = f"/tmp/search_ws_{H}_{K}_{WS}.hip"
+    with open(src, "w") as f:
+        f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<' + cfg +
+                ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, double*);\n')
+    p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+                        "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-mllvm",
+                        "-pragma-unroll-threshold=1000000", "--cuda-device-only", "-c", src, "-o", src + ".o",
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    if "error" in p.stderr:
+        return None
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", p.stderr).group(1))
+    spills = int(re.search(r"VGPRs Spill: (\d+)", p.stderr).group(1))
+    return scratch, spills
+
+
+def best(H, K):
+    kc = (K + 1) // 2
+    for WS in range(max(0, kc - REG_STEPS[H]), kc + 1):
+        LS = min(WS, LDS_STEPS[H])
+        r = resources(H, K, WS, LS)
+        if r is None:
+            return f"// H={H} K={K}: compile error"
+        if r[0] == 0 and r[1] <= 16:      # no scratch; a few registers parked in AGPRs are fine
+            ms, mi, me, dv = SHAPES[H]
+            return f"MTG_DLW({H}, {K}, {ms}, {mi}, {me}, {dv}, 3, {2 if K <= 8 else 1}, 0, 0, {WS}, {LS})   // spilled VGPRs: {r[1]}"
+    return f"// H={H} K={K}: no setting without scratch"
+
+
+if __name__ == "__main__":
+    k0, k1 = int(sys.argv[1]), int(sys.argv[2])
+    hs = [int(x) for x in sys.argv[3:]] or [4, 5, 6]
+    jobs = [(H, K) for H in hs for K in range(k0, k1 + 1)]
+    with cf.ThreadPoolExecutor(max(1, (os.cpu_count() or 2) - 1)) as ex:
+        for line in ex.map(lambda a: best(*a), jobs):
+            print(line, flush=True)
