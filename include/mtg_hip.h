@@ -164,6 +164,13 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
 int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
                               const double* const* times, const double* const* d_fixed, double* const* coeffs,
                               uint32_t flags);
+/* The same with two caller-owned hipEvent_t (either may be NULL) recorded on the context's stream immediately before the
+ * first and after the last launch, inside the call: a caller that times the queue with events does not measure its own
+ * latency between recording the start event and enqueueing the first launch (several microseconds from Python -- as
+ * much as a kernel of this library).                                                                                  */
+int mtg_solve_linear_sequence_events(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
+                                     const double* const* times, const double* const* d_fixed, double* const* coeffs,
+                                     uint32_t flags, void* start_event, void* stop_event);
 
 /* Replaces updateSegmentTimes() + setFreeConstraints() (LIN:500-508): coefficients from
  * caller-provided free constraints, no solve (the nonlinear optimiser's path,

@@ -51,6 +51,9 @@ EXPORTS = {
                                                c_double_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_solve_linear_sequence": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "mtg_solve_linear_sequence_events": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
+                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                        ctypes.c_void_p, ctypes.c_void_p]),
     "mtg_mellinger_cost_gradient": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                    c_double_p, ctypes.c_double, ctypes.c_double, c_double_p, c_double_p]),
     "mtg_shard_range": (None, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

@@ -720,17 +720,27 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false, trajectory_status);
 }
 
+int mtg_solve_linear_sequence_events(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
+                                     const double* const* times, const double* const* d_fixed, double* const* coeffs,
+                                     uint32_t flags, void* start_event, void* stop_event) {
+  if (!plan || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
+  if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = plan->ctx;
+  if (start_event) {
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)start_event, ctx->stream));
+  }
+  int rc = MTG_OK;
+  for (int32_t i = 0; i < n && rc == MTG_OK; ++i)
+    rc = solve_impl(plan, batch, layout, times[i], d_fixed ? d_fixed[i] : nullptr, coeffs[i], nullptr, nullptr, flags, false);
+  if (stop_event) MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)stop_event, ctx->stream));
+  return rc;
+}
+
 int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
                               const double* const* times, const double* const* d_fixed, double* const* coeffs,
                               uint32_t flags) {
-  if (!plan || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
-  if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
-  for (int32_t i = 0; i < n; ++i) {
-    const int rc = solve_impl(plan, batch, layout, times[i], d_fixed ? d_fixed[i] : nullptr, coeffs[i], nullptr, nullptr,
-                              flags, false);
-    if (rc != MTG_OK) return rc;
-  }
-  return MTG_OK;
+  return mtg_solve_linear_sequence_events(plan, n, batch, layout, times, d_fixed, coeffs, flags, nullptr, nullptr);
 }
 
 namespace {
