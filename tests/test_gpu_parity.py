@@ -651,3 +651,34 @@ def test_cross_structure_dimlane_request(ctx):
     assert e.value.code == -2
     req.close()
     solver.close()
+
+
+def test_sequence_with_events(ctx):
+    """mtg_solve_linear_sequence_events: n independent batches enqueued by one call, start / stop events recorded inside
+    the call on the context's stream; results equal single solves, the events bracket the launches."""
+    import ctypes
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    sets = []
+    for s in range(3):
+        t, f = m.random_waypoint_batch(1000, 8, 3, 10, masks, seed=40 + s, device="cuda", layout="soa")
+        sets.append((t, f, torch.zeros((1000, 8, 3, 10), dtype=torch.float64, device="cuda")))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(ctx.stream):
+        e0.record(ctx.stream)
+        e1.record(ctx.stream)          # materialise the hipEvent_t handles
+        arr = [(ctypes.c_void_p * 3)(*[x[j].data_ptr() for x in sets]) for j in range(3)]
+        lay = plan.layout(1000, "soa")
+        rc = plan.lib.mtg_solve_linear_sequence_events(plan.handle, 3, 1000, ctypes.byref(lay), arr[0], arr[1], arr[2], 0,
+                                                       ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event))
+        assert rc == 0
+        torch.cuda.synchronize()
+    ctx.sync()
+    assert e0.elapsed_time(e1) > 0.0
+    for t, f, co in sets:
+        ref, _, _ = plan.solve(t, f, layout="soa")
+        ctx.sync()
+        assert torch.equal(co, ref)
+    plan.close()
