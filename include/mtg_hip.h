@@ -278,6 +278,21 @@ int mtg_multi_solve(mtg_multi* multi);              /* asynchronous on the conte
 int mtg_multi_launch_count(const mtg_multi* multi); /* kernel launches one mtg_multi_solve enqueues */
 int mtg_multi_destroy(mtg_multi* multi);
 
+/* ---- synthetic inputs and result check on the device (no tensor library needed) -------------
+ * mtg_generate_waypoints: fills `times` / `d_fixed` (device pointers, any layout) of `batch` trajectories of the plan's
+ * structure with the reference's random-waypoint recipe (src/vertex.cpp:27-82 createRandomVertices: positions uniform in
+ * [-box, box]^D, consecutive vertices more than 0.2 apart, start / goal at rest; :255-272 estimateSegmentTimesNfabian with
+ * the default magic constant 6.5); other fixed derivatives of interior vertices: random direction, magnitude <= v_max /
+ * a_max / 1.  yaw_dimension != 0 with D = 4: the last dimension is an angle in [-3 pi, 3 pi].  Counter-based random
+ * numbers: reproducible per (seed, trajectory), distribution-equivalent (not bit-equal) to the mt19937 original.
+ * Asynchronous on the context's stream.
+ * mtg_compare_coefficients: max over polynomials of ||a - b||_inf / ||b||_inf (the parity tests' norm-wise measure) and the
+ * max absolute difference of two device buffers of n_polynomials x n_coeffs doubles; synchronous.                      */
+int mtg_generate_waypoints(mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint64_t seed, double box, double v_max,
+                           double a_max, int32_t yaw_dimension, double* times, double* d_fixed);
+int mtg_compare_coefficients(mtg_context* ctx, const double* a, const double* b, int64_t n_polynomials, int32_t n_coeffs,
+                             double* max_normwise_rel, double* max_abs);
+
 /* ---- several GPUs from one host process -----------------------------------------------------
  * The path shards by independent trajectories (LIN:339-379 touches only one optimiser's state): shard s of G is the
  * contiguous range mtg_shard_range(batch, G, s), solved on device s by that device's own context / plan / stream, with

@@ -56,6 +56,11 @@ EXPORTS = {
                                                         ctypes.c_void_p, ctypes.c_void_p]),
     "mtg_mellinger_cost_gradient": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p,
                                                    c_double_p, ctypes.c_double, ctypes.c_double, c_double_p, c_double_p]),
+    "mtg_generate_waypoints": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_uint64,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_double_p,
+                                              c_double_p]),
+    "mtg_compare_coefficients": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "mtg_shard_range": (None, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "mtg_device_group_create": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]),
     "mtg_device_group_destroy": (ctypes.c_int, [ctypes.c_void_p]),

@@ -67,6 +67,19 @@ class Context:
     def sync(self):
         _check(self.lib, self.lib.mtg_context_sync(self.handle), self.handle)
 
+    def compare_coefficients(self, a, b):
+        """(max over polynomials of ||a - b||_inf / ||b||_inf, max |a - b|) of two coefficient tensors [..., N], computed on
+        the device (C ABI: mtg_compare_coefficients).  Synchronous."""
+        assert a.shape == b.shape and a.is_cuda and b.is_cuda and a.is_contiguous() and b.is_contiguous()
+        n = a.shape[-1]
+        rel, ab = ctypes.c_double(0), ctypes.c_double(0)
+        cur = self._enter()
+        rc = self.lib.mtg_compare_coefficients(self.handle, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                               a.numel() // n, n, ctypes.byref(rel), ctypes.byref(ab))
+        self._leave(cur)
+        _check(self.lib, rc, self.handle)
+        return rel.value, ab.value
+
     def selftest_rcp(self, n: int = 1 << 20) -> float:
         out = ctypes.c_double(0)
         _check(self.lib, self.lib.mtg_selftest_rcp(self.handle, n, ctypes.byref(out)), self.handle)
@@ -193,6 +206,27 @@ class Plan:
     @staticmethod
     def _ptr(t):
         return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def generate_waypoints(self, batch: int, seed: int = 0, layout: str = "soa", box: float = 10.0, v_max: float = 3.0,
+                           a_max: float = 5.0, yaw_dim: bool = False):
+        """Random-waypoint inputs of this plan's structure generated by the library's own kernel (C ABI:
+        mtg_generate_waypoints; the torch generator of workload.py has the same semantics).  Returns (times, d_fixed) float64
+        CUDA tensors in `layout`.  Asynchronous on the library's stream (ordered against torch's current stream)."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        if layout == "soa":
+            t = torch.empty((self.K, batch), dtype=torch.float64, device=dev)
+            f = torch.empty((self.D, self.n_fixed, batch), dtype=torch.float64, device=dev)
+        else:
+            t = torch.empty((batch, self.K), dtype=torch.float64, device=dev)
+            f = torch.empty((batch, self.D, self.n_fixed), dtype=torch.float64, device=dev)
+        lay = self.layout(batch, layout)
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_generate_waypoints(self.handle, batch, ctypes.byref(lay), int(seed) & (2**64 - 1), float(box),
+                                             float(v_max), float(a_max), 1 if yaw_dim else 0, self._ptr(t), self._ptr(f))
+        self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+        return t, f
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
               coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True,

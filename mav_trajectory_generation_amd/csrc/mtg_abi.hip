@@ -270,6 +270,15 @@ int mtg_context_destroy(mtg_context* ctx) {
   return MTG_OK;
 }
 
+// used by mtg_workload.hip: a plan's context, shape and device-resident mask table
+int mtg_plan_context_tables(const mtg_plan* plan, mtg_context** ctx, int* n_coeffs, int* dimension, int* n_segments,
+                            const int** device_masks) {
+  if (!plan || !ctx || !n_coeffs || !dimension || !n_segments || !device_masks) return MTG_ERR_INVALID_ARGUMENT;
+  *ctx = plan->ctx; *n_coeffs = plan->N; *dimension = plan->D; *n_segments = plan->K;
+  *device_masks = plan->d_tables;     // [K + 1] fixed masks, then the offset tables
+  return MTG_OK;
+}
+
 // used by the other translation units of the library (mtg_sample.hip): the context's stream and device
 int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device) {
   if (!ctx || !stream || !device) return MTG_ERR_INVALID_ARGUMENT;

@@ -682,3 +682,56 @@ def test_sequence_with_events(ctx):
         ctx.sync()
         assert torch.equal(co, ref)
     plan.close()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+def test_device_side_generator_and_compare(ctx, layout):
+    """mtg_generate_waypoints / mtg_compare_coefficients: inputs with the reference's
+    random-waypoint recipe made by the library's own kernel, results checked on the device."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    for (n, k, dim, d, interior, yaw) in ((10, 8, 3, 4, 1, False), (10, 16, 4, 4, 7, True), (8, 5, 3, 3, 1, False)):
+        masks = m.ends_full_masks(n, k, interior)
+        plan = m.Plan(ctx, n, dim, k, d, masks)
+        bsz = 3000
+        t, f = plan.generate_waypoints(bsz, seed=77, layout=layout, yaw_dim=yaw)
+        t2, f2 = plan.generate_waypoints(bsz, seed=77, layout=layout, yaw_dim=yaw)
+        t3, _ = plan.generate_waypoints(bsz, seed=78, layout=layout, yaw_dim=yaw)
+        torch.cuda.synchronize()
+        assert torch.equal(t, t2) and torch.equal(f, f2) and not torch.equal(t, t3)      # reproducible per seed
+        tb = t.t() if layout == "soa" else t                       # [B][K]
+        fb = f.permute(2, 0, 1) if layout == "soa" else f          # [B][D][n_fixed]
+        assert torch.isfinite(tb).all() and torch.isfinite(fb).all() and float(tb.min()) > 0.0
+        # position columns: the first fixed slot of every vertex
+        h = n // 2
+        cols, c = [], 0
+        for v in range(k + 1):
+            cols.append(c)
+            c += bin(masks[v]).count("1")
+        pos = fb[:, :, cols]                                       # [B][D][K+1]
+        lim = torch.full((dim,), 10.0, dtype=torch.float64, device="cuda")
+        if yaw:
+            lim[3] = 3 * np.pi
+        assert bool((pos.abs() <= lim[None, :, None]).all())
+        dist = (pos[:, :, 1:] - pos[:, :, :-1]).norm(dim=1)        # [B][K]
+        assert float((dist <= 0.2).double().mean()) < 1e-3
+        want = dist / 3.0 * 2 * (1.0 + 6.5 * 3.0 / 5.0 * torch.exp(-dist / 3.0 * 2))
+        assert float(((tb - want).abs() / want).max()) < 1e-12    # estimateSegmentTimesNfabian
+        # end vertices at rest: every fixed derivative above position is zero
+        assert float(fb[:, :, 1:h].abs().max()) == 0.0 and float(fb[:, :, c - h + 1:].abs().max()) == 0.0
+        # roughly uniform positions: mean ~ 0, std ~ box / sqrt(3)
+        p0 = pos[:, 0, :].flatten()
+        assert abs(float(p0.mean())) < 0.3 and abs(float(p0.std()) - 10.0 / 3 ** 0.5) < 0.3
+        co, _, _ = plan.solve(t.contiguous(), f.contiguous(), layout=layout)
+        ctx.sync()
+        assert torch.isfinite(co).all()
+        # on-device comparison against torch: identical buffers, then a perturbed one
+        rel, ab = ctx.compare_coefficients(co, co.clone())
+        assert rel == 0.0 and ab == 0.0
+        other = co.clone()
+        other[5, 1, 0, 2] += 1e-6
+        rel, ab = ctx.compare_coefficients(other, co)
+        den = co.abs().amax(dim=-1).clamp_min(1e-300)
+        want_rel = float(((other - co).abs().amax(dim=-1) / den).max())
+        assert abs(rel - want_rel) <= 1e-12 * want_rel and abs(ab - float((other - co).abs().max())) < 1e-18
+        plan.close()
