@@ -735,3 +735,15 @@ def test_device_side_generator_and_compare(ctx, layout):
         want_rel = float(((other - co).abs().amax(dim=-1) / den).max())
         assert abs(rel - want_rel) <= 1e-12 * want_rel and abs(ab - float((other - co).abs().max())) < 1e-18
         plan.close()
+
+
+def test_plain_c_consumer_of_the_abi():
+    """tools/c/roundtrip.c: a C program that sees only include/mtg_hip.h generates a batch on the device, solves it with
+    two kernels, compares the results on the device and times the launch (exit code 0 = the two kernels agree to 1e-10)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "c", "roundtrip")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    for argv in (["20000", "8"], ["3000", "11"]):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "trajectories/s" in r.stdout
