@@ -46,6 +46,7 @@ SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 4, 3, 4, 1)
 # every other chain length up to 15 of the three standard shapes (mtg_dimlane_more_h*.inc), odd ones included
 SHAPES += [(n, k, 3, n // 2 - 1, 1) for n in (8, 10, 12) for k in (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15)]
 SHAPES += [(n, k, 3, n // 2 - 1, 1) for n in (8, 10, 12) for k in range(17, 32)]   # mtg_dimlane_more_h*b.inc
+SHAPES += [(10, 50, 3, 4, 1), (8, 50, 3, 3, 1)]
 
 
 # shapes that also have a one-dimension-per-workgroup static variant (csrc/mtg_variants.inc): same instruction stream per lane
