@@ -183,6 +183,9 @@ def test_generators_bit_exact(k, dim, seed):
     (10, 4, 1, 3, None, 30),                                 # n_free == 0 (LIN:343-349)
     (10, 4, 3, 2, [3, 1, 1, 7], 30),                         # free end-vertex slots
     (6, 2, 4, 3, None, 30), (4, 1, 3, 2, None, 30), (2, 0, 3, 2, None, 30),
+    # chain lengths between the BASELINE ones (odd K included): every K = 2 .. 32 has its own GPU kernel since round 2
+    (10, 4, 5, 3, None, 30), (10, 4, 11, 3, None, 20), (10, 4, 20, 3, None, 12), (10, 4, 27, 3, None, 12),
+    (8, 3, 7, 3, None, 30), (8, 3, 21, 3, None, 12), (10, 4, 50, 3, None, 12),
 ])
 def test_fresh_batches_restatements_vs_live_reference(n, d, k, dim, masks, bsz):
     masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 20260924, masks)
