@@ -72,7 +72,7 @@ struct MtgSlabOut {
   static constexpr int max_range_chunks() {
     int m = 0;
     for (int seg = (DIR > 0 ? 0 : KA); seg < (DIR > 0 ? KA : K); ++seg) {
-      int lo, hi;
+      int lo = 0, hi = 0;
       range_of(seg, lo, hi);
       if ((hi - lo) / 16 > m) m = (hi - lo) / 16;
     }
