@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: trajectories/s for 8-segment, N=10, 3-D minimum-snap solveLinear().
 
-One "step" = one pass of the hot path (fused updateSegmentTimes + constructR + solve + coefficient recovery: ONE kernel
-launch through the C ABI, mtg_solve_linear) over one batch of synthetic random-waypoint trajectories that is already
-resident in HBM.  The timed loop ROTATES over `--buffer-sets` (default 16) independent input/output buffer sets, so that
-with the default workload (24 MB per set, 382 MB in total > the 256 MiB Infinity Cache) every step's reads and writes
-really go to HBM; the same loop over ONE resident set is reported beside it (`extra.resident_buffers`).
+One "step" = one pass of the hot path (fused updateSegmentTimes + constructR + solve + coefficient recovery) over one batch
+of synthetic random-waypoint trajectories that is already resident in HBM.  The K timed steps are K INDEPENDENT batches
+handed to the library by ONE call of the C ABI's mtg_solve_linear_sequence_events, rotating over `--buffer-sets` (default
+16) independent input/output buffer sets (24 MB per set, 382 MB in total > the 256 MiB Infinity Cache: every step's reads
+and writes really go to HBM).  `--sequence queue` (default): the library runs the queue as ONE persistent launch whose
+workgroups walk the tiles of all batches (<= 96 batches per launch) -- the throughput form, `value`;
+`--sequence launches`: one kernel launch per batch back to back on one stream -- the latency form of round 2, reported
+beside it as `extra.one_launch_per_batch`.  The same loop over ONE resident buffer set is `extra.resident_buffers`.
 
 N GPUs = N processes, one per GPU (`--gpus N` spawns them itself via torch.distributed.run when not already launched
-that way).  The path shards embarrassingly: every rank solves its own batch, RCCL is used only for the
+that way).  The path shards embarrassingly: every rank solves its own batches, RCCL is used only for the
 barrier / max-reduce of the timing and -- reported separately, never part of `value` -- the optional final all_gather of
 the coefficients, chunked so that chunk i's gather overlaps chunk i+1's solve  => "scaling": "weak".
 
 `--config` picks the BASELINE.json configuration (per-GPU share): 2 = 10k x (K=8, N=10, D=3) [default, the configuration
-the metric is quoted on], 3 = 125k of the same (1M over 8 GPUs), 5 = 12.5k x (K=16, N=10, D=4, velocity + acceleration
-fixed at interior vertices; 100k over 8 GPUs).
+the metric is quoted on], 3 = 125k of the same (1M over 8 GPUs), 4 = the mixed request (N in {8, 10, 12} x K in {4, 8, 16,
+32}, D = 3: 12 buckets x 2500 = 30k trajectories per step, ONE cross-structure launch per step through mtg_multi_solve),
+5 = 12.5k x (K=16, N=10, D=4, velocity + acceleration fixed at interior vertices; 100k over 8 GPUs).
+`--next` adds the SURVEY 8(f) rows (sampling, extrema / time scaling, Mellinger cost + gradient) as `extra.next`.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch (SURVEY.md 8(d):
-8*(K + D*n_fixed + K*D*N) per trajectory) / mean launch duration, measured with HIP events recorded on the launch stream
-around the SAME timed region that `value` comes from.  `cpu_baseline` = the reference algorithm's CPU restatement
-(oracle/, the checker -- never the product path) timed on this box's host cores.
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (8*(K + D*n_fixed + K*D*N) per
+trajectory) of the timed steps / their duration on the device, measured with HIP events recorded by the library on the
+launch stream immediately around the SAME launches that `value` comes from.  `cpu_baseline` = the reference algorithm's
+CPU restatement (oracle/, the checker -- never the product path) timed on this box's host cores.
 """
 import argparse
 import ctypes
@@ -38,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 CONFIGS = {
     2: dict(name="BASELINE configs[1]", batch=10_000, K=8, D=3, interior=1, yaw=False),
     3: dict(name="BASELINE configs[2] per-GPU share (1M / 8)", batch=125_000, K=8, D=3, interior=1, yaw=False),
+    4: dict(name="BASELINE configs[3]: mixed N / K request", batch=2_500, K=None, D=3, interior=1, yaw=False),
     5: dict(name="BASELINE configs[4] per-GPU share (100k / 8)", batch=12_500, K=16, D=4, interior=7, yaw=True),
 }
 
@@ -61,6 +67,11 @@ def parse_args(argv=None):
     ap.add_argument("--same-device", action="store_true", help="all ranks on HIP device 0 (multi-process tests on a 1-GPU box)")
     ap.add_argument("--plumbing-only", action="store_true", help="spawn / rendezvous / reduce only, no GPU work (CPU test)")
     ap.add_argument("--extra", action="store_true", help="also time the 1M per-launch batch and the host-pointer paths")
+    ap.add_argument("--sequence", default="queue", choices=["queue", "launches"],
+                    help="how the library runs the K independent batches of the timed region: 'queue' = one persistent launch "
+                         "over all of them (throughput form), 'launches' = one kernel launch per batch (latency form)")
+    ap.add_argument("--next", action="store_true", help="also time the SURVEY 8(f) rows: sampling, extrema / time scaling, "
+                                                        "Mellinger cost + gradient (extra.next)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (profiling runs: the kernel statistics then cover the same launches as the metric)")
     return ap.parse_args(argv)
@@ -116,14 +127,17 @@ def profile_traffic(batch):
 
 
 class SolveLoop:
-    """The timed loop: `steps` solves (one kernel launch each) rotating over the buffer sets, enqueued by ONE call of
-    mtg_solve_linear_sequence (C ABI) so that the host enqueues faster than the GPU executes (a Python loop over
-    mtg_solve_linear costs ~8 us per call -- more than the kernel)."""
+    """The timed loop: `steps` independent batches rotating over the buffer sets, handed to the library by ONE call of
+    mtg_solve_linear_sequence_events (C ABI).  per_batch=False: the library runs the queue as one persistent launch
+    (<= 96 batches per launch); per_batch=True: one kernel launch per batch, enqueued back to back (a Python loop over
+    mtg_solve_linear would cost ~8 us per call -- more than the kernel)."""
 
-    def __init__(self, plan, sets, layout, dims):
+    def __init__(self, plan, sets, layout, dims, per_batch=False):
         from mav_trajectory_generation_amd import _lib as L
         self.plan = plan
         self.flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        if per_batch:
+            self.flags |= L.FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH
         self.batch = sets[0][2].shape[0]
         self.lay = plan.layout(self.batch, layout)
         self.ptrs = [(t.data_ptr(), f.data_ptr(), co.data_ptr()) for (t, f, co) in sets]
@@ -143,9 +157,7 @@ class SolveLoop:
     def run(self, steps, first=0, start_event=None, stop_event=None):
         """start_event / stop_event: torch.cuda.Event objects (already recorded once, so that their hipEvent_t exists)
         recorded by the library right before the first / after the last launch -- the measured interval then does not
-        contain Python's latency between an `event.record()` and the first launch.  (Measured: it makes no difference to
-        the 20-step figure, 8.4-9.0 us against 8.1-8.2 us for 1000+ steps -- the excess of short runs is the GPU coming
-        out of the idle period behind the contract's barrier, not host latency.)"""
+        contain Python's latency between an `event.record()` and the first launch."""
         if steps <= 0:
             return
         t, f, c = self._arrays(steps, first)
@@ -154,6 +166,90 @@ class SolveLoop:
                                                             t, f, c, self.flags, ev[0], ev[1])
         if rc != 0:
             raise RuntimeError(f"mtg_solve_linear_sequence failed: {rc}")
+
+
+class MixedLoop:
+    """BASELINE config 4: one step = ONE mixed request of 12 buckets (N in {8, 10, 12} x K in {4, 8, 16, 32}, D = 3) x
+    `per_bucket` trajectories = one mtg_multi_solve call (one cross-structure kernel launch); rotating over the buffer sets
+    (each set = its own inputs and outputs for all twelve buckets)."""
+
+    SHAPES = [(n, d, k) for (n, d) in ((8, 3), (10, 4), (12, 5)) for k in (4, 8, 16, 32)]
+
+    def __init__(self, m, ctx, per_bucket, nsets, dev, seed):
+        self.solver = m.MixedBatchSolver(ctx, n_streams=1)
+        self.reqs, self.bytes_per_step = [], 0
+        for s in range(nsets):
+            buckets = []
+            for (n, d, k) in self.SHAPES:
+                masks = m.ends_full_masks(n, k, 1)
+                t, f = m.random_waypoint_batch(per_bucket, k, 3, n, masks, seed=seed + 1000 * s + k + n, device=dev, layout="soa")
+                buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
+            self.reqs.append(self.solver.merged(buckets))
+        # SURVEY 8(d): position-only interior vertices => n_fixed = N + K - 1
+        self.bytes_per_step = sum(per_bucket * 8 * (k + 3 * (n + k - 1) + k * 3 * n) for (n, _, k) in self.SHAPES)
+        self.per_step = per_bucket * len(self.SHAPES)
+        self.launches_per_step = self.reqs[0].launch_count
+
+    def prepare(self, steps, first=0):
+        pass
+
+    def run(self, steps, first=0, start_event=None, stop_event=None):
+        stream = self.solver.ctx.stream
+        if start_event is not None:
+            start_event.record(stream)
+        n = len(self.reqs)
+        for i in range(steps):
+            self.reqs[(first + i) % n].solve()
+        if stop_event is not None:
+            stop_event.record(stream)
+
+    def outputs(self):
+        return [co for r in self.reqs for (co, _) in r.out]
+
+
+def next_rows(m, ctx, plan, sets, B, K, D, N):
+    """SURVEY 8(f) rows on the config's batch (coefficients of buffer set 0): device durations from events on the library's
+    stream, each with the roofline that bounds it."""
+    import torch
+    t, f, co = sets[0]
+    tt = t.t().contiguous() if t.shape[0] == K else t          # [B][K] for the post-solve kernels
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0.record(ctx.stream)
+        for _ in range(reps):
+            fn()
+        e1.record(ctx.stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    # N3: batched sampling, 100 samples per trajectory, position .. snap (HBM-bound: the write stream)
+    ns, nd = 100, 5
+    us = timed(lambda: m.sample_range(ctx, co, tt, 0.0, 0.05, ns, nd), 20)
+    by = B * ns * nd * D * 8 + B * (K * D * N + K) * 8
+    out["sample"] = {"what": f"{B} trajectories x {ns} samples x derivatives 0..{nd - 1} (Trajectory::evaluateRange)",
+                     "us": us, "samples_per_s": B * ns / us * 1e6,
+                     "roofline": {"bound": "hbm", "bytes": by, "achieved_GBps": by / us * 1e-3, "frac": by / us * 1e-3 / HBM_PEAK_GBS}}
+    # N4: velocity + acceleration maxima per segment, then the feasibility time scaling (FP64-issue-bound root isolation)
+    us_v = timed(lambda: m.minmax_magnitude(ctx, co, tt, 1), 5)
+    out["extrema"] = {"what": f"{B} x {K} segments, velocity magnitude extrema (Trajectory::computeMinMaxMagnitude)", "us": us_v,
+                      "segment_derivatives_per_s": B * K / us_v * 1e6,
+                      "roofline": {"bound": "fp64 issue (DESIGN.md 4b: ~4e4 VALU instructions per wave, 272 B per lane)",
+                                   "hbm_frac": B * K * (D * N * 8 + 32) / us_v * 1e-3 / HBM_PEAK_GBS}}
+    us_s = timed(lambda: m.scale_segment_times_to_meet_constraints(ctx, co.clone(), tt.clone(), 2.0, 3.0), 3)
+    out["time_scaling"] = {"what": f"{B} trajectories, scaleSegmentTimesToMeetConstraints(v_max 2, a_max 3), incl. the copies "
+                                   f"of its inputs", "us": us_s, "traj_per_s": B / us_s * 1e6}
+    # N2: Mellinger cost + gradient = (K + 1) x B perturbed-time cost-only solves in one launch
+    lay = "soa" if t.shape[0] == K else "aos"
+    us_m = timed(lambda: m.mellinger_cost_and_gradient(plan, t, f, layout=lay), 10)
+    out["mellinger"] = {"what": f"{B} trajectories x {K + 1} perturbed-time cost-only solves (getCostAndGradientMellinger)",
+                        "us": us_m, "solves_per_s": B * (K + 1) / us_m * 1e6,
+                        "roofline": {"bound": "fp64 issue (no coefficient output)",
+                                     "hbm_frac": B * (K + 1) * (K + D * plan.n_fixed + 1) * 8 / us_m * 1e-3 / HBM_PEAK_GBS}}
+    return out
 
 
 def main():
@@ -173,15 +269,23 @@ def main():
     import torch.distributed as dist
 
     if args.plumbing_only:
+        ranks_seen, devices = 1, [0]
         if world > 1:
             dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
             assert dist.get_world_size() == args.gpus
             tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             assert float(tt.item()) == world
+            ones = torch.ones(1, dtype=torch.float64)
+            dist.all_reduce(ones)
+            ranks_seen = int(ones.item())
+            dv = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(dv, torch.tensor([0 if args.same_device else local], dtype=torch.int64))
+            devices = [int(x.item()) for x in dv]
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"plumbing_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}))
+            print(json.dumps({"plumbing_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ranks_seen": ranks_seen, "rank_devices": devices}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -197,18 +301,26 @@ def main():
         else:
             dist.init_process_group(args.backend)
         assert dist.get_world_size() == args.gpus
+    red_dev = dev if (world > 1 and args.backend == "nccl") else "cpu"
+    ranks_seen, rank_devices = 1, [device_index]
+    if world > 1:   # evidence that the collective backend really spans `world` ranks, and where each rank runs
+        ones = torch.ones(1, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        dv = [torch.zeros(1, dtype=torch.int64, device=red_dev) for _ in range(world)]
+        dist.all_gather(dv, torch.tensor([device_index], dtype=torch.int64, device=red_dev))
+        rank_devices = [int(x.item()) for x in dv]
+        assert ranks_seen == world
 
     cfg = CONFIGS[args.config]
-    N, K, D, d = 10, cfg["K"], cfg["D"], 4
+    mixed = args.config == 4
+    N, K, D, d = 10, (cfg["K"] or 8), cfg["D"], 4
     B = args.batch if args.batch is not None else cfg["batch"]
     masks = m.ends_full_masks(N, K, cfg["interior"])
     ctx = m.Context(device_index)
     plan = m.Plan(ctx, N, D, K, d, masks)
     nsets = max(1, args.buffer_sets)
-    # keep the rotating footprint bounded (config 3: 300 MB per set)
-    set_bytes = B * (plan.bytes_per_trajectory)
-    while nsets > 2 and nsets * set_bytes > 24 * 2**30:
-        nsets //= 2
+    per_batch = args.sequence == "launches"
 
     def barrier():
         if world > 1:
@@ -220,8 +332,19 @@ def main():
         return t, f, torch.zeros((B, K, D, N), dtype=torch.float64, device=dev)
 
     with torch.cuda.stream(ctx.stream):
-        sets = [make_set(1234 + rank + 1000 * s) for s in range(nsets)]
-        loop = SolveLoop(plan, sets, args.layout, args.dims)
+        if mixed:
+            loop = MixedLoop(m, ctx, B, nsets, dev, 1234 + rank)
+            sets = None
+            bytes_per_step, traj_per_step = loop.bytes_per_step, loop.per_step
+            set_bytes = bytes_per_step
+        else:
+            # keep the rotating footprint bounded (config 3: 300 MB per set)
+            set_bytes = B * (plan.bytes_per_trajectory)
+            while nsets > 2 and nsets * set_bytes > 24 * 2**30:
+                nsets //= 2
+            sets = [make_set(1234 + rank + 1000 * s) for s in range(nsets)]
+            loop = SolveLoop(plan, sets, args.layout, args.dims, per_batch)
+            bytes_per_step, traj_per_step = B * plan.bytes_per_trajectory, B
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(ctx.stream)   # (creates the underlying hipEvent_t handles: torch makes them on first record)
         e1.record(ctx.stream)
@@ -237,81 +360,59 @@ def main():
             loop_.run(warmup)
             barrier()
             t0 = time.perf_counter()
-            loop_.run(steps, first=warmup, start_event=e0, stop_event=e1)   # events recorded inside the C call
+            loop_.run(steps, first=warmup, start_event=e0, stop_event=e1)   # events recorded around the launches
             finish()
-            return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e3 / steps   # wall seconds, event us per launch
+            return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e3 / steps   # wall seconds, device us per step
+
+        def side_run(loop_, steps, warm=20):
+            """(device us per step, wall s) of `steps` steps outside the contract's timed region (extras)."""
+            loop_.prepare(warm, 0)
+            loop_.prepare(steps, 0)
+            loop_.run(warm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop_.run(steps, start_event=e0, stop_event=e1)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / steps, time.perf_counter() - t0
+
+        def side_entry(us, wall, steps, sets_):
+            return {"buffer_sets": sets_, "steps": steps, "us_per_step": us, "traj_per_s": traj_per_step * steps / wall,
+                    "frac_of_8TBps": bytes_per_step / us * 1e-3 / HBM_PEAK_GBS}
 
         # set-up, not a step: every buffer set is touched once (first use of fresh allocations: page-table / TLB fills),
         # as in any pipeline that has been running for longer than one rotation
         loop.run(nsets)
         torch.cuda.synchronize()
-        dt, kern_us = timed(loop, args.steps, args.warmup)
+        dt, step_us = timed(loop, args.steps, args.warmup)
         ctx.sync()  # raises if any trajectory flagged bad time / singular
-        for (_, _, co) in sets:
+        for co in (loop.outputs() if mixed else [x[2] for x in sets]):
             assert torch.isfinite(co).all()
 
-        extra = {}
-        if rank == 0 and not args.no_extras:
+        extra, fill_us = {}, None
+        if rank == 0 and not args.no_extras and mixed:
+            us, wall = side_run(loop, 200)
+            extra["rotating_buffers_200_steps"] = side_entry(us, wall, 200, nsets)
+        if rank == 0 and not args.no_extras and not mixed:
+            big = set_bytes * nsets > 8 * 2**30          # config 3: keep the extras short
+            long_steps = 200 if big else 2000
+            # the other form of the same loop: one launch per batch (latency form) when `value` is the queue, and vice versa
+            other = SolveLoop(plan, sets, args.layout, args.dims, not per_batch)
+            us, wall = side_run(other, 200)
+            extra["one_launch_per_batch" if not per_batch else "queue_one_persistent_launch"] = dict(
+                side_entry(us, wall, 200, nsets),
+                note=("one kernel launch per batch, back to back on ONE stream: the launch-to-launch period (latency form)"
+                      if not per_batch else "the queue as one persistent launch per <= 96 batches (throughput form)"))
             # the same loop over ONE resident buffer set (inputs and outputs stay in the 256 MiB Infinity Cache)
-            res = SolveLoop(plan, sets[:1], args.layout, args.dims)
-            steps_r = max(args.steps, 200)
-            res.run(20)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            e0.record(ctx.stream)
-            res.run(steps_r)
-            e1.record(ctx.stream)
-            torch.cuda.synchronize()
-            dt_r = time.perf_counter() - t0
-            us_r = e0.elapsed_time(e1) * 1e3 / steps_r
-            extra["resident_buffers"] = {"buffer_sets": 1, "steps": steps_r, "launch_us": us_r,
-                                         "traj_per_s": B * steps_r / dt_r,
-                                         "frac_of_8TBps": B * plan.bytes_per_trajectory / us_r * 1e-3 / HBM_PEAK_GBS}
-            # a longer rotating run of the same loop (the driver's --steps can be as small as 20: 150 us of GPU work)
-            if args.steps < 1000:
-                loop.run(20)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                e0.record(ctx.stream)
-                loop.run(2000)
-                e1.record(ctx.stream)
-                torch.cuda.synchronize()
-                dt_l = time.perf_counter() - t0
-                us_l = e0.elapsed_time(e1) * 1e3 / 2000
-                extra["rotating_buffers_2000_steps"] = {"buffer_sets": nsets, "steps": 2000, "launch_us": us_l,
-                                                        "traj_per_s": B * 2000 / dt_l,
-                                                        "frac_of_8TBps": B * plan.bytes_per_trajectory / us_l * 1e-3 / HBM_PEAK_GBS}
-            # steady state of a pipeline that feeds TWO streams (independent batches: nothing orders them): the launches of
-            # one stream fill the gap between dependent launches of the other (~1.0-1.3 us) and overlap its store tail.
-            # Reported beside the one-stream numbers, never as `value`.
-            if args.config == 2 and nsets >= 4:
-                ctx2 = m.Context(device_index)
-                plan2 = m.Plan(ctx2, N, D, K, d, masks)
-                la = SolveLoop(plan, sets[0::2], args.layout, args.dims)
-                lb = SolveLoop(plan2, sets[1::2], args.layout, args.dims)
-                chunk, rounds = 8, 125
-                for _ in range(3):
-                    la.run(chunk)
-                    lb.run(chunk)
-                torch.cuda.synchronize()
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0 = time.perf_counter()
-                e0.record(ctx.stream)
-                for _ in range(rounds):
-                    la.run(chunk)
-                    lb.run(chunk)
-                ea.record(ctx.stream)
-                eb.record(ctx2.stream)
-                torch.cuda.synchronize()
-                dt_2 = time.perf_counter() - t0
-                n2 = 2 * chunk * rounds
-                us_2 = max(e0.elapsed_time(ea), e0.elapsed_time(eb)) * 1e3 / n2
-                ctx2.sync()
-                extra["two_streams_steady_state"] = {"buffer_sets": nsets, "launches": n2, "us_per_launch": us_2,
-                                                     "traj_per_s": B * n2 / dt_2,
-                                                     "frac_of_8TBps": B * plan.bytes_per_trajectory / us_2 * 1e-3 / HBM_PEAK_GBS}
-                plan2.close()
-                ctx2.close()
+            res = SolveLoop(plan, sets[:1], args.layout, args.dims, per_batch)
+            us, wall = side_run(res, max(args.steps, 200))
+            extra["resident_buffers"] = side_entry(us, wall, max(args.steps, 200), 1)
+            # a longer rotating run of the same loop (the driver's --steps can be as small as 20)
+            if args.steps < long_steps:
+                us, wall = side_run(loop, long_steps)
+                extra[f"rotating_buffers_{long_steps}_steps"] = side_entry(us, wall, long_steps, nsets)
+            if args.steps != 96 and not per_batch and not big:
+                us, wall = side_run(loop, 96, warm=96)
+                extra["rotating_buffers_96_steps_one_full_launch"] = side_entry(us, wall, 96, nsets)
             # context for small launches: a write-only fill of the same coefficient buffer (zero compute, zero reads)
             co0 = sets[0][2]
             co0_copy = co0.clone()
@@ -325,19 +426,19 @@ def main():
             co0.copy_(co0_copy)
             del co0_copy
             if args.config == 2:
-                # the per-GPU share of BASELINE configs[2] (1M over 8 GPUs) always; --extra adds 1M on this GPU
-                for big in ((125_000, 1_000_000) if args.extra else (125_000,)):
-                    tb, fb = m.random_waypoint_batch(big, K, D, N, masks, seed=99, device=dev, layout=args.layout)
-                    cb = torch.empty((big, K, D, N), dtype=torch.float64, device=dev)
+                # ONE launch over the per-GPU share of BASELINE configs[2] (1M over 8 GPUs) always; --extra adds 1M on this GPU
+                for bigb in ((125_000, 1_000_000) if args.extra else (125_000,)):
+                    tb, fb = m.random_waypoint_batch(bigb, K, D, N, masks, seed=99, device=dev, layout=args.layout)
+                    cb = torch.empty((bigb, K, D, N), dtype=torch.float64, device=dev)
                     plan.solve(tb, fb, layout=args.layout, coeffs=cb, dims=args.dims)
                     torch.cuda.synchronize()
                     us = plan.time_last_solve(20)
-                    extra[f"batch_{big}"] = {"kernel_us": us, "traj_per_s": big / us * 1e6,
-                                             "GBps": big * plan.bytes_per_trajectory / us * 1e-3,
-                                             "frac_of_8TBps": big * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
+                    extra[f"batch_{bigb}"] = {"kernel_us": us, "traj_per_s": bigb / us * 1e6,
+                                              "GBps": bigb * plan.bytes_per_trajectory / us * 1e-3,
+                                              "frac_of_8TBps": bigb * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
                     del tb, fb, cb
-        else:
-            fill_us = None
+            if args.next:
+                extra["next"] = next_rows(m, ctx, plan, sets, B, K, D, N)
         if args.extra and rank == 0 and args.config == 2:
             # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value.
             t, f, _ = sets[0]
@@ -353,7 +454,7 @@ def main():
                 extra[f"host_pointers_{tag}_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
 
         gather = None
-        if world > 1 and not args.no_gather:
+        if world > 1 and not args.no_gather and not mixed:
             # solve + final all_gather of the coefficients: chunked, chunk i's gather overlaps chunk i+1's
             # solve; reported beside the solve-only number, never part of `value`
             from mav_trajectory_generation_amd import dist as mdist
@@ -384,54 +485,86 @@ def main():
                       "gather_only_ms": gather_only * 1e3,
                       "gathered_bytes_per_rank": world * B * K * D * N * 8, "backend": args.backend}
 
+    per_rank = None
     if world > 1:
-        vals = torch.tensor([dt, kern_us], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        mine = torch.tensor([dt, step_us], dtype=torch.float64, device=red_dev)
+        allv = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [{"rank": r, "device": rank_devices[r], "wall_s": float(v[0]), "device_us_per_step": float(v[1])}
+                    for r, v in enumerate(allv)]
+        vals = mine.clone()
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-        dt, kern_us = float(vals[0].item()), float(vals[1].item())
+        dt, step_us = float(vals[0].item()), float(vals[1].item())
         if gather is not None:
             g = torch.tensor([gather["solve_plus_gather_ms"], gather["solve_only_ms"], gather["gather_only_ms"]],
-                             dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                             dtype=torch.float64, device=red_dev)
             dist.all_reduce(g, op=dist.ReduceOp.MAX)
             gather["solve_plus_gather_ms"], gather["solve_only_ms"], gather["gather_only_ms"] = [float(x) for x in g]
             gather["traj_per_s_with_gather"] = world * B / (gather["solve_plus_gather_ms"] * 1e-3)
 
     if rank == 0:
-        bytes_per_launch = B * plan.bytes_per_trajectory
-        achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
-        what = (f"batch of {B} random-waypoint trajectories per GPU per step ({cfg['name']}): {K} segments, N=10, "
-                f"dim={D}, snap" + (", velocity + acceleration fixed at interior vertices" if cfg["interior"] == 7 else "")
-                + f"; one kernel launch per step on ONE stream (latency figure, no overlap between steps), rotating over "
-                  f"{nsets} independent input/output buffer sets ({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; "
-                  f"inputs {args.layout.upper()}, coeffs [B][K][D][N]")
+        achieved = bytes_per_step / (step_us * 1e-6) / 1e9
+        if mixed:
+            form = (f"ONE library call (mtg_multi_solve) = {loop.launches_per_step} cross-structure kernel launch(es) per step")
+            what = (f"mixed request of {traj_per_step} random-waypoint trajectories per GPU per step ({cfg['name']}): 12 buckets = "
+                    f"N in {{8 jerk, 10 snap, 12}} x K in {{4, 8, 16, 32}} segments x {B} trajectories, dim=3; {form}; rotating "
+                    f"over {nsets} independent input/output buffer sets ({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; "
+                    f"inputs SOA, coeffs [B][K][D][N] per bucket")
+            launches, batches_per_launch = args.steps * loop.launches_per_step, None
+        else:
+            queue = not per_batch
+            launches = (args.steps + 95) // 96 if queue else args.steps
+            batches_per_launch = min(args.steps, 96) if queue else 1
+            form = (f"the {args.steps} timed steps are {args.steps} independent batches handed to the library in ONE "
+                    f"mtg_solve_linear_sequence call and run as {launches} persistent kernel launch(es) whose workgroups walk the "
+                    f"tiles of all batches (throughput form; the one-launch-per-batch latency figure is extra.one_launch_per_batch)"
+                    if queue else "one kernel launch per step on ONE stream (latency figure, no overlap between steps)")
+            what = (f"batch of {B} random-waypoint trajectories per GPU per step ({cfg['name']}): {K} segments, N=10, "
+                    f"dim={D}, snap" + (", velocity + acceleration fixed at interior vertices" if cfg["interior"] == 7 else "")
+                    + f"; {form}; rotating over {nsets} independent input/output buffer sets "
+                      f"({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; inputs {args.layout.upper()}, coeffs [B][K][D][N]")
         out = {
-            "metric": "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)" if args.config != 5 else
-                      "trajectories/sec (16-seg, N=10, 4D min-snap solveLinear, config 5)",
-            "value": world * B * args.steps / dt,
+            "metric": {2: "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)",
+                       3: "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)",
+                       4: "trajectories/sec (mixed N = 8/10/12, 4-32 segments, 3D solveLinear, config 4)",
+                       5: "trajectories/sec (16-seg, N=10, 4D min-snap solveLinear, config 5)"}[args.config],
+            "value": world * traj_per_step * args.steps / dt,
             "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": what, "baseline_config": args.config, "buffer_sets": nsets,
-                       "kernel_variant": plan.kernel_variant, "launch_form": args.dims,
-                       "bytes_per_trajectory": plan.bytes_per_trajectory},
+                       "kernel_variant": plan.kernel_variant, "launch_form": args.dims, "sequence": args.sequence,
+                       "bytes_per_trajectory": None if mixed else plan.bytes_per_trajectory,
+                       "trajectories_per_step": traj_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_from_profile": profile_traffic(B),
-                         "kernel_us": kern_us, "bytes_per_launch": bytes_per_launch,
-                         "kernel_us_is": "HIP events on the launch stream around the timed steps / steps "
-                                         "(launch-to-launch period of the back-to-back stream)",
+                         "traffic_from_profile": profile_traffic(traj_per_step),
+                         "kernel_us": step_us * args.steps / launches, "launches": launches,
+                         "batches_per_launch": batches_per_launch,
+                         "bytes_per_launch": bytes_per_step * args.steps / launches,
+                         "device_us_per_step": step_us, "bytes_per_step": bytes_per_step,
+                         "kernel_us_is": "HIP events recorded on the launch stream immediately before the first and after the "
+                                         "last launch of the timed steps / launches (max over ranks)",
                          "output_fill_only_us": fill_us},
+            "ranks_seen": ranks_seen, "rank_devices": rank_devices,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if extra:
             out["extra"] = extra
         if gather is not None:
             out["gather"] = gather
-        if not args.no_cpu_baseline and world == 1 and args.config == 2:
+    if not args.no_cpu_baseline and args.config == 2:
+        # rank 0's host cores, after every GPU measurement (the other ranks wait in the barrier below)
+        if rank == 0:
             out["cpu_baseline"] = cpu_baseline(200_000, 4321)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

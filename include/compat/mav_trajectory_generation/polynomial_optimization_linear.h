@@ -14,7 +14,9 @@
 #ifndef MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
 #define MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
 #include <cmath>
+#include <cstdlib>
 #include <memory>
+#include <string>
 #include <numeric>
 #include <vector>
 
@@ -50,7 +52,9 @@ inline std::shared_ptr<mtg_context> context_ref() {
   if (!tc.ctx) {
     mtg_context* raw = nullptr;
     const int rc = mtg_context_create(0, nullptr, &raw);
-    CHECK(rc == MTG_OK) << "mtg_context_create: " << mtg_status_string(rc) << " (the solver has no CPU fallback)";
+    CHECK(rc == MTG_OK) << "mtg_context_create: " << mtg_status_string(rc)
+                        << " (a library context always owns a gfx950 device: batches have no CPU path; only single-trajectory "
+                           "calls may run on the library's host build of the kernel code, see setSingleCallsOnDevice)";
     tc.ctx = std::shared_ptr<mtg_context>(raw, [](mtg_context* c) { mtg_context_destroy(c); });
   }
   return tc.ctx;
@@ -72,12 +76,44 @@ inline std::shared_ptr<mtg_plan> make_plan(int N, int D, int K, int derivative, 
   tc.plans.emplace(std::move(key), sp);
   return sp;
 }
-inline void check_sync() {
-  const int rc = mtg_context_sync(context());
+// Synchronises the context a PLAN lives on (not the calling thread's): a batch object may be used from, or outlive,
+// another thread than the one that created it, and its launches, status flags and error text belong to the plan's context.
+inline void check_sync(const mtg_plan* plan) {
+  mtg_context* ctx = plan ? mtg_plan_context(plan) : context();
+  const int rc = mtg_context_sync(ctx);
   // LIN:297 CHECK_GT(segment_time, 0) and friends surface here
-  CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(context());
+  CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(ctx);
+}
+inline void check_sync() { check_sync(nullptr); }
+
+// Where the single-trajectory calls of the reference API (solveLinear(), setFreeConstraints() on ONE optimiser object)
+// run.  One trajectory per call is latency-bound (a launch plus a PCIe round trip: ~25 us), so by default they run on
+// the library's HOST BUILD of the kernels' lane code on the calling thread (MTG_FLAG_HOST_BACKEND: the same functions the
+// kernels are made of, ~2-8 us per call; product code, not the test oracle) -- what SURVEY 8(b) asks for the reference's
+// nlopt-style callers.  A run-time switch, process-wide:
+//   * environment MTG_COMPAT_SINGLE_CALLS = device | host (read once), or
+//   * mav_trajectory_generation::setSingleCallsOnDevice(true / false),
+//   * compile-time default `device` with -DMTG_COMPAT_SINGLE_CALLS_ON_DEVICE.
+// Batched entries (PolynomialOptimizationBatch, solveLinearMixed) always run on the GPU.
+inline int& single_calls_on_device_state() {
+  static int state = [] {
+#if defined(MTG_COMPAT_SINGLE_CALLS_ON_DEVICE)
+    int v = 1;
+#else
+    int v = 0;
+#endif
+    if (const char* e = std::getenv("MTG_COMPAT_SINGLE_CALLS")) {
+      if (std::string(e) == "device") v = 1;
+      else if (std::string(e) == "host") v = 0;
+    }
+    return v;
+  }();
+  return state;
 }
 }  // namespace mtg_compat_detail
+
+inline void setSingleCallsOnDevice(bool on_device) { mtg_compat_detail::single_calls_on_device_state() = on_device ? 1 : 0; }
+inline bool singleCallsOnDevice() { return mtg_compat_detail::single_calls_on_device_state() != 0; }
 
 template <int _N = 10>
 class PolynomialOptimization {
@@ -374,16 +410,9 @@ class PolynomialOptimization {
     return col;
   }
 
-  // One trajectory per call is latency-bound: by default the library runs its host build of the kernels' lane code on
-  // this thread (MTG_FLAG_HOST_BACKEND; ~microseconds) instead of a launch plus a PCIe round trip (~25 us).  Define
-  // MTG_COMPAT_SINGLE_CALLS_ON_DEVICE to send even these calls through the GPU (what the veneer GPU tests do).
-  static uint32_t single_call_backend() {
-#if defined(MTG_COMPAT_SINGLE_CALLS_ON_DEVICE)
-    return 0u;
-#else
-    return (uint32_t)MTG_FLAG_HOST_BACKEND;
-#endif
-  }
+  // One trajectory per call is latency-bound: see mtg_compat_detail::single_calls_on_device_state (run-time switch;
+  // default: the library's host build of the kernels' lane code on this thread instead of a launch + PCIe round trip).
+  static uint32_t single_call_backend() { return singleCallsOnDevice() ? 0u : (uint32_t)MTG_FLAG_HOST_BACKEND; }
   int run(bool solve) {
     CHECK(plan_ != nullptr) << "setupFromVertices() has to be called first";
     const size_t D = dimension_, K = n_segments_, nf = n_fixed_constraints_, np = n_free_constraints_;
@@ -456,10 +485,11 @@ class PolynomialOptimizationBatch {
     const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
                                     device_pointers ? 0u : (uint32_t)MTG_FLAG_HOST_POINTERS);
     if (rc == MTG_ERR_SINGULAR) return false;   // host-pointer calls report their status themselves
-    CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_compat_detail::context());
+    CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_plan_context(plan_.get()));
     return true;
   }
-  void sync() { mtg_compat_detail::check_sync(); }
+  // waits for the device-pointer solves of THIS object (the context its plan was created on, whichever thread calls)
+  void sync() { mtg_compat_detail::check_sync(plan_.get()); }
 
   // Segment::Vector view of trajectory b of a host coefficient buffer
   void getSegments(const double* coeffs, const double* times, size_t b, Segment::Vector* segments) const {

@@ -96,10 +96,13 @@ enum {
                                      /* (no launch, no PCIe): the single-trajectory calls of  */
                                      /* the reference's nlopt loops (polynomial_optimization_ */
                                      /* nonlinear_impl.h:569-571).  Ignored otherwise.        */
-  MTG_FLAG_CONCURRENT_ITEMS = 1u << 7 /* mtg_multi_create: no merging -- every item runs as its */
+  MTG_FLAG_CONCURRENT_ITEMS = 1u << 7, /* mtg_multi_create: no merging -- every item runs as its */
                                      /* own best launch, spread over the context's side       */
                                      /* streams (longest chains first), forked from and       */
                                      /* joined back onto the context's stream                 */
+  MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 1u << 8 /* mtg_solve_linear_sequence: never merge   */
+                                     /* the queue into one persistent launch (latency of the  */
+                                     /* single launches; A/B measurements)                    */
 };
 #define MTG_HOST_BACKEND_MAX_BATCH 64
 
@@ -119,6 +122,13 @@ const char* mtg_status_string(int status);
 int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out);
 int mtg_plan_destroy(mtg_plan* plan);
 int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
+/* The context a plan was created on (its stream, status word and error text): host objects that hold a plan and may be
+ * used from another thread than their creator synchronise THIS context, not their own thread's.                     */
+mtg_context* mtg_plan_context(const mtg_plan* plan);
+/* Which kernel form a device-pointer mtg_solve_linear(plan, batch, layout, ..., flags) call with coefficient output only
+ * takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
+ * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane.  Negative: mtg_status.                        */
+int mtg_plan_launch_form(const mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint32_t flags);
 void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 
@@ -157,10 +167,15 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
                             const double* times, const double* d_fixed, double* coeffs,
                             double* d_free, double* cost, int32_t* trajectory_status, uint32_t flags);
 
-/* A queue of n independent batches of the same plan (same batch size, layout and flags): solve i reads times[i] /
- * d_fixed[i] and writes coeffs[i] (host arrays of n DEVICE pointers), one kernel launch each, enqueued back to back on the
- * context's stream by ONE host call -- what a pipeline that streams batch after batch through the solver does (the
- * reference's counterpart is a loop over setupFromVertices + solveLinear, polynomial_timing_evaluation.cpp:104-110).  */
+/* A queue of n INDEPENDENT batches of the same plan (same batch size, layout and flags): solve i reads times[i] /
+ * d_fixed[i] and writes coeffs[i] (host arrays of n DEVICE pointers; no batch may read what another one writes), enqueued
+ * on the context's stream by ONE host call -- what a pipeline that streams batch after batch through the solver does (the
+ * reference's counterpart is a loop over setupFromVertices + solveLinear, polynomial_timing_evaluation.cpp:104-110).
+ * Because the batches are independent the library overlaps them: plans with a slab-output kernel (the standard shapes)
+ * run the whole queue as ONE persistent launch whose workgroups walk the tiles of all batches, batch-major (the pointer
+ * triples travel in the kernel arguments, up to 96 batches per launch): no drain / launch gap between batches, the store
+ * tail of batch i under the elimination of batch i + 1.  Results are bit-identical to n mtg_solve_linear calls.  Other
+ * plans, and calls with MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH, enqueue one launch per batch back to back.           */
 int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
                               const double* const* times, const double* const* d_fixed, double* const* coeffs,
                               uint32_t flags);

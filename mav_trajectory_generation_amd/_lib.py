@@ -42,6 +42,8 @@ EXPORTS = {
     "mtg_plan_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]),
     "mtg_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mtg_plan_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]),
+    "mtg_plan_context": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mtg_plan_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_uint32]),
     "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_layout_soa": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_plan_set_workspace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
@@ -103,6 +105,7 @@ FLAG_COST_ONLY = 16
 FLAG_DIMLANE = 32
 FLAG_HOST_BACKEND = 64
 FLAG_CONCURRENT_ITEMS = 128
+FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 256
 
 _lib = None
 
@@ -115,7 +118,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the solver.")
+            "(hipcc --offload-arch=gfx950).  The batched solver has no CPU fallback (only single-trajectory host calls can opt "
+            "into the library's own host build of the kernel code, MTG_FLAG_HOST_BACKEND -- which lives in the same library).")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -41,7 +41,7 @@ class Context:
     def __init__(self, device: int = 0, stream=None):
         import torch
         if not torch.cuda.is_available():
-            raise RuntimeError("mav_trajectory_generation_amd needs a HIP device (no CPU fallback)")
+            raise RuntimeError("mav_trajectory_generation_amd needs a HIP device (a context always owns a GPU; batches have no CPU path)")
         self.lib = L.load()
         self.device = int(device)
         self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
@@ -265,6 +265,35 @@ class Plan:
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
 
+    def solve_sequence(self, sets, layout: str = "soa", dims: str = "auto", one_launch_per_batch: bool = False,
+                       start_event=None, stop_event=None, ordered: bool = True):
+        """A queue of INDEPENDENT batches of equal size (mtg_solve_linear_sequence[_events]): `sets` = sequence of
+        (times, d_fixed, coeffs) CUDA tensors in `layout`, coeffs [B][K][D][N] allocated by the caller.  Plans with a
+        slab-output kernel run the whole queue as ONE persistent launch (workgroups walk the tiles of all batches);
+        one_launch_per_batch=True keeps one launch per batch.  start_event / stop_event: torch.cuda.Event objects that
+        have been recorded once (their hipEvent_t exists), recorded by the library around the queue."""
+        import torch
+        n = len(sets)
+        if n == 0:
+            return
+        batch = sets[0][2].shape[0]
+        for (t, f, co) in sets:
+            assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+            assert f.dtype == torch.float64 and f.is_cuda and f.is_contiguous()
+            assert co.dtype == torch.float64 and co.is_cuda and co.is_contiguous() and co.shape[0] == batch
+        arr = [(ctypes.c_void_p * n)(*[x[j].data_ptr() for x in sets]) for j in range(3)]
+        lay = self.layout(batch, layout)
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        if one_launch_per_batch:
+            flags |= L.FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH
+        ev = [ctypes.c_void_p(e.cuda_event) if e is not None else None for e in (start_event, stop_event)]
+        cur = self.ctx._enter() if ordered else None
+        rc = self.lib.mtg_solve_linear_sequence_events(self.handle, n, batch, ctypes.byref(lay), arr[0], arr[1], arr[2],
+                                                       flags, ev[0], ev[1])
+        if ordered:
+            self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
+
     def solve_cost_only(self, times, d_fixed, layout: str = "aos", cost=None):
         """computeCost() of the optimum for every trajectory without materialising the segments
         (MTG_FLAG_COST_ONLY): what the time optimisers' objective callbacks need.  Returns cost [B]."""
@@ -317,6 +346,17 @@ class Plan:
                                        p(d_free), p(cost), flags)
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
+
+    LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane"}
+
+    def launch_form(self, batch: int, layout: str = "soa", dims: str = "auto") -> str:
+        """Kernel form a coefficient-only device-pointer solve of `batch` trajectories takes (mtg_plan_launch_form)."""
+        lay = self.layout(batch, layout)
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        rc = self.lib.mtg_plan_launch_form(self.handle, batch, ctypes.byref(lay), flags)
+        if rc < 0:
+            _check(self.lib, rc, self.ctx.handle)
+        return self.LAUNCH_FORMS[rc]
 
     def time_last_solve(self, iters: int = 100) -> float:
         """Mean device duration (us) of the last solve launch, hipEvents on the context stream."""

@@ -107,6 +107,7 @@ struct mtg_context {
   bool knob_no_dimlane = false;      // MTG_NO_DIMLANE: never pick the dimension-in-lane form
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
+  bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
@@ -140,6 +141,7 @@ struct mtg_plan {
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
   bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
+  bool slab_queue_attr_set = false;
   double* ws = nullptr;
   size_t ws_bytes = 0;
   double* pert_cost = nullptr;      // [(K + 1)][batch] costs of mtg_mellinger_cost_gradient's virtual problems
@@ -248,6 +250,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_dimlane = getenv("MTG_NO_DIMLANE") != nullptr;
   if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
+  ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
@@ -398,6 +401,8 @@ int mtg_plan_destroy(mtg_plan* p) {
   return MTG_OK;
 }
 
+mtg_context* mtg_plan_context(const mtg_plan* p) { return p ? p->ctx : nullptr; }
+
 int mtg_plan_get_info(const mtg_plan* p, mtg_plan_info* out) {
   if (!p || !out) return MTG_ERR_INVALID_ARGUMENT;
   out->n_all = p->N * p->K;
@@ -429,6 +434,16 @@ static int64_t span(int64_t batch, int64_t sb, int64_t n1, int64_t s1, int64_t n
 // d_fixed[D][n_fixed][B]), coefficient output only, sizes whose 32-bit byte offsets cannot overflow.  Chosen by default
 // while the launch is at most a few workgroups per CU (measured cross-over against the fused form: DESIGN.md section 4);
 // MTG_FLAG_DIMLANE forces it, MTG_FLAG_FUSED_DIMS / MTG_FLAG_SPLIT_DIMS / MTG_FLAG_GENERIC_KERNEL exclude it.
+// default range of the dimension-in-lane form (mtg_dimlane_variants.inc): LO * CUs <= workgroups <= HI * CUs / 2
+// (HI = 0: no upper limit; HI = 3 = 1.5 workgroups per CU, the measured cross-over against the slab-output fused kernel)
+static bool dimlane_is_default(const mtg_plan* p, const MtgDimlaneEntry* dl, int64_t trajectories) {
+  const int64_t units = ((trajectories + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
+  const int64_t cus = p->ctx->n_cu;
+  const int hi = p->ctx->dl_max_units_per_cu >= 0 ? 2 * p->ctx->dl_max_units_per_cu : dl->hi_per_cu;
+  if (units < (int64_t)dl->lo_per_cu * cus) return false;
+  return hi == 0 || 2 * units <= (int64_t)hi * cus;
+}
+
 static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P,
                                            uint32_t flags, bool cost_only) {
   const MtgDimlaneEntry* dl = p->dimlane;
@@ -438,11 +453,54 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   if (L->fixed_stride_b != 1 || L->fixed_stride_c != batch || L->fixed_stride_d != (int64_t)p->n_fixed * batch) return nullptr;
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
   if (flags & MTG_FLAG_DIMLANE) return dl;
-  const int64_t units = ((batch + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
-  const int64_t cus = p->ctx->n_cu;
-  const int hi = p->ctx->dl_max_units_per_cu >= 0 ? p->ctx->dl_max_units_per_cu : dl->hi_per_cu;
-  if (units < (int64_t)dl->lo_per_cu * cus) return nullptr;
-  return (hi == 0 || units <= (int64_t)hi * cus) ? dl : nullptr;
+  return dimlane_is_default(p, dl, batch) ? dl : nullptr;
+}
+
+// Variant choice of the fused / dimension-split forms: specialised kernels when the plan matches one; with few tiles (small
+// batch) the dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.  nullptr: generic.
+static const MtgSlabEntry* pick_slab(const mtg_plan* p, const MtgStaticEntry* var);
+static const MtgStaticEntry* pick_static(const mtg_plan* p, int ntiles, uint32_t flags, bool coeffs_only) {
+  const mtg_context* ctx = p->ctx;
+  const MtgStaticEntry* var = nullptr;
+  if (flags & MTG_FLAG_GENERIC_KERNEL) return nullptr;
+  // Coefficient output only and a slab-output fused kernel for the shape: never the dimension-split form by default.  Its
+  // 80-byte pieces complete sectors from different workgroups (1.21x write amplification, read-modify-write at the memory
+  // side once the output is not cache-resident): with rotating buffers 15.4 / 25.7 us at B = 10k / 20k against 10.4 / 14.3 us
+  // (profiles/r02_sweep_forms.txt).  Round 2 still sent SoA batches between 1.5 workgroups per CU of the dimension-in-lane
+  // form (~16k) and 4 x CUs split-form workgroups (~21.8k) to the split form (found with mtg_plan_launch_form).
+  if (coeffs_only && !(flags & MTG_FLAG_SPLIT_DIMS) && ctx->knob_force_dg <= 0 && !ctx->knob_prefer_rolled && pick_slab(p, p->fast))
+    return p->fast;
+  // Dimension-split form while ALL its workgroups (tiles x dimension groups) are resident at once at <= 2 waves per
+  // SIMD (4 x CUs workgroups); beyond that it runs in rounds and the fused form -- no repeated factorisation, one
+  // round up to 2 x CUs tiles -- wins (measured, N = 10 / K = 8 / D = 3: B = 20k 15.0 vs 15.4 us, B = 30k 25.5 vs
+  // 18.3 us, B = 60k 44.1 vs 34.3 us).  Plans whose fused kernel spills ("heavy") keep the split form longer.
+  bool auto_split = ntiles < 4 * ctx->n_cu;
+  if (p->fast && p->fast_split && !p->fast->heavy)
+    auto_split = (long long)ntiles * (p->D / p->fast_split->d) <= 4ll * ctx->n_cu;
+  const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) || (!(flags & MTG_FLAG_FUSED_DIMS) && auto_split);
+  var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
+  if (var && var->heavy && !want_split) {   // large launch, spilling static kernel: the rolled form is faster
+    const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+    if (v) var = v;
+  }
+  if (ctx->knob_prefer_rolled) {
+    const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+    if (v) var = v;
+  }
+  if (ctx->knob_force_dg > 0) {
+    const int dg = ctx->knob_force_dg;
+    if (p->D % dg == 0) {
+      const MtgStaticEntry* v = mtg_find_static(p->H, dg, p->K, p->deriv, p->mask.data());
+      if (v) var = v;
+    }
+  }
+  return var;
+}
+
+// fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
+static const MtgSlabEntry* pick_slab(const mtg_plan* p, const MtgStaticEntry* var) {
+  if (!var || var->k <= 0 || var->d != p->D || p->ctx->knob_no_slab) return nullptr;
+  return mtg_find_slab(p->H, p->D, p->K, p->deriv, p->mask.data());
 }
 
 struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradient: (K + 1) virtual problems per trajectory
@@ -488,11 +546,15 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
   bool bounce = false;
   int host_status = 0;
+  int* host_status_dev = nullptr;           // host-pointer calls: this call's own status word (in the staging area)
   int32_t* dts = traj_status;               // per-trajectory status on the device
   const int64_t n_ts = traj_status ? (batch + 1) / 2 : 0;   // doubles that hold `batch` int32
   constexpr size_t kBounceLimit = 1u << 20;
   if (host) {
-    const size_t need = (size_t)(n_times + n_fix + n_fre + n_coef + batch + n_ts) * sizeof(double);
+    // (+ 1: the call's OWN status word.  A host-pointer call reports its status itself; it must neither collect nor clear
+    // the flags that earlier asynchronous device-pointer / graph launches left in the context's word -- those belong to
+    // the next mtg_context_sync.)
+    const size_t need = (size_t)(n_times + n_fix + n_fre + n_coef + batch + n_ts + 1) * sizeof(double);
     int rc = ensure_buffer(ctx, &p->stage, &p->stage_bytes, need);
     if (rc != MTG_OK) return rc;
     double* s = p->stage;
@@ -502,6 +564,8 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     double* s_c = s; s += n_coef;
     double* s_j = s; s += batch;
     if (traj_status) dts = reinterpret_cast<int32_t*>(s);
+    s += n_ts;
+    host_status_dev = reinterpret_cast<int*>(s);
     // small calls go through the context's page-locked bounce buffer: [times | d_fixed | d_free] is one H2D DMA
     const size_t n_in = (size_t)(n_times + n_fix + (update_only ? n_fre : 0));
     bounce = need <= kBounceLimit;
@@ -528,9 +592,11 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   }
   if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, (pert ? (size_t)(p->K + 1) : (size_t)1) * batch * sizeof(double), st));
   if (dts) MTG_HIP_TRY(ctx, hipMemsetAsync(dts, 0, batch * sizeof(int32_t), st));
+  if (host_status_dev) MTG_HIP_TRY(ctx, hipMemsetAsync(host_status_dev, 0, sizeof(double), st));
 
   MtgParams P;
   fill_common(p, P, batch, L);
+  if (host_status_dev) P.status = host_status_dev;
   P.times = dt; P.dfix = dfx; P.coeffs = dco; P.dfree = (p->n_free ? dfr : nullptr); P.cost = dcs;
   P.tstatus = dts;
   const bool wc = dcs != nullptr || (!update_only && P.dfree != nullptr);
@@ -578,7 +644,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         dl_ws = p->ws;
       }
     }
-    if (dl->launch((void*)st, grid, dt, dfx, dco, ctx->d_status, dts, (int)batch, nt, policy, dl_ws) != 0)
+    if (dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws) != 0)
       return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
     LaunchRecord r;
     r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws;
@@ -586,33 +652,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   } else {
     // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
     // dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.
-    const MtgStaticEntry* var = nullptr;
-    if (!(flags & MTG_FLAG_GENERIC_KERNEL)) {
-      // Dimension-split form while ALL its workgroups (tiles x dimension groups) are resident at once at <= 2 waves per
-      // SIMD (4 x CUs workgroups); beyond that it runs in rounds and the fused form -- no repeated factorisation, one
-      // round up to 2 x CUs tiles -- wins (measured, N = 10 / K = 8 / D = 3: B = 20k 15.0 vs 15.4 us, B = 30k 25.5 vs
-      // 18.3 us, B = 60k 44.1 vs 34.3 us).  Plans whose fused kernel spills ("heavy") keep the split form longer.
-      bool auto_split = ntiles < 4 * ctx->n_cu;
-      if (p->fast && p->fast_split && !p->fast->heavy)
-        auto_split = (long long)ntiles * (p->D / p->fast_split->d) <= 4ll * ctx->n_cu;
-      const bool want_split = (flags & MTG_FLAG_SPLIT_DIMS) || (!(flags & MTG_FLAG_FUSED_DIMS) && auto_split);
-      var = (want_split && p->fast_split) ? p->fast_split : (p->fast ? p->fast : p->fast_split);
-      if (var && var->heavy && !want_split) {   // large launch, spilling static kernel: the rolled form is faster
-        const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
-        if (v) var = v;
-      }
-      if (ctx->knob_prefer_rolled) {
-        const MtgStaticEntry* v = mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
-        if (v) var = v;
-      }
-      if (ctx->knob_force_dg > 0) {
-        const int dg = ctx->knob_force_dg;
-        if (p->D % dg == 0) {
-          const MtgStaticEntry* v = mtg_find_static(p->H, dg, p->K, p->deriv, p->mask.data());
-          if (v) var = v;
-        }
-      }
-    }
+    const MtgStaticEntry* var = pick_static(p, ntiles, flags, !wc && !cost_only && !pert);
     const int vm = (p->K + 1) / 2;
     const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
     for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
@@ -625,8 +665,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
       // fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
       const MtgSlabEntry* slab = nullptr;
-      if (var && var->k > 0 && var->d == p->D && !wc && !cost_only && !pert && !ctx->knob_no_slab)
-        slab = mtg_find_slab(p->H, p->D, p->K, p->deriv, p->mask.data());
+      if (!wc && !cost_only && !pert) slab = pick_slab(p, var);
       if (slab) {
         const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
         const int sgrid = std::min(ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
@@ -683,14 +722,12 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     // A host-pointer call synchronises anyway: the status word (and the per-trajectory status) come back with the
     // results, and the call itself returns MTG_ERR_BAD_SEGMENT_TIME / MTG_ERR_SINGULAR -- no mtg_context_sync needed.
     if (bounce) {
-      // [d_free | coeffs | cost | status] sit back to back in the device staging area: one D2H DMA
+      // [d_free | coeffs | cost | per-trajectory status | status word] sit back to back in the device staging area: one D2H DMA
       double* s_p = p->stage + n_times + n_fix;
-      const size_t n_out = (size_t)(n_fre + n_coef + batch + n_ts);
+      const size_t n_out = (size_t)(n_fre + n_coef + batch + n_ts + 1);
       MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounce, s_p, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
       MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
-      host_status = *ctx->h_status;
+      std::memcpy(&host_status, ctx->h_bounce + n_fre + n_coef + batch + n_ts, sizeof(int));
       if (!update_only && d_free && n_fre) std::memcpy(d_free, ctx->h_bounce, n_fre * sizeof(double));
       std::memcpy(coeffs, ctx->h_bounce + n_fre, n_coef * sizeof(double));
       if (cost) std::memcpy(cost, ctx->h_bounce + n_fre + n_coef, batch * sizeof(double));
@@ -700,14 +737,26 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
       if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
       if (traj_status) MTG_HIP_TRY(ctx, hipMemcpyAsync(traj_status, dts, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
+      // (h_status is the context's pinned word; the context lock is held, and mtg_context_sync overwrites it under the same lock)
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, host_status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
       MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
       host_status = *ctx->h_status;
     }
     return status_code(ctx, host_status);
   }
   return MTG_OK;
+}
+
+int mtg_plan_launch_form(const mtg_plan* p, int64_t batch, const mtg_layout* L, uint32_t flags) {
+  if (!p || !L || batch <= 0 || (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY))) return MTG_ERR_INVALID_ARGUMENT;
+  MtgParams P;
+  fill_common(p, P, batch, L);   // (no d_free / cost output: coefficient output only)
+  if (pick_dimlane(p, batch, L, P, flags, false)) return 5;
+  const MtgStaticEntry* var = pick_static(p, (int)((batch + kWave - 1) / kWave), flags, true);
+  if (!var) return 0;
+  if (pick_slab(p, var)) return 4;
+  if (var->k < 0) return 3;
+  return var->d == p->D ? 1 : 2;
 }
 
 int mtg_plan_set_workspace(mtg_plan* p, void* device_ptr, size_t bytes) {
@@ -729,19 +778,95 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false, trajectory_status);
 }
 
+// The queue as ONE persistent launch (several when n > kSeqMax), coefficient output only: the slab-output fused kernel
+// (mtg_solve_slab_queue_kernel) or the dimension-in-lane kernel (mtg_solve_dl_queue_kernel; canonical SoA inputs), chosen
+// by the TOTAL number of trajectories the way single launches choose by their batch.  Returns 1 when the call does not
+// qualify (the caller then enqueues one launch per batch), MTG_OK or an error otherwise.
+static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_layout* L, const double* const* times,
+                             const double* const* d_fixed, double* const* coeffs, uint32_t flags) {
+  mtg_context* ctx = p->ctx;
+  if (n < 2 || batch <= 0 || ctx->knob_no_queue) return 1;
+  if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH)) return 1;
+  const int32_t n_launch = std::min<int32_t>(n, kSeqMax);       // batches per launch
+  const MtgSlabEntry* slab = nullptr;
+  if (!(flags & MTG_FLAG_DIMLANE) && !ctx->knob_no_slab && p->fast && p->fast->k > 0 && p->fast->d == p->D)
+    slab = mtg_find_slab(p->H, p->D, p->K, p->deriv, p->mask.data());
+  if (slab && (!slab->queue || ((batch + kWave - 1) / kWave) * (int64_t)n_launch >= (1ll << 31))) slab = nullptr;
+  const MtgDimlaneEntry* dl = p->dimlane;
+  if (dl && (!dl->launch_queue || ctx->knob_no_dimlane || (flags & MTG_FLAG_FUSED_DIMS))) dl = nullptr;
+  if (dl && (L->times_stride_b != 1 || L->times_stride_k != batch || L->fixed_stride_b != 1 || L->fixed_stride_c != batch ||
+             L->fixed_stride_d != (int64_t)p->n_fixed * batch ||
+             batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32) ||
+             ((batch + dl->tpw - 1) / dl->tpw) * (int64_t)n_launch >= (1ll << 31)))
+    dl = nullptr;
+  if (slab && dl && !(flags & MTG_FLAG_DIMLANE) && !dimlane_is_default(p, dl, batch * (int64_t)n_launch)) dl = nullptr;
+  if (!slab && !dl) return 1;
+  for (int32_t i = 0; i < n; ++i) {
+    if (!times[i] || !coeffs[i] || (p->n_fixed > 0 && !d_fixed[i])) return MTG_ERR_INVALID_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(coeffs[i]) & 15) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");
+  }
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  p->last.clear();
+  const int64_t tpb = dl ? (batch + dl->tpw - 1) / dl->tpw : (batch + kWave - 1) / kWave;
+  MtgParams P;
+  fill_common(p, P, batch, L);
+  P.times = times[0]; P.dfix = d_fixed ? d_fixed[0] : nullptr; P.coeffs = coeffs[0];
+  if (!dl && !p->slab_queue_attr_set) {
+    MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->queue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
+    p->slab_queue_attr_set = true;
+  }
+  for (int32_t i0 = 0; i0 < n; i0 += kSeqMax) {
+    MtgSeqQueue q;
+    q.n = std::min<int32_t>(kSeqMax, n - i0);
+    q.tiles_per_batch = (int)tpb;
+    for (int i = 0; i < q.n; ++i) q.item[i] = MtgSeqItem{times[i0 + i], d_fixed ? d_fixed[i0 + i] : nullptr, coeffs[i0 + i]};
+    for (int i = q.n; i < kSeqMax; ++i) q.item[i] = MtgSeqItem{nullptr, nullptr, nullptr};
+    const int ntiles = q.n * (int)tpb;
+    if (dl) {
+      const int units = (ntiles + dl->np - 1) / dl->np;
+      int grid = std::min(units, ctx->n_cu * 8);
+      double* dl_ws = nullptr;
+      if (dl->ws_per_lane) {   // long chains: persistent workgroups only, as in single launches
+        grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
+        const size_t need = dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave;
+        if (p->user_ws) {
+          if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
+          dl_ws = p->user_ws;
+        } else {
+          int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+          if (rc != MTG_OK) return rc;
+          dl_ws = p->ws;
+        }
+      }
+      if (dl->launch_queue((void*)ctx->stream, grid, &q, ctx->d_status, (int)batch, ntiles, dl_ws) != 0)
+        return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane queue launch set-up failed");
+    } else {
+      const int grid = std::min(ntiles, ctx->n_cu * 2);   // two workgroups per CU, one wave per SIMD (as the single-batch launch)
+      hipLaunchKernelGGL(slab->queue, dim3(grid), dim3(kBlock), slab->lds, ctx->stream, P, ntiles, q);
+    }
+  }
+  MTG_HIP_TRY(ctx, hipGetLastError());
+  return MTG_OK;
+}
+
 int mtg_solve_linear_sequence_events(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
                                      const double* const* times, const double* const* d_fixed, double* const* coeffs,
                                      uint32_t flags, void* start_event, void* stop_event) {
-  if (!plan || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
+  if (!plan || !layout || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
   if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = plan->ctx;
   if (start_event) {
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)start_event, ctx->stream));
   }
-  int rc = MTG_OK;
-  for (int32_t i = 0; i < n && rc == MTG_OK; ++i)
-    rc = solve_impl(plan, batch, layout, times[i], d_fixed ? d_fixed[i] : nullptr, coeffs[i], nullptr, nullptr, flags, false);
+  int rc = sequence_as_queue(plan, n, batch, layout, times, d_fixed, coeffs, flags);
+  if (rc == 1) {
+    rc = MTG_OK;
+    for (int32_t i = 0; i < n && rc == MTG_OK; ++i)
+      rc = solve_impl(plan, batch, layout, times[i], d_fixed ? d_fixed[i] : nullptr, coeffs[i], nullptr, nullptr,
+                      flags & ~(uint32_t)MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH, false);
+  }
   if (stop_event) MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)stop_event, ctx->stream));
   return rc;
 }

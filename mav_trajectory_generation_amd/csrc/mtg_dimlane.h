@@ -95,14 +95,15 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
 // C: static configuration with C::D == 1 (one dimension per lane); DL: dimensions of the plan (lanes per trajectory);
 // NP: (tile, direction-pair) units per workgroup (2: four waves, one per SIMD of a CU; 1 where two slabs pairs do not fit
 // the LDS).  AUX: cache policy bits of the coefficient stores (0 write-back, 1 sc0, 2 nt, 16 sc1).
-template <class C, int DL, int NP, int OUT, int AUX>
-__global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
-                                                                            const double* __restrict__ dfix,
-                                                                            double* __restrict__ coeffs, int* status,
-                                                                            int* traj_status, int B, int ntiles, int nwg,
-                                                                            double* ws
+// QUEUE (mtg_solve_dl_queue_kernel, mtg_solve_linear_sequence): `ntiles` counts the tiles of ALL batches of the queue
+// (batch-major, q->tiles_per_batch each); a wave's tile index -> (batch, tile inside it) is advanced incrementally
+// (wave-uniform) and the batch's pointer triple comes from the kernel arguments.
+template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE>
+__device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ times, const double* __restrict__ dfix,
+                                                  double* __restrict__ coeffs, int* status, int* traj_status, int B, int ntiles,
+                                                  int nwg, double* ws, const MtgSeqQueue* q
 #if defined(MTG_LAB_TIMING)
-                                                                            , long long* tdbg_base
+                                                  , long long* tdbg_base
 #endif
 ) {
   static_assert(C::kStatic && C::D == 1 && C::KT >= 2, "dimension-in-lane form: static one-dimension configurations");
@@ -135,14 +136,38 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
 
   const int nunits = (ntiles + NP - 1) / NP;
   MtgLane<C> ln;
+  // QUEUE: this wave's tile as (batch, tile inside the batch); the clamp of a surplus tile (odd tile count, NP == 2) lands
+  // on the last tile of the last batch
+  const int tpb = QUEUE ? q->tiles_per_batch : ntiles;
+  int batch = 0, local = 0;
   auto tile_of = [&](int it) { const int tl = NP * it + pair; return tl < ntiles ? tl : ntiles - 1; };
-  auto fetch = [&](int tile_) {
-    unsigned bb = (unsigned)tile_ * TPW + t;
-    if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload<C, 1>(times, dfix, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
-    else mtg_dl_preload<C, -1>(times, dfix, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
+  auto locate = [&](int tile_) {        // absolute (first unit) ...
+    if constexpr (QUEUE) { batch = tile_ / tpb; local = tile_ - batch * tpb; } else { local = tile_; }
   };
-  if ((int)blockIdx.x < nunits) fetch(tile_of(blockIdx.x));
+  auto advance = [&](int tile_, int prev_) {   // ... then relative to the previous unit's tile
+    if constexpr (QUEUE) { local += tile_ - prev_; while (local >= tpb) { local -= tpb; ++batch; } } else { local = tile_; }
+  };
+  const double* t_cur = times; const double* f_cur = dfix; double* c_cur = coeffs;
+  auto bind = [&]() {
+    if constexpr (QUEUE) {
+      const MtgSeqItem it = q->item[batch];
+      t_cur = it.times; f_cur = it.dfix; c_cur = it.coeffs;
+      P.times = t_cur; P.dfix = f_cur; P.coeffs = c_cur;
+    }
+  };
+  auto fetch = [&]() {
+    unsigned bb = (unsigned)local * TPW + t;
+    if (bb >= (unsigned)B) bb = B - 1;
+    if (dir == 0) mtg_dl_preload<C, 1>(t_cur, f_cur, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
+    else mtg_dl_preload<C, -1>(t_cur, f_cur, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
+  };
+  int tile_prev = 0;
+  if ((int)blockIdx.x < nunits) {
+    tile_prev = tile_of(blockIdx.x);
+    locate(tile_prev);
+    bind();
+    fetch();
+  }
   const int lane_io = lane, t_io = t, d_io = d;
 #if defined(MTG_LAB_TIMING)
   if (lane == 0) tdbg[1] = clock64();
@@ -166,12 +191,17 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
   ioB.init(my_slab, lane_io, t_io, d_io);
   for (int it = blockIdx.x; it < nunits; it += nwg) {
     const int tile = tile_of(it);
-    const long long b0 = (long long)tile * TPW;
+    const bool first = it == (int)blockIdx.x;
+    if (!first) {
+      advance(tile, tile_prev);
+      tile_prev = tile;
+      bind();
+      fetch();
+    }
+    const long long b0 = (long long)local * TPW;
     const long long bl = b0 + t;
     const bool active = bl < B && !dup;
     const long long b = bl < B ? bl : B - 1;
-    const bool first = it == (int)blockIdx.x;
-    if (!first) fetch(tile);
     // the workspace column pointer is re-defined opaquely per tile: otherwise every one of the ~(f*f + f) * WSJ store and
     // load addresses derived from it is loop-invariant, gets hoisted out of the tile loop and spills (measured: 233
     // scratch stores in the prologue of the K = 32 kernel)
@@ -184,10 +214,10 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
     __syncthreads();
     MTG_DL_STAMP(3);
     if (dir == 0) {
-      ioA.begin_tile(coeffs, b0, B);
+      ioA.begin_tile(c_cur, b0, B);
       mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active);
     } else {
-      ioB.begin_tile(coeffs, b0, B);
+      ioB.begin_tile(c_cur, b0, B);
       mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active);
     }
 #if defined(MTG_LAB_TIMING)
@@ -198,6 +228,32 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
     __syncthreads();
   }
 }
+
+template <class C, int DL, int NP, int OUT, int AUX>
+__global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
+                                                                            const double* __restrict__ dfix,
+                                                                            double* __restrict__ coeffs, int* status,
+                                                                            int* traj_status, int B, int ntiles, int nwg,
+                                                                            double* ws
+#if defined(MTG_LAB_TIMING)
+                                                                            , long long* tdbg_base
+#endif
+) {
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, nullptr
+#if defined(MTG_LAB_TIMING)
+                                                , tdbg_base
+#endif
+  );
+}
+
+#if !defined(MTG_LAB_TIMING)
+// the queue form: same body, the batches' pointer triples in the kernel arguments (mtg_solve_linear_sequence)
+template <class C, int DL, int NP, int OUT, int AUX>
+__global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
+                                                                                  double* ws, MtgSeqQueue q) {
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, &q);
+}
+#endif
 
 // ---- cross-structure launch: the buckets of a mixed request (BASELINE config 4: N in {8, 10, 12} x K in {4, 8, 16, 32}) in ONE
 // launch, each unit (one tile = 64 / DL trajectories, both chain directions) running its own static configuration.  The

@@ -31,6 +31,26 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
   (void)policy;
   return go(mtg_solve_dl_kernel<C, DL, NP, 0, 18>, 0);
 }
+#if !defined(MTG_DL_SINGLE_POLICY)
+// the queue form (mtg_solve_linear_sequence): nt sc1 stores, main table only
+template <class C, int DL, int NP>
+int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws) {
+  constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
+  static bool attr_set[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+  auto kern = mtg_solve_dl_queue_kernel<C, DL, NP, 0, 18>;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, (hipStream_t)stream, status, B, ntiles, grid, ws, *q);
+  return 0;
+}
+#define MTG_DL_QUEUE_FN(...) launch_dl_queue<__VA_ARGS__>
+#else
+#define MTG_DL_QUEUE_FN(...) nullptr
+#endif
 }  // namespace
 
 #define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0), LS>
@@ -38,7 +58,8 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
   {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>(),    \
    (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::LSJ) *           \
        MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSE * sizeof(double),                                                   \
-   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>},
+   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>,                                                         \
+   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP)},
 #define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include MTG_DL_TABLE_INC
@@ -46,6 +67,7 @@ static const MtgDimlaneEntry kDimlaneTable[] = {
 #undef MTG_DL
 #undef MTG_DLW
 #undef MTG_DLCFG
+#undef MTG_DL_QUEUE_FN
 
 const MtgDimlaneEntry* MTG_DL_TABLE_FN(int* count) {
   *count = (int)(sizeof(kDimlaneTable) / sizeof(kDimlaneTable[0]));

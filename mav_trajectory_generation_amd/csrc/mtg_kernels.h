@@ -239,20 +239,46 @@ __host__ __device__ constexpr size_t mtg_slab_lds_bytes() {
   return 2 * (a > b ? a : b);
 }
 
-template <class C, int AUX>
-__global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, int ntiles) {
+// A queue of batches in ONE launch (mtg_solve_linear_sequence): n independent batches of the same plan, batch size and
+// layout; the persistent workgroups walk the tiles of all of them (tile -> (batch, tile inside the batch), batch-major), so
+// a wave of batch i + 1 starts the moment a SIMD is free -- no drain / launch gap between the batches (1.0-1.3 us between
+// dependent launches; ~1.8k cycles of store acknowledgement at the end of each) and the store tail of batch i runs under
+// the forward chains of batch i + 1.  The pointer triples travel in the kernel arguments (no upload in front of the launch).
+struct MtgSeqItem { const double* times; const double* dfix; double* coeffs; };
+constexpr int kSeqMax = 96;    // batches per launch (kernel arguments <= 4 KB); longer queues are cut into several launches
+struct MtgSeqQueue {
+  int n, tiles_per_batch;
+  MtgSeqItem item[kSeqMax];
+};
+
+template <class C, int AUX, bool QUEUE>
+__device__ __forceinline__ void mtg_solve_slab_body(const MtgParams& P, int ntiles, const MtgSeqQueue* q) {
   static_assert(C::kStatic && C::KT >= 2 && !C::kPert, "slab-output form: static configurations, K >= 2");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int lane = threadIdx.x & (kWave - 1);
   const int dir = threadIdx.x >> 6;  // wave-uniform
   MtgLane<C> ln;
-  auto fetch = [&](int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
+  // QUEUE: (batch, tile inside the batch) of a global tile index, advanced incrementally (wave-uniform, scalar)
+  const int tpb = QUEUE ? q->tiles_per_batch : ntiles;
+  auto norm = [&](int& bt, int& lc) { if constexpr (QUEUE) { while (lc >= tpb) { lc -= tpb; ++bt; } } };
+  auto params_of = [&](int bt) -> MtgParams {
+    MtgParams Pt = P;
+    if constexpr (QUEUE) {
+      const MtgSeqItem it = q->item[bt];
+      Pt.times = it.times; Pt.dfix = it.dfix; Pt.coeffs = it.coeffs;
+    }
+    return Pt;
+  };
+  auto fetch = [&](const MtgParams& Pt, int tile_, double (&T_)[C::KCS], double (&fx_)[C::D][C::NC]) {
     long long bb = (long long)tile_ * kWave + lane;
     if (bb >= P.B) bb = P.B - 1;
-    if (dir == 0) mtg_preload_into<C, 1>(P, bb, T_, fx_);
-    else mtg_preload_into<C, -1>(P, bb, T_, fx_);
+    if (dir == 0) mtg_preload_into<C, 1>(Pt, bb, T_, fx_);
+    else mtg_preload_into<C, -1>(Pt, bb, T_, fx_);
   };
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, ln.T, ln.fx);
+  int batch = 0, local = blockIdx.x;
+  norm(batch, local);
+  MtgParams Pc = params_of(batch);
+  if ((int)blockIdx.x < ntiles) fetch(Pc, local, ln.T, ln.fx);
   constexpr int mm = C::MI;
   constexpr int fmid = C::H - C::popc(mm);
   constexpr int nslots = fmid * (fmid + 1) / 2 + C::D * fmid;
@@ -267,22 +293,28 @@ __global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, 
   ioB.init(my_slab, lane, lane, 0);
   double nT[C::KCS], nfx[C::D][C::NC];
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b0 = (long long)tile * kWave;
+    const long long b0 = (long long)local * kWave;
     const long long bl = b0 + lane;
     const bool active = bl < P.B;
     const long long b = active ? bl : P.B - 1;   // tail lanes duplicate the last trajectory, outputs suppressed
     const bool has_next = tile + (int)gridDim.x < ntiles;
-    if (has_next) fetch(tile + gridDim.x, nT, nfx);   // the next tile's inputs land while this one is solved
-    if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, nullptr, false);
-    else mtg_lane_forward<C, -1>(P, b, ln, nullptr, false);
+    int nbatch = batch, nlocal = local + (int)gridDim.x;
+    norm(nbatch, nlocal);
+    MtgParams Pn = P;
+    if (has_next) {   // the next tile's inputs land while this one is solved
+      Pn = params_of(nbatch);
+      fetch(Pn, nlocal, nT, nfx);
+    }
+    if (dir == 0) mtg_lane_forward<C, 1>(Pc, b, ln, nullptr, false);
+    else mtg_lane_forward<C, -1>(Pc, b, ln, nullptr, false);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
     __syncthreads();
     if (dir == 0) {
-      ioA.begin_tile(P.coeffs, b0, P.B);
-      mtg_lane_finish<C, 1, 0>(P, b, ln, nullptr, other, kWave, ioA, active);
+      ioA.begin_tile(Pc.coeffs, b0, P.B);
+      mtg_lane_finish<C, 1, 0>(Pc, b, ln, nullptr, other, kWave, ioA, active);
     } else {
-      ioB.begin_tile(P.coeffs, b0, P.B);
-      mtg_lane_finish<C, -1, 0>(P, b, ln, nullptr, other, kWave, ioB, active);
+      ioB.begin_tile(Pc.coeffs, b0, P.B);
+      mtg_lane_finish<C, -1, 0>(Pc, b, ln, nullptr, other, kWave, ioB, active);
     }
     if (has_next) {
 #pragma unroll
@@ -293,8 +325,20 @@ __global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, 
         for (int c = 0; c < C::NC; ++c) ln.fx[dm][c] = nfx[dm][c];
       }
     }
+    if constexpr (QUEUE) { batch = nbatch; local = nlocal; Pc = Pn; }
+    else local = nlocal;
     __syncthreads();
   }
+}
+
+template <class C, int AUX>
+__global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, int ntiles) {
+  mtg_solve_slab_body<C, AUX, false>(P, ntiles, nullptr);
+}
+
+template <class C, int AUX>
+__global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_queue_kernel(MtgParams P, int ntiles, MtgSeqQueue q) {
+  mtg_solve_slab_body<C, AUX, true>(P, ntiles, &q);
 }
 
 // Several plans in ONE launch (BASELINE config 4: a mixed request whose buckets share N, D, masks and derivative but not
@@ -407,10 +451,12 @@ struct MtgStaticEntry {
   SolveMultiFn multi[4];            // rolled entries: several plans in one launch, [extra outputs] + 2 * [write-through]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);
+using SolveQueueFn = void (*)(MtgParams, int, MtgSeqQueue);
 struct MtgSlabEntry {
   int h, d, k, ms, mi, me, dv;
   size_t lds;
   SolveFn fn[2];   // coefficient store policy: [0] write-back, [1] nt sc1
+  SolveQueueFn queue;   // the same (nt sc1) over a queue of batches: mtg_solve_linear_sequence
 };
 const MtgSlabEntry* mtg_find_slab(int h, int d, int k, int deriv, const int* mask);
 
@@ -418,13 +464,16 @@ const MtgSlabEntry* mtg_find_slab(int h, int d, int k, int deriv, const int* mas
 struct MtgDimlaneEntry {
   int h, k, ms, mi, me, dv, dl, np;
   int tpw;            // trajectories per wave (64 / dl)
-  int lo_per_cu, hi_per_cu;   // default form while lo * CUs <= workgroups <= hi * CUs (hi = 0: no upper limit)
+  int lo_per_cu, hi_per_cu;   // default form while lo * CUs <= workgroups <= hi * CUs / 2 (hi = 0: no upper limit; hi counts HALF workgroups per CU)
   size_t lds;         // dynamic LDS per workgroup
   size_t ws_per_lane; // long-chain variants (MtgCfg::WSJ > 0): workspace bytes per resident lane (grid * np * 128 lanes), else 0
   // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
   // cache policy (0 nt sc1, 1 sc1, 2 write-back); returns 0 or -1 (attribute / launch set-up failed)
   int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
                 int* traj_status, int B, int ntiles, int policy, double* ws);
+  // a queue of batches in one launch (mtg_solve_linear_sequence; main-table variants only, else null): ntiles = tiles of
+  // all batches (q->n * q->tiles_per_batch)
+  int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws);
 };
 // cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
 // dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])

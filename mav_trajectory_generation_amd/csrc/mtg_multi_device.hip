@@ -27,6 +27,11 @@ struct mtg_device_group {
 extern "C" {
 
 void mtg_shard_range(int64_t batch, int32_t n_shards, int32_t shard, int64_t* lo, int64_t* hi) {
+  if (n_shards <= 0 || shard < 0 || shard >= n_shards || batch < 0) {   // no such shard: the empty range
+    if (lo) *lo = 0;
+    if (hi) *hi = 0;
+    return;
+  }
   const int64_t base = batch / n_shards, rem = batch % n_shards;
   const int64_t l = shard * base + (shard < rem ? shard : rem);
   if (lo) *lo = l;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void mtg_compare_kernel(const double* __restri
       num = fmax(num, fabs(x - y));
       den = fmax(den, fabs(y));
     }
-    if (bad) num = den = 1.0e300;                 // a NaN anywhere reports as a huge difference
+    if (bad) { num = 1.0e300; den = 1.0; }        // a NaN anywhere saturates BOTH outputs (relative and absolute)
     ab = fmax(ab, num);
     rel = fmax(rel, den > 0.0 ? fmin(num / den, 1.0e300) : (num > 0.0 ? 1.0e300 : 0.0));
   }

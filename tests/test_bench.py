@@ -32,6 +32,7 @@ def test_gpus_flag_spawns_the_ranks_itself():
     assert r.returncode == 0, r.stderr[-2000:]
     out = last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["ranks_seen"] == 2 and out["rank_devices"] == [0, 1]     # an all_reduce of ones / all_gather of LOCAL_RANK
 
 
 def test_world_size_mismatch_fails_loudly():
@@ -50,6 +51,20 @@ def test_two_rank_bench_on_one_gpu():
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     g = out["gather"]
     assert g["chunks"] == 2 and g["solve_plus_gather_ms"] > 0 and g["gathered_bytes_per_rank"] == 2 * 4000 * 8 * 3 * 10 * 8
+    # what a SCALE record needs beyond the contract fields: proof that the backend spans the ranks, where each rank ran,
+    # every rank's own timing (value uses the max), and the CPU baseline when asked for
+    assert out["ranks_seen"] == 2 and out["rank_devices"] == [0, 0]
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["device_us_per_step"] > 0 for r in out["per_rank"])
+    assert out["roofline"]["device_us_per_step"] == max(r["device_us_per_step"] for r in out["per_rank"])
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_carries_the_cpu_baseline():
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "2", "--batch", "2000",
+                  "--buffer-sets", "2", "--no-gather", "--no-extras")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1
 
 
 @pytest.mark.gpu
@@ -63,7 +78,28 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["config"]["buffer_sets"] == 16
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["traffic"] is None and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["bytes_per_launch"] == 10_000 * 2392
+    # the 20 timed steps = 20 independent batches in ONE persistent launch (mtg_solve_linear_sequence)
+    assert out["config"]["sequence"] == "queue" and rf["launches"] == 1 and rf["batches_per_launch"] == 20
+    assert rf["bytes_per_launch"] == 20 * 10_000 * 2392 and rf["bytes_per_step"] == 10_000 * 2392
+    assert abs(rf["achieved"] - rf["bytes_per_step"] / rf["device_us_per_step"] * 1e-3) < 1e-6 * rf["achieved"]
+    assert out["ranks_seen"] == 1
     assert "resident_buffers" in out["extra"]
-    two = out["extra"]["two_streams_steady_state"]      # pipeline over two streams: reported beside, never as `value`
-    assert two["launches"] == 2000 and 0 < two["us_per_launch"] < rf["kernel_us"] * 1.2
+    one = out["extra"]["one_launch_per_batch"]          # the latency form: reported beside, never as `value`
+    assert one["steps"] == 200 and one["us_per_step"] > rf["device_us_per_step"]
+
+
+@pytest.mark.gpu
+def test_latency_form_and_config4_lines():
+    r = run_bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--sequence", "launches", "--no-extras")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    assert out["config"]["sequence"] == "launches" and out["roofline"]["launches"] == 20
+    assert out["roofline"]["bytes_per_launch"] == 10_000 * 2392
+    r = run_bench("--config", "4", "--steps", "10", "--warmup", "3", "--buffer-sets", "4")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    # 12 buckets x 2500: sum over buckets of 8 * (K + 3 (N + K - 1) + 3 K N) bytes per trajectory = 128.9 MB per step
+    want = sum(2500 * 8 * (k + 3 * (n + k - 1) + k * 3 * n) for n in (8, 10, 12) for k in (4, 8, 16, 32))
+    assert out["config"]["baseline_config"] == 4 and out["config"]["trajectories_per_step"] == 30_000
+    assert out["roofline"]["bytes_per_step"] == want and 0 < out["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in out

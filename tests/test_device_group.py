@@ -17,6 +17,10 @@ def test_shard_range_matches_the_multi_process_split():
             for r in range(world):
                 lib.mtg_shard_range(batch, world, r, ctypes.byref(lo), ctypes.byref(hi))
                 assert (lo.value, hi.value) == shard_range(batch, r, world)
+    for (batch, world, r) in ((100, 0, 0), (100, -2, 0), (100, 4, 4), (100, 4, -1), (-5, 2, 0)):   # no such shard: empty range
+        lo.value, hi.value = 7, 9
+        lib.mtg_shard_range(batch, world, r, ctypes.byref(lo), ctypes.byref(hi))
+        assert (lo.value, hi.value) == (0, 0)
 
 
 @pytest.mark.gpu

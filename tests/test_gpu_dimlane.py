@@ -209,3 +209,58 @@ def test_status_of_graph_replays_is_reported(ctx):
     g.replay()
     ctx.sync()
     plan.close()
+
+
+@pytest.mark.parametrize("bsz_host", [1, 40, 9000])      # bounce-buffer calls and staged pageable copies
+def test_host_pointer_calls_have_their_own_status_word(ctx, bsz_host):
+    """flags raised by an asynchronous device-pointer solve belong to the next mtg_context_sync; a
+    host-pointer call in between reports (and clears) only the flags of its own launch."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 8)
+    plan = m.Plan(ctx, 10, 3, 8, 4, masks)
+    t, f = m.random_waypoint_batch(2000, 8, 3, 10, masks, seed=8, device="cuda", layout="soa")
+    t[4, 1234] = -2.0
+    plan.solve(t, f, layout="soa")                     # asynchronous, raises the bad-time flag on the device
+    th, fh = m.random_waypoint_batch(bsz_host, 8, 3, 10, masks, seed=9, device="cpu")
+    co, _, cost = plan.solve_host(th.numpy(), fh.numpy())         # a correct solve: must not be blamed
+    assert np.isfinite(co).all() and np.isfinite(cost).all()
+    with pytest.raises(m.MtgError) as e:               # ... and the failed batch is still reported
+        ctx.sync()
+    assert e.value.code == -2
+    ctx.sync()
+    # the other way round: a failing host-pointer call reports itself and leaves nothing behind
+    th2 = th.clone()
+    th2[0, 3] = 0.0
+    with pytest.raises(m.MtgError) as e:
+        plan.solve_host(th2.numpy(), fh.numpy())
+    assert e.value.code == -2
+    ctx.sync()
+    plan.close()
+
+
+def test_default_form_cross_over_is_pinned(ctx):
+    """mtg_dimlane_variants.inc's HI counts HALF workgroups per CU (HI = 3: the dimension-in-lane form is the
+    default up to 1.5 workgroups of 42 trajectories per CU, B ~ 16k on 256 CUs; profiles/r02_sweep_forms.txt: the slab-output
+    fused kernel wins from 20k on).  mtg_plan_launch_form reports the choice without launching."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    plan = m.Plan(ctx, 10, 3, 8, 4, m.ends_full_masks(10, 8))
+    edge = (3 * cus // 2) * 42                  # largest batch with 2 * workgroups <= 3 * CUs
+    assert plan.launch_form(10_000) == "dimlane" and plan.launch_form(edge) == "dimlane"
+    assert plan.launch_form(edge + 1) == "slab" and plan.launch_form(125_000) == "slab"
+    assert plan.launch_form(125_000, dims="dimlane") == "dimlane" and plan.launch_form(10_000, dims="split") == "split"
+    # the dimension-in-lane form needs canonical SoA inputs; coefficient-only calls of a shape with a slab-output kernel
+    # never take the split form by default (partial sectors: 15.4 vs 10.4 us at 10k with rotating buffers)
+    assert plan.launch_form(10_000, layout="aos") == "slab" and plan.launch_form(20_000) == "slab"
+    plan.close()
+    p5 = m.Plan(ctx, 10, 4, 16, 4, m.ends_full_masks(10, 16, 7))      # config 5: no upper limit
+    assert p5.launch_form(12_500) == "dimlane" and p5.launch_form(1_000_000) == "dimlane"
+    p5.close()
+    p12 = m.Plan(ctx, 12, 3, 4, 5, m.ends_full_masks(12, 4))          # HI = 3 here as well
+    assert p12.launch_form(edge) == "dimlane" and p12.launch_form(edge + 1) == "slab"
+    p12.close()
+    odd = m.Plan(ctx, 10, 3, 8, 4, [31, 3, 1, 1, 7, 1, 1, 1, 31])     # ragged masks: the generic kernel
+    assert odd.launch_form(5000) == "generic"
+    odd.close()

@@ -734,6 +734,11 @@ def test_device_side_generator_and_compare(ctx, layout):
         den = co.abs().amax(dim=-1).clamp_min(1e-300)
         want_rel = float(((other - co).abs().amax(dim=-1) / den).max())
         assert abs(rel - want_rel) <= 1e-12 * want_rel and abs(ab - float((other - co).abs().max())) < 1e-18
+        # a NaN on either side saturates both outputs (a caller with a loose threshold must not accept NaN output)
+        other[7, 0, 1, 3] = float("nan")
+        for a_, b_ in ((other, co), (co, other)):
+            rel, ab = ctx.compare_coefficients(a_, b_)
+            assert rel >= 1e299 and ab >= 1e299
         plan.close()
 
 
