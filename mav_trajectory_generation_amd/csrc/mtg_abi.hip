@@ -108,6 +108,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
+  bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
@@ -251,6 +252,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
+  ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
@@ -434,6 +436,16 @@ static int64_t span(int64_t batch, int64_t sb, int64_t n1, int64_t s1, int64_t n
 // d_fixed[D][n_fixed][B]), coefficient output only, sizes whose 32-bit byte offsets cannot overflow.  Chosen by default
 // while the launch is at most a few workgroups per CU (measured cross-over against the fused form: DESIGN.md section 4);
 // MTG_FLAG_DIMLANE forces it, MTG_FLAG_FUSED_DIMS / MTG_FLAG_SPLIT_DIMS / MTG_FLAG_GENERIC_KERNEL exclude it.
+// Persistent grid over equal-cost tiles: with `cap` resident workgroups the launch takes ceil(ntiles / cap) rounds whatever
+// the grid; spreading the tiles evenly over those rounds (grid = ceil(ntiles / rounds) <= cap) keeps the rounds, and
+// every round runs with fewer workgroups competing for HBM (a 20 x 10k queue: 3140 tiles = 6.13 rounds of 512 -> 7 rounds
+// of 449 instead of 6 full rounds and a 13 %-full one).  MTG_NO_BALANCE: the full grid (A/B runs).
+static int balanced_grid(const mtg_context* ctx, int ntiles, int cap) {
+  if (ntiles <= cap || ctx->knob_no_balance) return std::min(ntiles, cap);
+  const int rounds = (ntiles + cap - 1) / cap;
+  return (ntiles + rounds - 1) / rounds;
+}
+
 // default range of the dimension-in-lane form (mtg_dimlane_variants.inc): LO * CUs <= workgroups <= HI * CUs / 2
 // (HI = 0: no upper limit; HI = 3 = 1.5 workgroups per CU, the measured cross-over against the slab-output fused kernel)
 static bool dimlane_is_default(const mtg_plan* p, const MtgDimlaneEntry* dl, int64_t trajectories) {
@@ -668,7 +680,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       if (!wc && !cost_only && !pert) slab = pick_slab(p, var);
       if (slab) {
         const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
-        const int sgrid = std::min(ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
+        const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
         if (!p->slab_attr_set[pol]) {
           MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->fn[pol], hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
           p->slab_attr_set[pol] = true;
@@ -842,7 +854,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
       if (dl->launch_queue((void*)ctx->stream, grid, &q, ctx->d_status, (int)batch, ntiles, dl_ws) != 0)
         return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane queue launch set-up failed");
     } else {
-      const int grid = std::min(ntiles, ctx->n_cu * 2);   // two workgroups per CU, one wave per SIMD (as the single-batch launch)
+      const int grid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // two workgroups per CU, one wave per SIMD (as the single-batch launch)
       hipLaunchKernelGGL(slab->queue, dim3(grid), dim3(kBlock), slab->lds, ctx->stream, P, ntiles, q);
     }
   }

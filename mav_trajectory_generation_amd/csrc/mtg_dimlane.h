@@ -320,21 +320,21 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   // (the caller's end-of-unit barrier frees the LDS)
 }
 
-// The configurations a cross-structure launch can hold (index = MtgDlAnyItem::cfg): X(index, H, K, MS, MI, ME, DV, WS, LS),
-// DL = 3; (WS, LS) as in mtg_dimlane_variants.inc
-#define MTG_DL_ANY_LIST(X)             \
-  X(0, 4, 4, 15, 1, 15, 3, 0, 0)       \
-  X(1, 4, 8, 15, 1, 15, 3, 0, 0)       \
-  X(2, 4, 16, 15, 1, 15, 3, 0, 0)      \
-  X(3, 4, 32, 15, 1, 15, 3, 8, 7)      \
-  X(4, 5, 4, 31, 1, 31, 4, 0, 0)       \
-  X(5, 5, 8, 31, 1, 31, 4, 0, 0)       \
-  X(6, 5, 16, 31, 1, 31, 4, 0, 0)      \
-  X(7, 5, 32, 31, 1, 31, 4, 11, 5)     \
-  X(8, 6, 4, 63, 1, 63, 5, 0, 0)       \
-  X(9, 6, 8, 63, 1, 63, 5, 0, 0)       \
-  X(10, 6, 16, 63, 1, 63, 5, 6, 3)     \
-  X(11, 6, 32, 63, 1, 63, 5, 15, 3)
+// The configurations a cross-structure launch can hold (index = MtgDlAnyItem::cfg): X(index, H, K, MS, MI, ME, DV, WS, LS, RS),
+// DL = 3; (WS, LS, RS) as in mtg_dimlane_variants.inc
+#define MTG_DL_ANY_LIST(X)                \
+  X(0, 4, 4, 15, 1, 15, 3, 0, 0, 0)       \
+  X(1, 4, 8, 15, 1, 15, 3, 0, 0, 0)       \
+  X(2, 4, 16, 15, 1, 15, 3, 0, 0, 0)      \
+  X(3, 4, 32, 15, 1, 15, 3, 0, 0, 1)      \
+  X(4, 5, 4, 31, 1, 31, 4, 0, 0, 0)       \
+  X(5, 5, 8, 31, 1, 31, 4, 0, 0, 0)       \
+  X(6, 5, 16, 31, 1, 31, 4, 0, 0, 0)      \
+  X(7, 5, 32, 31, 1, 31, 4, 7, 5, 1)      \
+  X(8, 6, 4, 63, 1, 63, 5, 0, 0, 0)       \
+  X(9, 6, 8, 63, 1, 63, 5, 0, 0, 0)       \
+  X(10, 6, 16, 63, 1, 63, 5, 4, 3, 1)     \
+  X(11, 6, 32, 63, 1, 63, 5, 15, 3, 0)
 
 // Units are sorted longest-chain-first by the host; persistent workgroups take them with stride gridDim.x, so neighbouring
 // workgroups (same CU, same instruction cache) run the same configuration's code at about the same time.  (Measured and
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_any_kernel(const Mt
     const MtgDlAnyUnit un = units[u];
     const MtgDlAnyItem it = items[un.item];
     switch (__builtin_amdgcn_readfirstlane(it.cfg)) {
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
-      case I: mtg_dl_any_unit<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>, 3, AUX>(it, un.tile, status, wsl0, ws_stride, lds_raw); break;
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS, RS) \
+      case I: mtg_dl_any_unit<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, ((WS > 0 || RS) ? 3 : 0), LS, RS>, 3, AUX>(it, un.tile, status, wsl0, ws_stride, lds_raw); break;
       MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
       default: break;

@@ -33,7 +33,7 @@ const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const i
 // ---- cross-structure launches (mtg_solve_dl_any_kernel) ----
 int mtg_dl_any_index(const MtgDimlaneEntry* e) {
   if (!e || e->dl != 3) return -1;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS, RS) \
   if (e->h == H && e->k == K && e->ms == MS && e->mi == MI && e->me == ME && e->dv == DV) return I;
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
@@ -41,16 +41,16 @@ int mtg_dl_any_index(const MtgDimlaneEntry* e) {
 }
 size_t mtg_dl_any_lds_bytes() {
   size_t m = 0;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
-  m = std::max(m, mtg_dl_pair_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>, 3>());
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS, RS) \
+  m = std::max(m, mtg_dl_pair_bytes<MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, ((WS > 0 || RS) ? 3 : 0), LS, RS>, 3>());
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
   return m;
 }
 size_t mtg_dl_any_ws_per_lane() {
   size_t m = 0;
-#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS) \
-  m = std::max(m, (size_t)(WS - LS) * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? 3 : 0), LS>::WSE * sizeof(double));
+#define MTG_X(I, H, K, MS, MI, ME, DV, WS, LS, RS) \
+  m = std::max(m, (size_t)(WS - LS) * MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, ((WS > 0 || RS) ? 3 : 0), LS, RS>::WSE * sizeof(double));
   MTG_DL_ANY_LIST(MTG_X)
 #undef MTG_X
   return m;

@@ -53,19 +53,24 @@ int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, i
 #endif
 }  // namespace
 
-#define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, (WS > 0 ? DL : 0), LS>
-#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS)                                                              \
-  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>(),    \
-   (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::LSJ) *           \
-       MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS)::WSE * sizeof(double),                                                   \
-   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP>,                                                         \
-   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS), DL, NP)},
-#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0)
+// MTG_DLR: as MTG_DLW with the register steps' G shared between the dimension lanes as well (MtgCfg::kRegShared)
+#define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, ((WS > 0 || RS) ? DL : 0), LS, RS>
+#define MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, RS)                                                              \
+  {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP>(),    \
+   (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::LSJ) *           \
+       MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSE * sizeof(double),                                                   \
+   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP>,                                                         \
+   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP)},
+#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 0)
+#define MTG_DLR(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 1)
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0, 0)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include MTG_DL_TABLE_INC
 };
 #undef MTG_DL
 #undef MTG_DLW
+#undef MTG_DLR
+#undef MTG_DLX
 #undef MTG_DLCFG
 #undef MTG_DL_QUEUE_FN
 

@@ -78,7 +78,7 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
-template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0>
+template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0, int RS_ = 0>
 struct MtgCfg {
   // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
   // instantiations carry that code
@@ -113,6 +113,11 @@ struct MtgCfg {
   static constexpr int LSJ = (kStatic && DLW_ > 0) ? LS_ : 0;
   static constexpr int WSE = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
+  // RS_ != 0 (with DLW_): the REGISTER steps keep G shared as well -- lane of dimension k holds elements k, DLW + k, ... of
+  // G (GROWS doubles instead of up to H * H) and fetches its siblings' elements with ds_bpermute at back-substitution time
+  // (the three lanes of a trajectory compute identical G): half the registers per step, i.e. twice the steps on chip.
+  static constexpr bool kRegShared = kStatic && DLW_ > 0 && RS_ != 0;
+  static constexpr int GROWS = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW : 1;
   static constexpr int FULL = (1 << H_) - 1;
   // static mode: fixed-slot column prefix and the column range each direction touches
   static constexpr int offF(int v) { return v == 0 ? 0 : popc(MS_) + (v - 1) * popc(MI_); }
@@ -233,7 +238,8 @@ template <int DIR> MTG_HD int mtg_vr(int K, int j) { return DIR > 0 ? j + 1 : K 
 
 template <class C>
 struct MtgLane {
-  double G[C::KREG][C::H][C::H];  // G_v = Dtilde_v^-1 U_v          (static mode: registers; steps >= C::WSJ)
+  double G[C::kRegShared ? 1 : C::KREG][C::H][C::H];  // G_v = Dtilde_v^-1 U_v          (static mode: registers; steps >= C::WSJ)
+  double Gs[C::kRegShared ? C::KREG : 1][C::kRegShared ? C::GROWS : 1];   // MtgCfg::kRegShared: this lane's share of G_v
   double g[C::KREG][C::D][C::H];  // g_v = Dtilde_v^-1 rtilde_v
   double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
   double rc[C::D][C::H];          // its right-hand side
@@ -1036,6 +1042,56 @@ MTG_HD void mtg_ws_load_shared(PTR w, long long stride, long long share, double 
   }
 }
 
+// MtgCfg::kRegShared: register steps.  pack: this dimension lane's share of G (row r = elements DLW r .. DLW r + DLW - 1 in
+// traversal order, element DLW r + k kept by the lane of dimension k).  unpack: all elements back, element DLW r + k from
+// the sibling lane of dimension k (byte address perm[k] = 4 * that lane) -- a ds_bpermute pair per double, no LDS memory.
+template <class C>
+MTG_HD void mtg_rs_pack(int d, const double (&G)[C::H][C::H], int ml, int mr, double (&Gs)[C::kRegShared ? C::GROWS : 1]) {
+  constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1;
+  double cand[DL];
+  int cnt = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    if ((ml >> p) & 1) continue;
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      if ((mr >> q) & 1) continue;
+      cand[cnt % DL] = G[p][q];
+      ++cnt;
+      if (cnt % DL == 0) Gs[cnt / DL - 1] = mtg_pick<DL>(d, cand);
+    }
+  }
+  if (cnt % DL != 0) {   // last, partial row: the lanes beyond it keep a duplicate that is never read
+#pragma unroll
+    for (int k = 1; k < DL; ++k)
+      if (k >= cnt % DL) cand[k] = cand[0];
+    Gs[cnt / DL] = mtg_pick<DL>(d, cand);
+  }
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double mtg_bperm(int addr, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <class C>
+__device__ __forceinline__ void mtg_rs_unpack(const int (&perm)[C::DLW > 0 ? C::DLW : 1], const double (&Gs)[C::kRegShared ? C::GROWS : 1],
+                                              int ml, int mr, double (&G)[C::H][C::H]) {
+  constexpr int H = C::H, DL = C::DLW > 0 ? C::DLW : 1;
+  int cnt = 0;
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      G[p][q] = 0.0;
+      if (((ml >> p) & 1) || ((mr >> q) & 1)) continue;
+      G[p][q] = mtg_bperm(perm[cnt % DL], Gs[cnt / DL]);
+      ++cnt;
+    }
+  }
+}
+#endif
+
 // ---- whole-lane phases -----------------------------------------------------------------
 // wsl: this lane's slab of the generic-mode workspace (element stride P.ws_stride)
 // do_preload = false: the caller already filled ln.T / ln.fx (the kernel prefetches the next tile's inputs
@@ -1087,6 +1143,11 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
         } else {
           mtg_ws_store<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, G, g, ml, mr);
         }
+      } else if constexpr (C::kRegShared) {
+        constexpr int JR0 = C::WSJ;
+        double G[H][H];
+        mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, ln.g[j < JR0 ? 0 : j - JR0]);
+        mtg_rs_pack<C>(P.dim0, G, ml, mr, ln.Gs[j < JR0 ? 0 : j - JR0]);
       } else {
         constexpr int JR0 = C::WSJ;
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, ln.G[j < JR0 ? 0 : j - JR0], ln.g[j < JR0 ? 0 : j - JR0]);
@@ -1163,7 +1224,23 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
     // steps below C::WSJ: (G, g) come back from the workspace, requested one step ahead -- right after the previous
     // step's back-substitution and BEFORE its coefficient stores (loads and stores retire through one in-order counter)
     double Gw[H][H], gw[D][H];
+    [[maybe_unused]] int perm[C::DLW > 0 ? C::DLW : 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (C::kRegShared) {   // byte addresses (4 * lane) of this trajectory's dimension lanes, for ds_bpermute
+#pragma unroll
+      for (int k = 0; k < C::DLW; ++k) perm[k] = 4 * ((int)(threadIdx.x & 63) + (int)P.ws_share + k * (64 / C::DLW));
+    }
+#endif
     auto request = [&](int j) {
+      if constexpr (C::kRegShared) {
+        if (j >= C::WSJ) {   // register step: G back from the three dimension lanes' shares (g is per lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+          mtg_rs_unpack<C>(perm, ln.Gs[j - C::WSJ < 0 ? 0 : j - C::WSJ], mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
+                           mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)), Gw);
+#endif
+          return;
+        }
+      }
       if constexpr (C::DLW > 0) {
         if (j >= C::WSJ - C::LSJ) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1178,16 +1255,19 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         mtg_ws_load<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
                        mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
     };
-    if (C::WSJ > 0 && KC <= C::WSJ) request(KC - 1);
+    if ((C::WSJ > 0 && KC <= C::WSJ) || C::kRegShared) request(KC - 1);
 #pragma unroll
     for (int j = KC - 1; j >= 0; --j) {
       const int ml = mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j));
-      if constexpr (C::WSJ > 0) {
+      if constexpr (C::WSJ > 0 || C::kRegShared) {
         double fix_l[D][H], xl[D][H];
         mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(C::KT, j), ml, ln, fix_l);
         if (j < C::WSJ) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, gw, xr, xl);
+        else if constexpr (C::kRegShared) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, ln.g[j - C::WSJ < 0 ? 0 : j - C::WSJ], xr, xl);
         else mtg_bwd_backsub<C>(ml, mr, fix_l, ln.G[j - C::WSJ < 0 ? 0 : j - C::WSJ], ln.g[j - C::WSJ < 0 ? 0 : j - C::WSJ], xr, xl);
-        if (j >= 1 && j - 1 < C::WSJ) request(j - 1);
+        // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
+        // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
+        if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
       } else {
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);

@@ -183,3 +183,105 @@ def test_integration_binding_on_the_reference_class(mode):
         pytest.skip("tests/cpp/test_reference_binding not built (needs /root/reference at build time)")
     r = subprocess.run([exe] + (["device"] if mode == "device" else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REFERENCE BINDING OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ---- the kernels the bench times, directly against the compiled reference -----------------------
+# test_hip_vs_live_reference_on_fresh_batches asks for d_free and cost, which excludes the dimension-in-lane, slab-output,
+# queue and cross-structure forms (coefficient output only).  Here: coefficient-only calls of exactly those forms on fresh
+# 2000-trajectory batches of BASELINE configs 2 / 3 (same shape), 5 and the twelve config-4 buckets.
+def coeff_only(ctx, n, d, masks, times, d_fixed, dims):
+    import torch
+    import mav_trajectory_generation_amd as m
+    dim, k = d_fixed.shape[1], times.shape[1]
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t = torch.from_numpy(np.ascontiguousarray(times)).cuda().t().contiguous()
+    f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda().permute(1, 2, 0).contiguous()
+    form = plan.launch_form(times.shape[0], "soa", dims)
+    co, _, _ = plan.solve(t, f, layout="soa", dims=dims)
+    ctx.sync()
+    out = co.cpu().numpy()
+    plan.close()
+    return out, form
+
+
+CONFIG4 = [(n, n // 2 - 1, k) for n in (8, 10, 12) for k in (4, 8, 16, 32)]
+
+
+def assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c):
+    """N <= 10: the north-star tolerance, 1e-9 norm-wise per polynomial.  N = 12: float64 evaluation of the reference's own
+    formulas (cond(A) up to 1e17) is only ~1e-8 .. 1e-7 from the exact solution, so two correct float64 results differ by
+    that much; the bound is 5e-7, and on the worst trajectory the 50-digit solve (oracle/oracle_mp.py) must put the HIP
+    result at least 100x closer to the truth than the reference is (i.e. the reference is the side that is off)."""
+    per_traj = np.array([helpers.poly_relerr(co[b:b + 1], ref_c[b:b + 1]) for b in range(co.shape[0])])
+    if n <= 10:
+        assert per_traj.max() < 1e-9
+        return
+    assert per_traj.max() < 5e-7
+    if len(masks) - 1 > 8:      # (a dense 50-digit solve of a 16 / 32-segment chain takes minutes: short chains arbitrate)
+        return
+    from oracle import oracle_mp
+    b = int(per_traj.argmax())
+    truth, _, _ = oracle_mp.solve(n, d, masks, times[b], d_fixed[b])
+    truth = np.asarray(truth, dtype=np.float64)[None]
+    e_hip, e_ref = helpers.poly_relerr(co[b:b + 1], truth), helpers.poly_relerr(ref_c[b:b + 1], truth)
+    assert e_hip < 1e-10 and e_hip * 100 < max(e_ref, 1e-12), (e_hip, e_ref)
+
+
+@live
+@pytest.mark.parametrize("n,d,k,dim,interior,dims,want_form", [
+    (10, 4, 8, 3, 1, "dimlane", "dimlane"), (10, 4, 8, 3, 1, "fused", "slab"),         # configs 2 / 3: the bench kernels
+    (10, 4, 16, 4, 7, "dimlane", "dimlane"), (10, 4, 16, 4, 7, "auto", "dimlane"),     # config 5
+] + [(n, d, k, 3, 1, "dimlane", "dimlane") for (n, d, k) in CONFIG4]                     # config 4 buckets
+  + [(n, d, k, 3, 1, "fused", "slab") for (n, d, k) in ((8, 3, 4), (8, 3, 8), (10, 4, 4), (12, 5, 4))])
+def test_bench_kernels_vs_live_reference(ctx, n, d, k, dim, interior, dims, want_form):
+    import mav_trajectory_generation_amd as m
+    bsz = 2000 if k <= 16 else 600
+    masks = m.ends_full_masks(n, k, interior)
+    masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 31415 + 7 * k + n, masks)
+    ref_c, _, _, _ = ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())
+    co, form = coeff_only(ctx, n, d, masks, times, d_fixed, dims)
+    assert form == want_form
+    assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c)
+
+
+@live
+def test_queue_and_cross_structure_launches_vs_live_reference(ctx):
+    """mtg_solve_linear_sequence's persistent queue launch (config 2 shape: the bench's `value` kernel; config 5 shape: the
+    dimension-in-lane queue) and mtg_multi_solve's cross-structure launch over the twelve config-4 buckets."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    for (n, d, k, dim, interior) in ((10, 4, 8, 3, 1), (10, 4, 16, 4, 7)):
+        masks = m.ends_full_masks(n, k, interior)
+        plan = m.Plan(ctx, n, dim, k, d, masks)
+        sets, refs = [], []
+        for s in range(3):
+            _, times, d_fixed = helpers.reference_batch(2000, k, n, dim, 2718 + s, masks)
+            refs.append(ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())[0])
+            t = torch.from_numpy(np.ascontiguousarray(times)).cuda().t().contiguous()
+            f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda().permute(1, 2, 0).contiguous()
+            sets.append((t, f, torch.zeros((2000, k, dim, n), dtype=torch.float64, device="cuda")))
+        plan.solve_sequence(sets, layout="soa")
+        ctx.sync()
+        for (_, _, co), ref_c in zip(sets, refs):
+            assert helpers.poly_relerr(co.cpu().numpy(), ref_c) < 1e-9
+        plan.close()
+    buckets, refs, inputs = [], [], {}
+    for (n, d, k) in CONFIG4:
+        bsz = 2000 if k <= 16 else 600
+        masks = m.ends_full_masks(n, k, 1)
+        _, times, d_fixed = helpers.reference_batch(bsz, k, n, 3, 1618 + k + n, masks)
+        refs.append(ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())[0])
+        inputs[(n, k)] = (times, d_fixed)
+        t = torch.from_numpy(np.ascontiguousarray(times)).cuda().t().contiguous()
+        f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda().permute(1, 2, 0).contiguous()
+        buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
+    solver = m.MixedBatchSolver(ctx, n_streams=1)
+    req = solver.merged(buckets)
+    assert req.launch_count == 1          # ONE cross-structure dimension-in-lane launch (mtg_solve_dl_any_kernel)
+    out = req.solve()
+    torch.cuda.synchronize()
+    solver.sync()
+    for (n, d, k), (co, _), ref_c in zip(CONFIG4, out, refs):
+        assert_close_to_reference(n, d, masks, *inputs[(n, k)], co.cpu().numpy(), ref_c)
+    req.close()
+    solver.close()

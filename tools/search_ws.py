@@ -17,10 +17,10 @@ LDS_STEPS = {4: 8, 5: 5, 6: 3}                                          # steps 
 REG_STEPS = {4: 9, 5: 6, 6: 2}                                          # where the search starts (steps the registers hold)
 
 
-def resources(H, K, WS, LS):
+def resources(H, K, WS, LS, RS=0, full=False):
     ms, mi, me, dv = SHAPES[H]
-    cfg = f"MtgCfg<{H},1,{K},{ms},{mi},{me},{dv},0,{WS},{3 if WS > 0 else 0},{LS}>"
-    src = f"/tmp/search_ws_{H}_{K}_{WS}.hip"
+    cfg = f"MtgCfg<{H},1,{K},{ms},{mi},{me},{dv},0,{WS},{3 if (WS > 0 or RS) else 0},{LS},{RS}>"
+    src = f"/tmp/search_ws_{H}_{K}_{WS}_{LS}_{RS}.hip"
     with open(src, "w") as f:
         f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<' + cfg +
                 ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, double*);\n')
@@ -32,6 +32,10 @@ def resources(H, K, WS, LS):
         return None
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", p.stderr).group(1))
     spills = int(re.search(r"VGPRs Spill: (\d+)", p.stderr).group(1))
+    if full:
+        return dict(scratch=scratch, spills=spills, vgpr=int(re.search(r" VGPRs: (\d+)", p.stderr).group(1)),
+                    agpr=int(re.search(r"AGPRs: (\d+)", p.stderr).group(1)), sgpr_spill=int(re.search(r"SGPRs Spill: (\d+)", p.stderr).group(1)),
+                    lds=int(re.search(r"LDS Size \[bytes/block\]: (\d+)", p.stderr).group(1)))
     return scratch, spills
 
 
@@ -47,6 +51,15 @@ def best(H, K):
             return f"MTG_DLW({H}, {K}, {ms}, {mi}, {me}, {dv}, 3, {2 if K <= 8 else 1}, 0, 0, {WS}, {LS})   // spilled VGPRs: {r[1]}"
     return f"// H={H} K={K}: no setting without scratch"
 
+
+if __name__ == "__main__" and sys.argv[1] == "probe":
+    # python tools/search_ws.py probe H K WS LS RS [WS LS RS ...]: resource usage of explicit settings
+    H, K = int(sys.argv[2]), int(sys.argv[3])
+    trip = [tuple(int(x) for x in sys.argv[i:i + 3]) for i in range(4, len(sys.argv), 3)]
+    with cf.ThreadPoolExecutor(max(1, (os.cpu_count() or 2) - 1)) as ex:
+        for t, r in zip(trip, ex.map(lambda a: resources(H, K, a[0], a[1], a[2], True), trip)):
+            print(f"H={H} K={K} WS={t[0]} LS={t[1]} RS={t[2]}: {r}", flush=True)
+    sys.exit(0)
 
 if __name__ == "__main__":
     k0, k1 = int(sys.argv[1]), int(sys.argv[2])
