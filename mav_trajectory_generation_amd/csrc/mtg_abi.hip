@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <queue>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -108,6 +110,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
+  bool knob_dl_any_rr = false;       // MTG_DL_ANY_SCHED=rr: round 2's unit schedule of the cross-structure launch
   bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
@@ -253,6 +256,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
+  if (const char* e = getenv("MTG_DL_ANY_SCHED")) ctx->knob_dl_any_rr = std::string(e) == "rr";
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
@@ -968,6 +972,7 @@ struct MtgDlAnyGroup {                      // cross-structure dimension-in-lane
   std::vector<int> items;
   MtgDlAnyItem* d_items = nullptr;
   MtgDlAnyUnit* d_units = nullptr;
+  int* d_wg_begin = nullptr;                // [grid + 1]: workgroup w runs d_units[d_wg_begin[w] .. d_wg_begin[w + 1])
   double* d_ws = nullptr;
   int nunits = 0, grid = 0;
 };
@@ -988,6 +993,7 @@ int mtg_multi_destroy(mtg_multi* m) {
   hipStreamSynchronize(m->ctx->stream);
   if (m->dl_any.d_items) hipFree(m->dl_any.d_items);
   if (m->dl_any.d_units) hipFree(m->dl_any.d_units);
+  if (m->dl_any.d_wg_begin) hipFree(m->dl_any.d_wg_begin);
   if (m->dl_any.d_ws) hipFree(m->dl_any.d_ws);
   for (MtgMultiGroup& g : m->groups) {
     if (g.d_table) hipFree(g.d_table);
@@ -1089,17 +1095,46 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
       }
       g.nunits = (int)units.size();
       g.grid = std::min(g.nunits, ctx->n_cu * 2);      // two 2-wave workgroups per CU: one wave per SIMD
-      // workgroup w takes units w, w + grid, w + 2 grid, ...: every second round is reversed, so the workgroups that started
-      // with the longest chains continue with the shortest ones of the next round
-      for (size_t r = 1; r * (size_t)g.grid < units.size(); r += 2) {
-        const size_t lo = r * (size_t)g.grid, hi = std::min(units.size(), lo + (size_t)g.grid);
-        if (hi - lo == (size_t)g.grid) std::reverse(units.begin() + lo, units.begin() + hi);
+      // Every workgroup gets its own unit list.  Default: greedy longest-processing-time assignment (units in order of
+      // decreasing cost, each to the least-loaded workgroup; ties -> the lowest index, so the first `grid` units land on
+      // workgroups 0, 1, 2, ... and neighbours start with the same configuration).  Cost model from the per-bucket kernel
+      // times (profiles/r03b_configs.jsonl): ~0.03 us x K x (N/2)^2 + ~2.5 us per unit.  MTG_DL_ANY_SCHED=rr: round 2's
+      // schedule (units w, w + grid, ... of the sorted list, every second round reversed).
+      std::vector<std::vector<MtgDlAnyUnit>> lists(g.grid);
+      if (ctx->knob_dl_any_rr) {
+        for (size_t r = 0; r * (size_t)g.grid < units.size(); ++r) {
+          const size_t lo = r * (size_t)g.grid, hi = std::min(units.size(), lo + (size_t)g.grid);
+          const bool rev = (r & 1) && hi - lo == (size_t)g.grid;
+          for (size_t u = lo; u < hi; ++u) lists[rev ? (hi - 1 - u) : (u - lo)].push_back(units[u]);
+        }
+      } else {
+        auto cost = [&](const MtgDlAnyUnit& u) {
+          const mtg_plan* pl = items[cand[u.item]].plan;
+          return (long long)pl->K * pl->H * pl->H + 90;
+        };
+        typedef std::pair<long long, int> Load;      // (load, workgroup): min-heap
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int w = 0; w < g.grid; ++w) heap.push(Load(0, w));
+        for (const MtgDlAnyUnit& u : units) {          // `units` is sorted by decreasing work already
+          Load l = heap.top();
+          heap.pop();
+          lists[l.second].push_back(u);
+          heap.push(Load(l.first + cost(u), l.second));
+        }
+      }
+      std::vector<int> wg_begin(g.grid + 1, 0);
+      units.clear();
+      for (int w = 0; w < g.grid; ++w) {
+        units.insert(units.end(), lists[w].begin(), lists[w].end());
+        wg_begin[w + 1] = (int)units.size();
       }
       const size_t ws_bytes = std::max<size_t>(16, mtg_dl_any_ws_per_lane() * (size_t)g.grid * 2 * kWave);
       if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
           hipMalloc((void**)&g.d_items, table.size() * sizeof(MtgDlAnyItem)) != hipSuccess ||
           hipMalloc((void**)&g.d_units, units.size() * sizeof(MtgDlAnyUnit)) != hipSuccess ||
           hipMemcpy(g.d_items, table.data(), table.size() * sizeof(MtgDlAnyItem), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMalloc((void**)&g.d_wg_begin, wg_begin.size() * sizeof(int)) != hipSuccess ||
+          hipMemcpy(g.d_wg_begin, wg_begin.data(), wg_begin.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
           hipMemcpy(g.d_units, units.data(), units.size() * sizeof(MtgDlAnyUnit), hipMemcpyHostToDevice) != hipSuccess) {
         mtg_multi_destroy(m);
         return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: device allocation failed");
@@ -1245,7 +1280,7 @@ int mtg_multi_solve(mtg_multi* m) {
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (m->dl_any.nunits > 0) {
       const MtgDlAnyGroup& g = m->dl_any;
-      if (mtg_dl_any_launch((void*)ctx->stream, g.grid, g.d_items, g.d_units, g.nunits, ctx->d_status, g.d_ws) != 0)
+      if (mtg_dl_any_launch((void*)ctx->stream, g.grid, g.d_items, g.d_units, g.d_wg_begin, ctx->d_status, g.d_ws) != 0)
         return set_err(ctx, MTG_ERR_DEVICE, "cross-structure dimension-in-lane launch set-up failed");
     }
     for (MtgMultiGroup& g : m->groups) {

@@ -336,18 +336,21 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   X(10, 6, 16, 63, 1, 63, 5, 4, 3, 1)     \
   X(11, 6, 32, 63, 1, 63, 5, 15, 3, 0)
 
-// Units are sorted longest-chain-first by the host; persistent workgroups take them with stride gridDim.x, so neighbouring
-// workgroups (same CU, same instruction cache) run the same configuration's code at about the same time.  (Measured and
-// rejected: a global unit counter, i.e. dynamic longest-first scheduling -- 81 us against 71 us for config 4 at 30k: the
-// bodies are straight-line code of 100-300 KB each, and workgroups that drift apart stop sharing instruction fetches.)
+// The host hands every persistent workgroup its own list of units (wg_begin[w] .. wg_begin[w + 1] of `units`), longest chains
+// first: a greedy longest-processing-time assignment over the workgroups with a per-configuration cost estimate, so that no
+// workgroup is left with a long chain at the end (round 2 took units w, w + grid, ... of the sorted list: the workgroups that
+// started with the 37-us chains of N = 12 / K = 32 still got two more units each).  The first unit of neighbouring workgroups
+// (same CU, same instruction cache) has the same configuration.  (Measured and rejected in round 2: a global unit counter,
+// i.e. dynamic scheduling -- 81 us against 71 us for config 4 at 30k.)
 template <int AUX>
 __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_any_kernel(const MtgDlAnyItem* __restrict__ items,
-                                                                      const MtgDlAnyUnit* __restrict__ units, int nunits,
-                                                                      int* status, double* ws) {
+                                                                      const MtgDlAnyUnit* __restrict__ units,
+                                                                      const int* __restrict__ wg_begin, int* status, double* ws) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   double* wsl0 = ws + (size_t)blockIdx.x * (2 * kWave) + threadIdx.x;
   const long long ws_stride = (long long)gridDim.x * (2 * kWave);
-  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+  const int u1 = wg_begin[blockIdx.x + 1];
+  for (int u = wg_begin[blockIdx.x]; u < u1; ++u) {
     const MtgDlAnyUnit un = units[u];
     const MtgDlAnyItem it = items[un.item];
     switch (__builtin_amdgcn_readfirstlane(it.cfg)) {

@@ -55,8 +55,8 @@ size_t mtg_dl_any_ws_per_lane() {
 #undef MTG_X
   return m;
 }
-int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, int nunits, int* status,
-                      double* ws) {
+int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, const int* wg_begin,
+                      int* status, double* ws) {
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
@@ -66,6 +66,6 @@ int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const M
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, items, units, nunits, status, ws);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, items, units, wg_begin, status, ws);
   return 0;
 }

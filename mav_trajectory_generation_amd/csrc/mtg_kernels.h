@@ -492,7 +492,8 @@ struct MtgDlAnyUnit { int item, tile; };
 int mtg_dl_any_index(const MtgDimlaneEntry* e);     // configuration index of a 3-dimensional variant, or -1
 size_t mtg_dl_any_lds_bytes();
 size_t mtg_dl_any_ws_per_lane();
-int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, int nunits, int* status,
-                      double* ws);
+// wg_begin: [grid + 1] offsets into `units` -- workgroup w runs units[wg_begin[w] .. wg_begin[w + 1])
+int mtg_dl_any_launch(void* stream, int grid, const MtgDlAnyItem* items, const MtgDlAnyUnit* units, const int* wg_begin,
+                      int* status, double* ws);
 
 #endif  // MTG_KERNELS_H_

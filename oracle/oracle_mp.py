@@ -66,14 +66,13 @@ def solve(n_coeffs: int, derivative: int, fixed_mask: Sequence[int], times, d_fi
     nf, npf = len(fixed_keys), len(free_keys)
     col_of = {key: i for i, key in enumerate(fixed_keys)}
     col_of.update({key: nf + i for i, key in enumerate(free_keys)})
-    # M (LIN:182-260): row i*N + p -> (vertex i, p); row i*N + h + p -> (vertex i+1, p)
-    m = mp.zeros(n * k, nf + npf)
-    for i in range(k):
-        for p in range(h):
-            m[i * n + p, col_of[(i, p)]] = 1
-            m[i * n + h + p, col_of[(i + 1, p)]] = 1
+    # M (LIN:182-260) is a 0/1 selection matrix: row i*N + p -> column of (vertex i, p); row i*N + h + p -> column of
+    # (vertex i+1, p).  R = M^T blkdiag(H_i) M (LIN:334-335) is therefore the scatter-add of the segments' H_i onto the
+    # columns of their two vertices, and M[iN:(i+1)N, :] d_all (LIN:274-275) a gather -- the same numbers as the dense
+    # products (exact arithmetic on 0/1 entries), without two (N K)^2 x (n_f + n_p) multiplications at 50 digits.
+    cols = [[col_of[(i, p)] for p in range(h)] + [col_of[(i + 1, p)] for p in range(h)] for i in range(k)]
     ainvs, qs = [], []
-    big = mp.zeros(n * k, n * k)
+    r_full = mp.zeros(nf + npf, nf + npf)
     for i in range(k):
         a = mapping_matrix(n, float(times[i]))
         ai = a ** -1
@@ -83,24 +82,28 @@ def solve(n_coeffs: int, derivative: int, fixed_mask: Sequence[int], times, d_fi
         qs.append(q)
         for r in range(n):
             for c in range(n):
-                big[i * n + r, i * n + c] = hm[r, c]
-    r_full = m.T * big * m
+                r_full[cols[i][r], cols[i][c]] += hm[r, c]
     coeffs = np.zeros((k, dim, n))
     d_free = np.zeros((dim, npf))
     cost = mp.mpf(0)
     if npf:
         rpf = r_full[nf:, :nf]
         rpp = r_full[nf:, nf:]
+        lu = mp.matrix(rpp)     # one factorisation for all dimensions (as the reference shares its QR, LIN:365-375)
+        lu_a, lu_p = mp.mp.LU_decomp(lu)
     for d in range(dim):
         df = mp.matrix([mp.mpf(float(x)) for x in d_fixed[d]])
         if npf:
-            dp = mp.lu_solve(rpp, -(rpf * df))
-            d_all = mp.matrix(list(df) + list(dp))
+            rhs = -(rpf * df)
+            # forward / backward substitution with the shared LU factors (mpmath's own helpers)
+            y = mp.mp.L_solve(lu_a, rhs, lu_p)
+            dp = mp.mp.U_solve(lu_a, y)
+            d_all = list(df) + list(dp)
             d_free[d] = [float(x) for x in dp]
         else:
-            d_all = df
+            d_all = list(df)
         for i in range(k):
-            new_d = m[i * n:(i + 1) * n, :] * d_all
+            new_d = mp.matrix([d_all[cidx] for cidx in cols[i]])
             c = ainvs[i] * new_d
             coeffs[i, d] = [float(x) for x in c]
             cost += (c.T * qs[i] * c)[0, 0]

@@ -209,22 +209,22 @@ CONFIG4 = [(n, n // 2 - 1, k) for n in (8, 10, 12) for k in (4, 8, 16, 32)]
 
 def assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c):
     """N <= 10: the north-star tolerance, 1e-9 norm-wise per polynomial.  N = 12: float64 evaluation of the reference's own
-    formulas (cond(A) up to 1e17) is only ~1e-8 .. 1e-7 from the exact solution, so two correct float64 results differ by
-    that much; the bound is 5e-7, and on the worst trajectory the 50-digit solve (oracle/oracle_mp.py) must put the HIP
-    result at least 100x closer to the truth than the reference is (i.e. the reference is the side that is off)."""
+    formulas (cond(A) up to 1e17) is only ~1e-8 .. 1e-6 from the exact solution on some trajectories of a 2000-trajectory
+    batch (observed: 1.2e-6 at K = 16), so two correct float64 results differ by that much.  There the check is: median
+    difference < 1e-8, no trajectory beyond 1e-5, and on the three WORST trajectories the 50-digit solve
+    (oracle/oracle_mp.py) must put the HIP result within 1e-10 of the truth and at least 100x closer to it than the
+    reference is (i.e. the reference is the side that is off)."""
     per_traj = np.array([helpers.poly_relerr(co[b:b + 1], ref_c[b:b + 1]) for b in range(co.shape[0])])
     if n <= 10:
         assert per_traj.max() < 1e-9
         return
-    assert per_traj.max() < 5e-7
-    if len(masks) - 1 > 8:      # (a dense 50-digit solve of a 16 / 32-segment chain takes minutes: short chains arbitrate)
-        return
+    assert np.median(per_traj) < 1e-8 and per_traj.max() < 1e-5
     from oracle import oracle_mp
-    b = int(per_traj.argmax())
-    truth, _, _ = oracle_mp.solve(n, d, masks, times[b], d_fixed[b])
-    truth = np.asarray(truth, dtype=np.float64)[None]
-    e_hip, e_ref = helpers.poly_relerr(co[b:b + 1], truth), helpers.poly_relerr(ref_c[b:b + 1], truth)
-    assert e_hip < 1e-10 and e_hip * 100 < max(e_ref, 1e-12), (e_hip, e_ref)
+    for b in np.argsort(per_traj)[-3:]:
+        truth, _, _ = oracle_mp.solve(n, d, masks, times[b], d_fixed[b])
+        truth = np.asarray(truth, dtype=np.float64)[None]
+        e_hip, e_ref = helpers.poly_relerr(co[b:b + 1], truth), helpers.poly_relerr(ref_c[b:b + 1], truth)
+        assert e_hip < 1e-10 and e_hip * 100 < max(e_ref, 1e-12), (int(b), e_hip, e_ref)
 
 
 @live
