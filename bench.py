@@ -19,7 +19,8 @@ the coefficients, chunked so that chunk i's gather overlaps chunk i+1's solve  =
 the metric is quoted on], 3 = 125k of the same (1M over 8 GPUs), 4 = the mixed request (N in {8, 10, 12} x K in {4, 8, 16,
 32}, D = 3: 12 buckets x 2500 = 30k trajectories per step, ONE cross-structure launch per step through mtg_multi_solve),
 5 = 12.5k x (K=16, N=10, D=4, velocity + acceleration fixed at interior vertices; 100k over 8 GPUs).
-`--next` adds the SURVEY 8(f) rows (sampling, extrema / time scaling, Mellinger cost + gradient) as `extra.next`.
+The default run (config 2) also times the SURVEY 8(f) rows -- sampling, extrema / time scaling, Mellinger cost + gradient --
+as `extra.next` (`--no-next` skips them).
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (8*(K + D*n_fixed + K*D*N) per
 trajectory) of the timed steps / their duration on the device, measured with HIP events recorded by the library on the
@@ -70,8 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--sequence", default="queue", choices=["queue", "launches"],
                     help="how the library runs the K independent batches of the timed region: 'queue' = one persistent launch "
                          "over all of them (throughput form), 'launches' = one kernel launch per batch (latency form)")
-    ap.add_argument("--next", action="store_true", help="also time the SURVEY 8(f) rows: sampling, extrema / time scaling, "
-                                                        "Mellinger cost + gradient (extra.next)")
+    ap.add_argument("--no-next", action="store_true", help="skip the SURVEY 8(f) rows (sampling, extrema / time scaling, "
+                                                           "Mellinger cost + gradient: extra.next, config 2 only)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (profiling runs: the kernel statistics then cover the same launches as the metric)")
     return ap.parse_args(argv)
@@ -437,7 +438,7 @@ def main():
                                               "GBps": bigb * plan.bytes_per_trajectory / us * 1e-3,
                                               "frac_of_8TBps": bigb * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
                     del tb, fb, cb
-            if args.next:
+            if args.config == 2 and not args.no_next:
                 extra["next"] = next_rows(m, ctx, plan, sets, B, K, D, N)
         if args.extra and rank == 0 and args.config == 2:
             # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value.

@@ -13,8 +13,10 @@
 // object owns only host data plus a shared, immutable plan handle; device scratch lives in a per-thread context.
 #ifndef MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
 #define MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <memory>
 #include <string>
 #include <numeric>
@@ -180,13 +182,93 @@ class PolynomialOptimization {
     segment_times_ = segment_times;
   }
 
-  // Returns false (instead of the reference's unconditional true) when the free-constraint system is rank deficient:
-  // the reference's rank-revealing SparseQR (LIN:365-367) still returns a basic solution there, the LDL^T solve on the
-  // device does not -- the segments are left untouched ("behaviour differences").
+  // Always returns true, like the reference (LIN:339-379).  A rank-deficient free-constraint system (under-constrained
+  // problems: e.g. one segment with only the end positions fixed -- any cubic through them has zero snap) makes the
+  // library's LDL^T sweep report MTG_ERR_SINGULAR; the reference's rank-revealing SparseQR (LIN:365-367) returns a BASIC
+  // solution there, and so does solveLinearBasic() below (a column-pivoted Householder QR of the dense R_PP on the host:
+  // such problems are tiny and rare).  The minimum cost is unique; the basic solution is not (free variables beyond the
+  // numerical rank are zero, and WHICH ones depends on the column order: Eigen processes COLAMD order, this code pivots by
+  // column norm), so coefficients may differ from the reference's while cost and all constraints agree.
   bool solveLinear() {
     CHECK(derivative_to_optimize_ >= 0 && derivative_to_optimize_ <= kHighestDerivativeToOptimize);
-    return run(/*solve=*/true) == MTG_OK;
+    const int rc = run(/*solve=*/true);
+    if (rc == MTG_OK) return true;
+    return solveLinearBasic();
   }
+
+  // d_P = basic solution of R_PP d_P = -R_PF d_F (LIN:360-375 with a rank-revealing factorisation), then the
+  // setFreeConstraints path (LIN:263-283) for the coefficients.  Rank threshold as in Eigen's SparseQR::factorize:
+  // 20 * (rows + cols) * (largest column norm) * epsilon.
+  bool solveLinearBasic() {
+    const size_t nf = n_fixed_constraints_, np = n_free_constraints_;
+    if (np == 0) return run(/*solve=*/false) == MTG_OK;
+    Eigen::MatrixXd R;
+    getR(&R);
+    std::vector<double> A(np * np);                       // R_PP, column-major
+    for (size_t c = 0; c < np; ++c) for (size_t r = 0; r < np; ++r) A[c * np + r] = R(nf + r, nf + c);
+    std::vector<std::vector<double>> rhs(dimension_, std::vector<double>(np, 0.0));
+    for (size_t d = 0; d < dimension_; ++d)
+      for (size_t r = 0; r < np; ++r) {
+        double acc = 0.0;
+        for (size_t c = 0; c < nf; ++c) acc += R(nf + r, c) * fixed_constraints_compact_[d][c];
+        rhs[d][r] = -acc;
+      }
+    // Householder QR with column pivoting (Businger-Golub), reflectors applied to the right-hand sides on the fly
+    std::vector<size_t> perm(np);
+    std::iota(perm.begin(), perm.end(), (size_t)0);
+    std::vector<double> cn(np);
+    double max_norm = 0.0;
+    for (size_t c = 0; c < np; ++c) {
+      double s2 = 0.0;
+      for (size_t r = 0; r < np; ++r) s2 += A[c * np + r] * A[c * np + r];
+      cn[c] = s2;
+      max_norm = std::max(max_norm, std::sqrt(s2));
+    }
+    const double threshold = 20.0 * double(2 * np) * max_norm * std::numeric_limits<double>::epsilon();
+    size_t rank = 0;
+    std::vector<double> v(np);
+    for (size_t k = 0; k < np; ++k) {
+      size_t piv = k;
+      for (size_t c = k; c < np; ++c) {                   // remaining column norms, recomputed (tiny matrices)
+        double s2 = 0.0;
+        for (size_t r = k; r < np; ++r) s2 += A[c * np + r] * A[c * np + r];
+        cn[c] = s2;
+        if (s2 > cn[piv]) piv = c;
+      }
+      if (std::sqrt(cn[piv]) <= threshold) break;         // every remaining column is numerically dependent
+      if (piv != k) {
+        for (size_t r = 0; r < np; ++r) std::swap(A[k * np + r], A[piv * np + r]);
+        std::swap(perm[k], perm[piv]);
+      }
+      const double alpha = A[k * np + k] > 0.0 ? -std::sqrt(cn[piv]) : std::sqrt(cn[piv]);
+      double vnorm2 = 0.0;
+      for (size_t r = k; r < np; ++r) { v[r] = A[k * np + r]; if (r == k) v[r] -= alpha; vnorm2 += v[r] * v[r]; }
+      if (vnorm2 > 0.0) {
+        auto reflect = [&](double* x) {
+          double dot = 0.0;
+          for (size_t r = k; r < np; ++r) dot += v[r] * x[r];
+          const double f = 2.0 * dot / vnorm2;
+          for (size_t r = k; r < np; ++r) x[r] -= f * v[r];
+        };
+        for (size_t c = k; c < np; ++c) reflect(&A[c * np]);
+        for (size_t d = 0; d < dimension_; ++d) reflect(rhs[d].data());
+      }
+      ++rank;
+    }
+    for (size_t d = 0; d < dimension_; ++d) {
+      std::vector<double> y(np, 0.0);                      // basic solution: variables beyond the rank stay zero
+      for (size_t i = rank; i-- > 0;) {
+        double acc = rhs[d][i];
+        for (size_t c = i + 1; c < rank; ++c) acc -= A[c * np + i] * y[c];
+        y[i] = acc / A[i * np + i];
+      }
+      for (size_t i = 0; i < np; ++i) free_constraints_compact_[d][perm[i]] = y[i];
+    }
+    last_solve_rank_ = rank;
+    return run(/*solve=*/false) == MTG_OK;
+  }
+  // numerical rank found by the last solveLinearBasic() (n_free when the last solveLinear() went through the device path)
+  size_t getLastSolveRank() const { return last_solve_rank_; }
 
   void setFreeConstraints(const std::vector<Eigen::VectorXd>& free_constraints) {
     CHECK(free_constraints.size() == dimension_);
@@ -434,6 +516,7 @@ class PolynomialOptimization {
     // host-pointer calls are synchronous and return the batch status themselves (on the plan's own context, whichever
     // thread created it)
     if (rc == MTG_ERR_SINGULAR) return rc;
+    if (solve) last_solve_rank_ = np;
     CHECK(rc == MTG_OK) << mtg_status_string(rc);   // LIN:297 CHECK_GT(segment_time, 0) and friends surface here
     for (size_t d = 0; d < D; ++d) {
       if (solve) for (size_t c = 0; c < np; ++c) free_constraints_compact_[d][c] = d_free[d * np + c];
@@ -456,6 +539,7 @@ class PolynomialOptimization {
   size_t dimension_;
   int derivative_to_optimize_;
   size_t n_vertices_, n_segments_, n_all_constraints_, n_fixed_constraints_, n_free_constraints_;
+  size_t last_solve_rank_ = 0;
 };
 
 // Batched entry: B trajectories sharing one constraint structure (masks).  Buffers are flat, AoS:

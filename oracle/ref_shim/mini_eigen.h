@@ -8,11 +8,18 @@
 //
 // What is NOT Eigen's here (stated so nobody mistakes it for the real thing):
 //   * every operation is eager and returns a dynamic matrix (no expression templates, no vectorisation);
-//   * Matrix::inverse() is Gauss-Jordan with partial pivoting for every size (Eigen uses cofactor formulas up to 4x4
-//     and PartialPivLU above);
+//   * Matrix::inverse() follows Eigen's algorithm CLASSES (round 3; Gauss-Jordan before): cofactor formulas (adjugate /
+//     determinant) up to 4x4 -- the N = 8 instantiation's 4x4 block, LIN:171 -- and an unblocked partial-pivoting LU with
+//     column-oriented triangular solves of the identity above (N = 10 / 12: 5x5 / 6x6), but not Eigen's exact operation
+//     order (its vectorised kernels, FMA contraction): equal to round-off x condition number, not bit for bit;
 //   * SparseMatrix is dense-backed; products skip exact zeros and accumulate in index order;
-//   * SparseQR<., COLAMDOrdering> is a Householder QR in natural column order with a diagonal threshold for rank
-//     detection (Eigen: COLAMD column permutation + Householder + pivot threshold).
+//   * SparseQR<., COLAMDOrdering> is Eigen's left-looking column Householder QR on the dense-backed matrix (round 3): the
+//     columns are processed in a fill-reducing order, each column gets the previous reflectors applied, a column whose
+//     remaining norm is below Eigen's default pivot threshold (20 (m + n) max-column-norm eps) is moved to the end (its
+//     solution component is zero: the basic solution).  The column order is an EXACT minimum-degree ordering of the column
+//     intersection graph (ties to the lowest index) where Eigen runs COLAMD (APPROXIMATE minimum degree with supercolumns
+//     and aggressive absorption on the same graph); on the block-tridiagonal R_PP of this path the minimum-degree order is
+//     the natural order up to the last two blocks (tests/test_reference_build.py pins that).
 // All of these are backward-stable evaluations of the same mathematical operations, so results agree with real
 // Eigen to round-off x condition number; nothing in the solveLinear() path depends on more than that.
 // Test infrastructure only (oracle/_ref); never linked into the product library.
@@ -177,36 +184,65 @@ class DenseBase {
     d -= o;
     return d.squaredNorm() <= tol * tol * std::min(squaredNorm(), o.squaredNorm());
   }
-  // Gauss-Jordan with partial pivoting (see header note).
+  // Eigen's algorithm classes (see header note): cofactors up to 4x4, partial-pivoting LU above.
   Dyn inverse() const {
     const Index n = rows();
     assert(n == cols());
-    Dyn a = eval(), inv(n, n);
-    inv.setZero();
-    for (Index i = 0; i < n; ++i) inv(i, i) = T(1);
-    for (Index k = 0; k < n; ++k) {
+    return n <= 4 ? inverse_cofactors() : inverse_partial_piv_lu();
+  }
+  // determinant of the sub-matrix without row `skip_r` and column `skip_c` (sizes 0 .. 3: closed forms)
+  T minor_det(Index skip_r, Index skip_c) const {
+    const Index n = rows() - 1;
+    Index ri[3], ci[3];
+    for (Index i = 0, k = 0; i < rows(); ++i) if (i != skip_r) ri[k++] = i;
+    for (Index j = 0, k = 0; j < cols(); ++j) if (j != skip_c) ci[k++] = j;
+    auto a = [&](Index i, Index j) { return coeff(ri[i], ci[j]); };
+    if (n == 0) return T(1);
+    if (n == 1) return a(0, 0);
+    if (n == 2) return a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+    return a(0, 0) * (a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) - a(0, 1) * (a(1, 0) * a(2, 2) - a(1, 2) * a(2, 0)) +
+           a(0, 2) * (a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0));
+  }
+  Dyn inverse_cofactors() const {
+    const Index n = rows();
+    Dyn inv(n, n);
+    for (Index i = 0; i < n; ++i)
+      for (Index j = 0; j < n; ++j) inv(j, i) = (((i + j) & 1) ? T(-1) : T(1)) * minor_det(i, j);   // adjugate = cofactor^T
+    T det = T(0);
+    for (Index i = 0; i < n; ++i) det += coeff(i, 0) * inv(0, i);   // first column . first row of the adjugate
+    for (Index i = 0; i < n; ++i)
+      for (Index j = 0; j < n; ++j) inv(i, j) /= det;
+    return inv;
+  }
+  Dyn inverse_partial_piv_lu() const {
+    const Index n = rows();
+    Dyn lu = eval();
+    std::vector<Index> perm((size_t)n);
+    for (Index i = 0; i < n; ++i) perm[(size_t)i] = i;
+    for (Index k = 0; k < n; ++k) {            // unblocked right-looking LU, row of the biggest entry of column k first
       Index p = k;
       for (Index r = k + 1; r < n; ++r)
-        if (std::abs(a(r, k)) > std::abs(a(p, k))) p = r;
-      if (p != k)
-        for (Index c = 0; c < n; ++c) {
-          std::swap(a(k, c), a(p, c));
-          std::swap(inv(k, c), inv(p, c));
-        }
-      const T piv = a(k, k);
-      for (Index c = 0; c < n; ++c) {
-        a(k, c) /= piv;
-        inv(k, c) /= piv;
+        if (std::abs(lu(r, k)) > std::abs(lu(p, k))) p = r;
+      if (p != k) {
+        for (Index c = 0; c < n; ++c) std::swap(lu(k, c), lu(p, c));
+        std::swap(perm[(size_t)k], perm[(size_t)p]);
       }
-      for (Index r = 0; r < n; ++r) {
-        if (r == k) continue;
-        const T f = a(r, k);
-        if (f == T(0)) continue;
-        for (Index c = 0; c < n; ++c) {
-          a(r, c) -= f * a(k, c);
-          inv(r, c) -= f * inv(k, c);
-        }
+      if (lu(k, k) != T(0))
+        for (Index r = k + 1; r < n; ++r) lu(r, k) /= lu(k, k);
+      for (Index c = k + 1; c < n; ++c)
+        for (Index r = k + 1; r < n; ++r) lu(r, c) -= lu(r, k) * lu(k, c);
+    }
+    Dyn inv(n, n);
+    for (Index c = 0; c < n; ++c) {            // solve L U x = P e_c, column-oriented (axpy) substitutions
+      std::vector<T> x((size_t)n, T(0));
+      for (Index i = 0; i < n; ++i) x[(size_t)i] = perm[(size_t)i] == c ? T(1) : T(0);
+      for (Index j = 0; j < n; ++j)            // unit lower triangle
+        for (Index r = j + 1; r < n; ++r) x[(size_t)r] -= x[(size_t)j] * lu(r, j);
+      for (Index j = n - 1; j >= 0; --j) {     // upper triangle
+        x[(size_t)j] /= lu(j, j);
+        for (Index r = 0; r < j; ++r) x[(size_t)r] -= x[(size_t)j] * lu(r, j);
       }
+      for (Index i = 0; i < n; ++i) inv(i, c) = x[(size_t)i];
     }
     return inv;
   }
@@ -717,75 +753,134 @@ template <class I>
 struct NaturalOrdering {};
 enum ComputationInfo { Success = 0, NumericalIssue = 1, NoConvergence = 2, InvalidInput = 3 };
 
-// Householder QR, natural column order, diagonal threshold for rank detection (see header note).
+// Exact minimum-degree ordering of the column intersection graph of `a` (columns i, j adjacent when some row holds a
+// non-zero of both), ties to the lowest column index; eliminating a column joins its remaining neighbours pairwise.
+template <class Dyn>
+std::vector<Index> minimum_degree_column_order(const Dyn& a) {
+  const Index m = a.rows(), n = a.cols();
+  std::vector<std::vector<char>> adj((size_t)n, std::vector<char>((size_t)n, 0));
+  for (Index r = 0; r < m; ++r)
+    for (Index i = 0; i < n; ++i) {
+      if (a(r, i) == 0.0) continue;
+      for (Index j = i + 1; j < n; ++j)
+        if (a(r, j) != 0.0) adj[(size_t)i][(size_t)j] = adj[(size_t)j][(size_t)i] = 1;
+    }
+  std::vector<char> done((size_t)n, 0);
+  std::vector<Index> order;
+  for (Index step = 0; step < n; ++step) {
+    Index best = -1, best_deg = n + 1;
+    for (Index c = 0; c < n; ++c) {
+      if (done[(size_t)c]) continue;
+      Index deg = 0;
+      for (Index j = 0; j < n; ++j) deg += !done[(size_t)j] && adj[(size_t)c][(size_t)j];
+      if (deg < best_deg) { best_deg = deg; best = c; }
+    }
+    done[(size_t)best] = 1;
+    order.push_back(best);
+    for (Index i = 0; i < n; ++i) {
+      if (done[(size_t)i] || !adj[(size_t)best][(size_t)i]) continue;
+      for (Index j = i + 1; j < n; ++j)
+        if (!done[(size_t)j] && adj[(size_t)best][(size_t)j]) adj[(size_t)i][(size_t)j] = adj[(size_t)j][(size_t)i] = 1;
+    }
+  }
+  return order;
+}
+
+// Left-looking column Householder QR in a fill-reducing column order, Eigen's pivot threshold and its treatment of
+// (numerically) dependent columns (see header note).
 template <class Mat, class Ordering>
 class SparseQR {
  public:
   typedef Matrix<double, Dynamic, Dynamic> Dyn;
-  SparseQR() : rank_(0), info_(InvalidInput) {}
-  explicit SparseQR(const Mat& a) { compute(a); }
+  SparseQR() : threshold_(0), user_threshold_(false), rank_(0), info_(InvalidInput) {}
+  explicit SparseQR(const Mat& a) : threshold_(0), user_threshold_(false) { compute(a); }
   void compute(const Mat& a) {
-    qr_ = a.dense();
-    const Index m = qr_.rows(), n = qr_.cols(), p = std::min(m, n);
-    beta_.assign((size_t)p, 0.0);
-    double max_col = 0;
-    for (Index c = 0; c < n; ++c) max_col = std::max(max_col, qr_.col(c).norm());
-    threshold_ = 20.0 * (double)(m + n) * max_col * std::numeric_limits<double>::epsilon();
-    rank_ = 0;
-    for (Index k = 0; k < p; ++k) {
-      double nrm = 0;
-      for (Index r = k; r < m; ++r) nrm += qr_(r, k) * qr_(r, k);
-      nrm = std::sqrt(nrm);
-      if (nrm == 0.0) continue;
-      const double alpha = qr_(k, k) > 0 ? -nrm : nrm;
-      const double v0 = qr_(k, k) - alpha;
-      // v = [1, x_{k+1..}/v0]; beta = -v0/alpha
-      for (Index r = k + 1; r < m; ++r) qr_(r, k) /= v0;
-      beta_[(size_t)k] = -v0 / alpha;
-      qr_(k, k) = alpha;
-      for (Index c = k + 1; c < n; ++c) {
-        double s = qr_(k, c);
-        for (Index r = k + 1; r < m; ++r) s += qr_(r, k) * qr_(r, c);
-        s *= beta_[(size_t)k];
-        qr_(k, c) -= s;
-        for (Index r = k + 1; r < m; ++r) qr_(r, c) -= s * qr_(r, k);
-      }
+    const Dyn A = a.dense();
+    const Index m = A.rows(), n = A.cols();
+    m_ = m; n_ = n;
+    std::vector<Index> order;
+    if (std::is_same<Ordering, NaturalOrdering<int>>::value) { for (Index c = 0; c < n; ++c) order.push_back(c); }
+    else order = minimum_degree_column_order(A);
+    if (!user_threshold_) {
+      double max_col = 0;
+      for (Index c = 0; c < n; ++c) max_col = std::max(max_col, A.col(c).norm());
+      if (max_col == 0.0) max_col = 1.0;
+      threshold_ = 20.0 * (double)(m + n) * max_col * std::numeric_limits<double>::epsilon();
     }
-    for (Index k = 0; k < p; ++k) rank_ += std::abs(qr_(k, k)) > threshold_;
+    v_.clear(); tau_.clear(); rcols_.clear(); accepted_.clear();
+    Index nz = 0;                                   // Eigen's nonzeroCol: reflectors / accepted columns so far
+    for (Index oc = 0; oc < n && nz < m; ++oc) {
+      const Index col = order[(size_t)oc];
+      std::vector<double> t((size_t)m);
+      for (Index r = 0; r < m; ++r) t[(size_t)r] = A(r, col);
+      for (Index k = 0; k < nz; ++k) apply(k, t);   // the previous reflectors, in order
+      const double c0 = t[(size_t)nz];
+      double sq = 0;
+      for (Index r = nz + 1; r < m; ++r) sq += t[(size_t)r] * t[(size_t)r];
+      double beta, tau;
+      std::vector<double> v((size_t)m, 0.0);
+      v[(size_t)nz] = 1.0;
+      if (sq == 0.0) {
+        beta = c0;
+        tau = 0.0;
+      } else {
+        beta = std::sqrt(c0 * c0 + sq);
+        if (c0 >= 0.0) beta = -beta;
+        for (Index r = nz + 1; r < m; ++r) v[(size_t)r] = t[(size_t)r] / (c0 - beta);
+        tau = (beta - c0) / beta;
+      }
+      if (std::abs(beta) > threshold_) {            // accepted: a column of R and a reflector
+        std::vector<double> rc(t.begin(), t.begin() + nz);
+        rc.push_back(beta);
+        rcols_.push_back(rc);
+        v_.push_back(v);
+        tau_.push_back(tau);
+        accepted_.push_back(col);
+        ++nz;
+      }                                             // else: dependent column, moved to the end (component zero)
+    }
+    rank_ = nz;
     info_ = Success;
   }
   template <class D>
   Dyn solve(const DenseBase<D, double>& b) const {
-    const Index m = qr_.rows(), n = qr_.cols(), p = std::min(m, n);
     Dyn y = b.eval();
-    for (Index c = 0; c < y.cols(); ++c)
-      for (Index k = 0; k < p; ++k) {
-        if (beta_[(size_t)k] == 0.0) continue;
-        double s = y(k, c);
-        for (Index r = k + 1; r < m; ++r) s += qr_(r, k) * y(r, c);
-        s *= beta_[(size_t)k];
-        y(k, c) -= s;
-        for (Index r = k + 1; r < m; ++r) y(r, c) -= s * qr_(r, k);
-      }
-    Dyn x(n, y.cols());
+    Dyn x(n_, y.cols());
     x.setZero();
-    for (Index c = 0; c < y.cols(); ++c)
-      for (Index k = p - 1; k >= 0; --k) {
-        if (std::abs(qr_(k, k)) <= threshold_) continue;  // rank-deficient direction: component left at zero
-        double s = y(k, c);
-        for (Index j = k + 1; j < n; ++j) s -= qr_(k, j) * x(j, c);
-        x(k, c) = s / qr_(k, k);
+    for (Index c = 0; c < y.cols(); ++c) {
+      std::vector<double> t((size_t)m_);
+      for (Index r = 0; r < m_; ++r) t[(size_t)r] = y(r, c);
+      for (Index k = 0; k < rank_; ++k) apply(k, t);          // Q^T b
+      std::vector<double> z((size_t)rank_, 0.0);
+      for (Index k = rank_ - 1; k >= 0; --k) {                // R11 z = (Q^T b)[0 .. rank)
+        double sacc = t[(size_t)k];
+        for (Index j = k + 1; j < rank_; ++j) sacc -= rcols_[(size_t)j][(size_t)k] * z[(size_t)j];
+        z[(size_t)k] = sacc / rcols_[(size_t)k][(size_t)k];
       }
+      for (Index k = 0; k < rank_; ++k) x(accepted_[(size_t)k], c) = z[(size_t)k];
+    }
     return x;
   }
   Index rank() const { return rank_; }
   ComputationInfo info() const { return info_; }
-  void setPivotThreshold(double t) { threshold_ = t; }
+  void setPivotThreshold(double t) { threshold_ = t; user_threshold_ = true; }
+  const std::vector<Index>& acceptedColumns() const { return accepted_; }   // column order of R (test hook)
 
  private:
-  Dyn qr_;
-  std::vector<double> beta_;
+  void apply(Index k, std::vector<double>& t) const {          // t <- (I - tau v v^T) t
+    const std::vector<double>& v = v_[(size_t)k];
+    double dot = 0;
+    for (Index r = k; r < m_; ++r) dot += v[(size_t)r] * t[(size_t)r];
+    dot *= tau_[(size_t)k];
+    if (dot == 0.0) return;
+    for (Index r = k; r < m_; ++r) t[(size_t)r] -= dot * v[(size_t)r];
+  }
+  std::vector<std::vector<double>> v_, rcols_;
+  std::vector<double> tau_;
+  std::vector<Index> accepted_;
+  Index m_ = 0, n_ = 0;
   double threshold_;
+  bool user_threshold_;
   Index rank_;
   ComputationInfo info_;
 };

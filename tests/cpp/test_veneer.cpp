@@ -386,6 +386,46 @@ int main() {
     EXPECT(checkPath(v, segs, 10) < 1e-6, "cross-thread checkPath");
     opt.reset();
   }
+  // --- rank-deficient free systems: the reference's rank-revealing SparseQR returns a basic solution and solveLinear()
+  //     returns true (LIN:365-378); so does the veneer (solveLinearBasic: pivoted QR on the host).  Under-constrained
+  //     problems: only positions fixed.  Checked the way the reference checks its paths (checkPath) + minimum cost.
+  for (int K = 1; K <= 2; ++K) {
+    for (int D = 1; D <= 3; D += 2) {
+      Vertex::Vector v;
+      std::vector<double> times;
+      for (int i = 0; i <= K; ++i) {
+        Vertex vx(D);
+        Eigen::VectorXd pos(D);
+        for (int d = 0; d < D; ++d) pos[d] = 1.5 * i - 0.7 * d + 0.3 * i * i * (d + 1);
+        vx.addConstraint(derivative_order::POSITION, pos);
+        v.push_back(vx);
+        if (i > 0) times.push_back(1.3 + 0.4 * i);
+      }
+      PolynomialOptimization<10> opt(D);
+      opt.setupFromVertices(v, times, derivative_order::SNAP);
+      const bool ok = opt.solveLinear();
+      EXPECT(ok, "rank-deficient K=%d D=%d: solveLinear() must return true like the reference", K, D);
+      EXPECT(opt.getLastSolveRank() < opt.getNumberFreeConstraints(), "rank %zu of %zu", opt.getLastSolveRank(),
+             opt.getNumberFreeConstraints());
+      Segment::Vector segs;
+      opt.getSegments(&segs);
+      EXPECT(checkPath(v, segs, 10) < 1e-6, "rank-deficient K=%d D=%d checkPath %.3g", K, D, checkPath(v, segs, 10));
+      // a cubic interpolates up to four points: the minimum snap cost is zero (the reference: 1e-20 .. 3e-19)
+      EXPECT(std::abs(opt.computeCost()) < 1e-9, "rank-deficient K=%d D=%d cost %.3g", K, D, opt.computeCost());
+      std::vector<Eigen::VectorXd> fr;
+      opt.getFreeConstraints(&fr);
+      size_t zeros = 0;
+      for (std::ptrdiff_t i = 0; i < fr[0].size(); ++i) zeros += fr[0][i] == 0.0;
+      EXPECT(zeros >= opt.getNumberFreeConstraints() - opt.getLastSolveRank(), "basic solution: %zu exact zeros", zeros);
+    }
+  }
+  {   // a full-rank problem still goes through the library (rank == n_free)
+    Vertex::Vector v = createRandomVertices(derivative_order::SNAP, 3, Eigen::VectorXd::Constant(3, -5.0),
+                                            Eigen::VectorXd::Constant(3, 5.0), 11);
+    PolynomialOptimization<10> opt(3);
+    opt.setupFromVertices(v, estimateSegmentTimes(v, 2.0, 2.0), derivative_order::SNAP);
+    EXPECT(opt.solveLinear() && opt.getLastSolveRank() == opt.getNumberFreeConstraints(), "full rank");
+  }
   std::printf(g_fail ? "VENEER TESTS FAILED: %d\n" : "VENEER TESTS PASSED%.0d\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -39,16 +39,25 @@ def resources(H, K, WS, LS, RS=0, full=False):
     return scratch, spills
 
 
-def best(H, K):
+RS_REG_STEPS = {4: 16, 5: 10, 6: 5}                                    # register steps with the shared storage (search start)
+
+
+def best(H, K, RS=1):
+    """RS = 1 (round 3): register steps with G shared between the dimension lanes (MtgCfg::kRegShared, MTG_DLR lines)."""
     kc = (K + 1) // 2
-    for WS in range(max(0, kc - REG_STEPS[H]), kc + 1):
+    start = kc - (RS_REG_STEPS if RS else REG_STEPS)[H]
+    for WS in range(max(0, start), kc + 1):
         LS = min(WS, LDS_STEPS[H])
-        r = resources(H, K, WS, LS)
+        r = resources(H, K, WS, LS, RS)
         if r is None:
             return f"// H={H} K={K}: compile error"
         if r[0] == 0 and r[1] <= 16:      # no scratch; a few registers parked in AGPRs are fine
             ms, mi, me, dv = SHAPES[H]
-            return f"MTG_DLW({H}, {K}, {ms}, {mi}, {me}, {dv}, 3, {2 if K <= 8 else 1}, 0, 0, {WS}, {LS})   // spilled VGPRs: {r[1]}"
+            macro = "MTG_DLR" if RS else "MTG_DLW"
+            if WS == 0 and kc <= REG_STEPS[H]:
+                macro, tail = "MTG_DL", ""      # fits without sharing: keep the plain variant
+                return f"MTG_DL({H}, {K}, {ms}, {mi}, {me}, {dv}, 3, {2 if K <= 8 else 1}, 0, 0)"
+            return f"{macro}({H}, {K}, {ms}, {mi}, {me}, {dv}, 3, {2 if K <= 8 else 1}, 0, 0, {WS}, {LS})   // spilled VGPRs: {r[1]}"
     return f"// H={H} K={K}: no setting without scratch"
 
 
