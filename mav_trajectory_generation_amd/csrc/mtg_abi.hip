@@ -110,6 +110,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
+  int knob_dl_occ2 = -1;             // MTG_DL_OCC2: 1 always / 0 never use the two-waves-per-SIMD twins (default: by launch size)
   bool knob_dl_any_rr = false;       // MTG_DL_ANY_SCHED=rr: round 2's unit schedule of the cross-structure launch
   bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
@@ -144,6 +145,7 @@ struct mtg_plan {
   const MtgStaticEntry* fast = nullptr;        // all dimensions in one workgroup
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
+  const MtgDimlaneEntry* dimlane2 = nullptr;   // its throughput twin (two waves per SIMD), where one exists
   bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
   bool slab_queue_attr_set = false;
   double* ws = nullptr;
@@ -256,6 +258,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
+  if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
   if (const char* e = getenv("MTG_DL_ANY_SCHED")) ctx->knob_dl_any_rr = std::string(e) == "rr";
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
@@ -382,6 +385,7 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
     if (D % dg == 0) p->fast_split = mtg_find_static(p->H, dg, K, d, p->mask.data());
   }
   p->dimlane = mtg_find_dimlane(p->H, D, K, d, p->mask.data());
+  p->dimlane2 = p->dimlane ? mtg_find_dimlane(p->H, D, K, d, p->mask.data(), 2) : nullptr;
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
   tab.insert(tab.end(), p->offF.begin(), p->offF.end());
@@ -448,6 +452,16 @@ static int balanced_grid(const mtg_context* ctx, int ntiles, int cap) {
   if (ntiles <= cap || ctx->knob_no_balance) return std::min(ntiles, cap);
   const int rounds = (ntiles + cap - 1) / cap;
   return (ntiles + rounds - 1) / rounds;
+}
+
+// The two-waves-per-SIMD twin of a dimension-in-lane variant (MTG_DLO) for launches with more workgroups than `kOcc2MinWgPerCu`
+// per CU: below that every workgroup has a CU to itself anyway and the plain variant (no spills) is faster.
+constexpr int kOcc2MinWgPerCu = 2;
+static const MtgDimlaneEntry* dimlane_twin(const mtg_plan* p, const MtgDimlaneEntry* dl, int64_t trajectories) {
+  if (!dl || dl != p->dimlane || !p->dimlane2 || p->ctx->knob_dl_occ2 == 0) return dl;
+  if (p->ctx->knob_dl_occ2 == 1) return p->dimlane2;
+  const int64_t units = ((trajectories + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
+  return units > (int64_t)kOcc2MinWgPerCu * p->ctx->n_cu ? p->dimlane2 : dl;
 }
 
 // default range of the dimension-in-lane form (mtg_dimlane_variants.inc): LO * CUs <= workgroups <= HI * CUs / 2
@@ -639,7 +653,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, st, Q, ntiles);
       if (uv) break;
     }
-  } else if (const MtgDimlaneEntry* dl = pick_dimlane(p, batch, L, P, flags, cost_only)) {
+  } else if (const MtgDimlaneEntry* dl = dimlane_twin(p, pick_dimlane(p, batch, L, P, flags, cost_only), batch)) {
     // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
     const int nt = (int)((batch + dl->tpw - 1) / dl->tpw);
     const int units = (nt + dl->np - 1) / dl->np;
@@ -817,6 +831,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
     dl = nullptr;
   if (slab && dl && !(flags & MTG_FLAG_DIMLANE) && !dimlane_is_default(p, dl, batch * (int64_t)n_launch)) dl = nullptr;
   if (!slab && !dl) return 1;
+  dl = dimlane_twin(p, dl, batch * (int64_t)n_launch);
   for (int32_t i = 0; i < n; ++i) {
     if (!times[i] || !coeffs[i] || (p->n_fixed > 0 && !d_fixed[i])) return MTG_ERR_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(coeffs[i]) & 15) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");

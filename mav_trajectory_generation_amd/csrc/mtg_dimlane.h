@@ -25,6 +25,15 @@
 #ifndef MTG_DL_OCC
 #define MTG_DL_OCC 1   // waves per SIMD the register allocation is held to
 #endif
+#ifndef MTG_DL_PREFETCH
+#define MTG_DL_PREFETCH 0   // 1: next tile's inputs requested before the current tile is solved (N = 10 / 12, K = 8).  Built and
+                            // measured in round 3, off by default: 30 more registers, no effect (B = 125k 90.3 vs 91.4 us,
+                            // N = 12 / K = 8 at 100k 93.7 vs 92.0 us) -- the third of its lifetime a wave spends parked
+                            // (profiles/r03f_pmc_stalls.txt) is not the input round trip
+#endif
+#ifndef MTG_DL_PEND
+#define MTG_DL_PEND true   // MtgSlabOut::PEND: a drained range's chunks wait in registers across one back-substitution step
+#endif
 
 
 template <class C, int DL>
@@ -98,7 +107,7 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
 // QUEUE (mtg_solve_dl_queue_kernel, mtg_solve_linear_sequence): `ntiles` counts the tiles of ALL batches of the queue
 // (batch-major, q->tiles_per_batch each); a wave's tile index -> (batch, tile inside it) is advanced incrementally
 // (wave-uniform) and the batch's pointer triple comes from the kernel arguments.
-template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE>
+template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE, int OCC = 1>
 __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ times, const double* __restrict__ dfix,
                                                   double* __restrict__ coeffs, int* status, int* traj_status, int B, int ntiles,
                                                   int nwg, double* ws, const MtgSeqQueue* q
@@ -139,34 +148,48 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   // QUEUE: this wave's tile as (batch, tile inside the batch); the clamp of a surplus tile (odd tile count, NP == 2) lands
   // on the last tile of the last batch
   const int tpb = QUEUE ? q->tiles_per_batch : ntiles;
-  int batch = 0, local = 0;
+  struct Where { int batch, local; const double* t; const double* f; double* c; };
   auto tile_of = [&](int it) { const int tl = NP * it + pair; return tl < ntiles ? tl : ntiles - 1; };
-  auto locate = [&](int tile_) {        // absolute (first unit) ...
-    if constexpr (QUEUE) { batch = tile_ / tpb; local = tile_ - batch * tpb; } else { local = tile_; }
-  };
-  auto advance = [&](int tile_, int prev_) {   // ... then relative to the previous unit's tile
-    if constexpr (QUEUE) { local += tile_ - prev_; while (local >= tpb) { local -= tpb; ++batch; } } else { local = tile_; }
-  };
-  const double* t_cur = times; const double* f_cur = dfix; double* c_cur = coeffs;
-  auto bind = [&]() {
+  auto bind = [&](Where& w) {
     if constexpr (QUEUE) {
-      const MtgSeqItem it = q->item[batch];
-      t_cur = it.times; f_cur = it.dfix; c_cur = it.coeffs;
-      P.times = t_cur; P.dfix = f_cur; P.coeffs = c_cur;
+      const MtgSeqItem it = q->item[w.batch];
+      w.t = it.times; w.f = it.dfix; w.c = it.coeffs;
+    } else {
+      w.t = times; w.f = dfix; w.c = coeffs;
     }
   };
-  auto fetch = [&]() {
-    unsigned bb = (unsigned)local * TPW + t;
-    if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload<C, 1>(t_cur, f_cur, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
-    else mtg_dl_preload<C, -1>(t_cur, f_cur, (unsigned)B, bb, (unsigned)d, ln.T, ln.fx);
+  auto locate = [&](int tile_) {        // absolute (first unit) ...
+    Where w;
+    if constexpr (QUEUE) { w.batch = tile_ / tpb; w.local = tile_ - w.batch * tpb; } else { w.batch = 0; w.local = tile_; }
+    bind(w);
+    return w;
   };
+  auto advance = [&](const Where& from, int delta) {   // ... then relative to the previous unit's tile
+    Where w = from;
+    w.local += delta;
+    if constexpr (QUEUE) {
+      while (w.local >= tpb) { w.local -= tpb; ++w.batch; }
+      bind(w);
+    }
+    return w;
+  };
+  auto fetch = [&](const Where& w, double (&T_)[C::KCS], double (&fx_)[1][C::NC]) {
+    unsigned bb = (unsigned)w.local * TPW + t;
+    if (bb >= (unsigned)B) bb = B - 1;
+    if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, T_, fx_);
+    else mtg_dl_preload<C, -1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, T_, fx_);
+  };
+  // Input prefetch (MTG_DL_PREFETCH, off by default -- see there): the NEXT tile's inputs requested before the current tile
+  // is solved instead of after its coefficient stores (loads retire behind stores in the in-order vmcnt counter).
+  // (N = 10 / 12 with K = 8 only: the N = 8 / K = 8 and N = 10 / K = 4 kernels fit 256 registers and run two per SIMD without it)
+  constexpr bool kPrefetch = MTG_DL_PREFETCH && C::H >= 5 && C::KT == 8 && C::WSJ == 0 && OCC == 1;
+  [[maybe_unused]] double nT[kPrefetch ? C::KCS : 1], nfx[1][kPrefetch ? C::NC : 1];
+  Where cur{0, 0, times, dfix, coeffs};
   int tile_prev = 0;
   if ((int)blockIdx.x < nunits) {
     tile_prev = tile_of(blockIdx.x);
-    locate(tile_prev);
-    bind();
-    fetch();
+    cur = locate(tile_prev);
+    fetch(cur, ln.T, ln.fx);
   }
   const int lane_io = lane, t_io = t, d_io = d;
 #if defined(MTG_LAB_TIMING)
@@ -185,20 +208,22 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   P.lds_steps = (unsigned)(size_t)(base + 2 * half + (size_t)dir * mtg_dl_steps_bytes<C>()) + (unsigned)lane * 8u;
   double* mine = reinterpret_cast<double*>(base + (size_t)(1 - dir) * half) + lane_io;
   const double* other = reinterpret_cast<const double*>(my_slab) + lane_io;
-  MtgSlabOut<C, DL, 1, AUX> ioA;
-  MtgSlabOut<C, DL, -1, AUX> ioB;
+  MtgSlabOut<C, DL, 1, AUX, MTG_DL_PEND> ioA;
+  MtgSlabOut<C, DL, -1, AUX, MTG_DL_PEND> ioB;
   ioA.init(my_slab, lane_io, t_io, d_io);
   ioB.init(my_slab, lane_io, t_io, d_io);
   for (int it = blockIdx.x; it < nunits; it += nwg) {
-    const int tile = tile_of(it);
-    const bool first = it == (int)blockIdx.x;
-    if (!first) {
-      advance(tile, tile_prev);
-      tile_prev = tile;
-      bind();
-      fetch();
+    [[maybe_unused]] const bool first = it == (int)blockIdx.x;
+    const bool has_next = it + nwg < nunits;
+    Where nxt = cur;
+    if (has_next) {
+      const int tile_next = tile_of(it + nwg);
+      nxt = advance(cur, tile_next - tile_prev);
+      tile_prev = tile_next;
+      if constexpr (kPrefetch) fetch(nxt, nT, nfx);
     }
-    const long long b0 = (long long)local * TPW;
+    if constexpr (QUEUE) { P.times = cur.t; P.dfix = cur.f; P.coeffs = cur.c; }
+    const long long b0 = (long long)cur.local * TPW;
     const long long bl = b0 + t;
     const bool active = bl < B && !dup;
     const long long b = bl < B ? bl : B - 1;
@@ -214,10 +239,10 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     __syncthreads();
     MTG_DL_STAMP(3);
     if (dir == 0) {
-      ioA.begin_tile(c_cur, b0, B);
+      ioA.begin_tile(cur.c, b0, B);
       mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active);
     } else {
-      ioB.begin_tile(c_cur, b0, B);
+      ioB.begin_tile(cur.c, b0, B);
       mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active);
     }
 #if defined(MTG_LAB_TIMING)
@@ -225,12 +250,23 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && first) { tdbg[5] = clock64(); tdbg[15] = wall_clock64(); }
 #endif
+    if (has_next) {
+      if constexpr (kPrefetch) {
+#pragma unroll
+        for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) ln.fx[0][c] = nfx[0][c];
+      } else {
+        fetch(nxt, ln.T, ln.fx);
+      }
+      cur = nxt;
+    }
     __syncthreads();
   }
 }
 
-template <class C, int DL, int NP, int OUT, int AUX>
-__global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
+template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
+__global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
                                                                             const double* __restrict__ dfix,
                                                                             double* __restrict__ coeffs, int* status,
                                                                             int* traj_status, int B, int ntiles, int nwg,
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
                                                                             , long long* tdbg_base
 #endif
 ) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, nullptr
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, nullptr
 #if defined(MTG_LAB_TIMING)
                                                 , tdbg_base
 #endif
@@ -248,10 +284,10 @@ __global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_kerne
 
 #if !defined(MTG_LAB_TIMING)
 // the queue form: same body, the batches' pointer triples in the kernel arguments (mtg_solve_linear_sequence)
-template <class C, int DL, int NP, int OUT, int AUX>
-__global__ __launch_bounds__(NP * 2 * kWave, MTG_DL_OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
+template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
+__global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
                                                                                   double* ws, MtgSeqQueue q) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, &q);
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true, OCC>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, &q);
 }
 #endif
 

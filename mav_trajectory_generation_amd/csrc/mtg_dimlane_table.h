@@ -6,7 +6,7 @@
 
 namespace {
 constexpr int kMaxDevices = 64;
-template <class C, int DL, int NP>
+template <class C, int DL, int NP, int OCC = 1>
 int launch_dl(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
               int* traj_status, int B, int ntiles, int policy, double* ws) {
   constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
@@ -25,21 +25,23 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
     return 0;
   };
 #if !defined(MTG_DL_SINGLE_POLICY)
-  if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
-  if (policy == 2) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 0>, 2);
+  if constexpr (OCC == 1) {
+    if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
+    if (policy == 2) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 0>, 2);
+  }
 #endif
   (void)policy;
-  return go(mtg_solve_dl_kernel<C, DL, NP, 0, 18>, 0);
+  return go(mtg_solve_dl_kernel<C, DL, NP, 0, 18, OCC>, 0);
 }
 #if !defined(MTG_DL_SINGLE_POLICY)
 // the queue form (mtg_solve_linear_sequence): nt sc1 stores, main table only
-template <class C, int DL, int NP>
+template <class C, int DL, int NP, int OCC = 1>
 int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws) {
   constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
-  auto kern = mtg_solve_dl_queue_kernel<C, DL, NP, 0, 18>;
+  auto kern = mtg_solve_dl_queue_kernel<C, DL, NP, 0, 18, OCC>;
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set[dev] = true;
@@ -54,22 +56,26 @@ int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, i
 }  // namespace
 
 // MTG_DLR: as MTG_DLW with the register steps' G shared between the dimension lanes as well (MtgCfg::kRegShared)
+// MTG_DLO: the throughput twin of a short-chain variant -- register-shared steps AND the register allocation held to 256
+// (two waves per SIMD; a few registers may spill): chosen for large launches (MtgDimlaneEntry::occ == 2)
 #define MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS) MtgCfg<H, 1, K, MS, MI, ME, DV, 0, WS, ((WS > 0 || RS) ? DL : 0), LS, RS>
-#define MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, RS)                                                              \
+#define MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, RS, OCC)                                                          \
   {H, K, MS, MI, ME, DV, DL, NP, 64 / DL, LO, HI, mtg_dl_lds_bytes<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP>(),    \
    (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::LSJ) *           \
        MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSE * sizeof(double),                                                   \
-   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP>,                                                         \
-   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP)},
-#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 0)
-#define MTG_DLR(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 1)
-#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0, 0)
+   launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC>,                                                    \
+   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC), OCC},
+#define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 0, 1)
+#define MTG_DLR(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 1, 1)
+#define MTG_DLO(H, K, MS, MI, ME, DV, DL, NP, RS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, 0, 0, 0, 0, RS, 2)
+#define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0, 0, 1)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include MTG_DL_TABLE_INC
 };
 #undef MTG_DL
 #undef MTG_DLW
 #undef MTG_DLR
+#undef MTG_DLO
 #undef MTG_DLX
 #undef MTG_DLCFG
 #undef MTG_DL_QUEUE_FN

@@ -474,12 +474,13 @@ struct MtgDimlaneEntry {
   // a queue of batches in one launch (mtg_solve_linear_sequence; main-table variants only, else null): ntiles = tiles of
   // all batches (q->n * q->tiles_per_batch)
   int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws);
+  int occ;            // waves per SIMD the kernel's registers allow: 1, or 2 for the throughput twins (MTG_DLO)
 };
 // cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
 // dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])
 int mtg_any_cfg_index(const MtgStaticEntry* e);
 SolveMultiFn mtg_multi_any_fn(int dg, int variant);
-const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask);
+const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask, int occ = 1);
 
 // cross-structure dimension-in-lane launches (mtg_dimlane.h: mtg_solve_dl_any_kernel)
 struct MtgDlAnyItem {     // one bucket
