@@ -549,7 +549,7 @@ class PolynomialOptimizationBatch {
  public:
   enum { N = _N };
   PolynomialOptimizationBatch(size_t dimension, const std::vector<uint32_t>& fixed_mask, int derivative_to_optimize = N / 2 - 1)
-      : dimension_(dimension), n_segments_(fixed_mask.size() - 1) {
+      : dimension_(dimension), n_segments_(fixed_mask.size() - 1), mask_(fixed_mask), derivative_(derivative_to_optimize) {
     plan_ = mtg_compat_detail::make_plan(N, (int)dimension, (int)n_segments_, derivative_to_optimize, fixed_mask);
     mtg_plan_get_info(plan_.get(), &info_);
   }
@@ -562,13 +562,61 @@ class PolynomialOptimizationBatch {
   size_t getNumberFixedConstraints() const { return info_.n_fixed; }
   size_t getNumberFreeConstraints() const { return info_.n_free; }
 
+  // Host pointers: synchronous; returns true like the reference -- trajectories whose free-constraint system is rank
+  // deficient (per-trajectory status bit 1 from the library) get the reference's behaviour, a BASIC solution from a
+  // rank-revealing factorisation (LIN:365-378), through PolynomialOptimization<N>::solveLinear() on the host, one by one
+  // (under-constrained problems are rare and tiny); every other trajectory of the batch keeps its device result.
+  // Device pointers: asynchronous, no fallback (sync() reports MTG_ERR_SINGULAR; mtg_solve_linear_status names the
+  // trajectories) -- returns true when the launch was enqueued.
   bool solveLinear(size_t batch, const double* times, const double* d_fixed, double* coeffs, double* d_free = nullptr,
                    double* cost = nullptr, bool device_pointers = false) {
     mtg_layout lay;
     mtg_layout_aos(plan_.get(), (int64_t)batch, &lay);
-    const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
-                                    device_pointers ? 0u : (uint32_t)MTG_FLAG_HOST_POINTERS);
-    if (rc == MTG_ERR_SINGULAR) return false;   // host-pointer calls report their status themselves
+    if (device_pointers) {
+      const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost, 0u);
+      CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_plan_context(plan_.get()));
+      return true;
+    }
+    std::vector<int32_t> status(batch, 0);
+    const int rc = mtg_solve_linear_status(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
+                                           status.data(), (uint32_t)MTG_FLAG_HOST_POINTERS);
+    if (rc == MTG_ERR_SINGULAR) {
+      const size_t K = n_segments_, D = dimension_, nf = info_.n_fixed, np = info_.n_free;
+      for (size_t b = 0; b < batch; ++b) {
+        if (!(status[b] & 2)) continue;
+        CHECK(!(status[b] & 1)) << "Segment times need to be greater than zero";   // LIN:297
+        Vertex::Vector vertices;
+        size_t col = 0;
+        for (size_t v = 0; v <= K; ++v) {
+          Vertex vx(D);
+          for (int p = 0; p < N / 2; ++p) {
+            if (!((mask_[v] >> p) & 1u)) continue;
+            Eigen::VectorXd value(D);
+            for (size_t d = 0; d < D; ++d) value[d] = d_fixed[(b * D + d) * nf + col];
+            vx.addConstraint(p, value);
+            ++col;
+          }
+          vertices.push_back(vx);
+        }
+        PolynomialOptimization<N> one(D);
+        one.setupFromVertices(vertices, std::vector<double>(times + b * K, times + (b + 1) * K), derivative_);
+        one.solveLinear();
+        Segment::Vector segs;
+        one.getSegments(&segs);
+        for (size_t k = 0; k < K; ++k)
+          for (size_t d = 0; d < D; ++d) {
+            const Eigen::VectorXd c = segs[k][d].getCoefficients(0);
+            for (int j = 0; j < N; ++j) coeffs[((b * K + k) * D + d) * N + j] = c[j];
+          }
+        if (d_free) {
+          std::vector<Eigen::VectorXd> fr;
+          one.getFreeConstraints(&fr);
+          for (size_t d = 0; d < D; ++d) for (size_t c = 0; c < np; ++c) d_free[(b * D + d) * np + c] = fr[d][c];
+        }
+        if (cost) cost[b] = one.computeCost();
+      }
+      return true;
+    }
     CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_plan_context(plan_.get()));
     return true;
   }
@@ -590,6 +638,8 @@ class PolynomialOptimizationBatch {
 
  private:
   size_t dimension_, n_segments_;
+  std::vector<uint32_t> mask_;
+  int derivative_;
   std::shared_ptr<mtg_plan> plan_;
   mtg_plan_info info_;
 };

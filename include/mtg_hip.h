@@ -127,7 +127,8 @@ int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
 mtg_context* mtg_plan_context(const mtg_plan* plan);
 /* Which kernel form a device-pointer mtg_solve_linear(plan, batch, layout, ..., flags) call with coefficient output only
  * takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
- * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane.  Negative: mtg_status.                        */
+ * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane (one unrolled body per chain length), 6 dimension-in-lane
+ * with a run-time chain length (one body per polynomial order).  Negative: mtg_status.                                 */
 int mtg_plan_launch_form(const mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint32_t flags);
 void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);

@@ -347,7 +347,7 @@ class Plan:
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
 
-    LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane"}
+    LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane", 6: "dimlane_rt"}
 
     def launch_form(self, batch: int, layout: str = "soa", dims: str = "auto") -> str:
         """Kernel form a coefficient-only device-pointer solve of `batch` trajectories takes (mtg_plan_launch_form)."""

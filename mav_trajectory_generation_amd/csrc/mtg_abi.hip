@@ -25,6 +25,7 @@
 
 #include "../../include/mtg_hip.h"
 #include "mtg_kernels.h"
+#include "mtg_dimlane_rt.h"
 
 int mtg_host_run(const MtgParams& P, int H, bool update);   // mtg_host.cpp: host build of the lane code
 
@@ -110,6 +111,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
+  int knob_dl_rt = -1;               // MTG_DL_RT: 1 = the run-time-K body even where a static variant exists, 0 = never (default: where none exists)
   int knob_dl_occ2 = -1;             // MTG_DL_OCC2: 1 always / 0 never use the two-waves-per-SIMD twins (default: by launch size)
   bool knob_dl_any_rr = false;       // MTG_DL_ANY_SCHED=rr: round 2's unit schedule of the cross-structure launch
   bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
@@ -131,6 +133,7 @@ struct LaunchRecord {
   int ntiles = 0, grid = 0, gridy = 1;
   size_t lds = 0;
   const MtgDimlaneEntry* dl = nullptr;   // dimension-in-lane launch (mtg_dimlane.h): uses params.{times,dfix,coeffs,status,tstatus,B}
+  const MtgDimlaneRtEntry* rt = nullptr; // run-time-K dimension-in-lane launch (mtg_dimlane_rt.h)
   int dl_policy = 0;
   double* dl_ws = nullptr;
 };
@@ -146,6 +149,7 @@ struct mtg_plan {
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
   const MtgDimlaneEntry* dimlane2 = nullptr;   // its throughput twin (two waves per SIMD), where one exists
+  const MtgDimlaneRtEntry* dimlane_rt = nullptr;   // run-time-K dimension-in-lane body (mtg_dimlane_rt.h): any chain length of the standard shapes
   bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
   bool slab_queue_attr_set = false;
   double* ws = nullptr;
@@ -259,6 +263,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
   if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
+  if (const char* e = getenv("MTG_DL_RT")) ctx->knob_dl_rt = atoi(e);
   if (const char* e = getenv("MTG_DL_ANY_SCHED")) ctx->knob_dl_any_rr = std::string(e) == "rr";
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
@@ -386,6 +391,7 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   }
   p->dimlane = mtg_find_dimlane(p->H, D, K, d, p->mask.data());
   p->dimlane2 = p->dimlane ? mtg_find_dimlane(p->H, D, K, d, p->mask.data(), 2) : nullptr;
+  p->dimlane_rt = mtg_find_dimlane_rt(p->H, D, K, d, p->mask.data());
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
   tab.insert(tab.end(), p->offF.begin(), p->offF.end());
@@ -484,6 +490,20 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
   if (flags & MTG_FLAG_DIMLANE) return dl;
   return dimlane_is_default(p, dl, batch) ? dl : nullptr;
+}
+
+// The run-time-K dimension-in-lane body (mtg_dimlane_rt.h): same eligibility as the static dimension-in-lane variants
+// (canonical SoA inputs, coefficient output only); taken where the plan has no static variant (K > 32, ...) -- or always /
+// never with MTG_DL_RT=1 / 0.
+static const MtgDimlaneRtEntry* pick_dimlane_rt(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P,
+                                                uint32_t flags, bool cost_only) {
+  const MtgDimlaneRtEntry* rt = p->dimlane_rt;
+  if (!rt || p->ctx->knob_dl_rt == 0 || p->ctx->knob_no_dimlane || cost_only || P.dfree || P.cost) return nullptr;
+  if (p->dimlane && p->ctx->knob_dl_rt != 1) return nullptr;
+  if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
+  if (L->times_stride_b != 1 || L->times_stride_k != batch) return nullptr;
+  if (L->fixed_stride_b != 1 || L->fixed_stride_c != batch || L->fixed_stride_d != (int64_t)p->n_fixed * batch) return nullptr;
+  return rt;
 }
 
 // Variant choice of the fused / dimension-split forms: specialised kernels when the plan matches one; with few tiles (small
@@ -653,6 +673,30 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, st, Q, ntiles);
       if (uv) break;
     }
+  } else if (const MtgDimlaneRtEntry* rt = pick_dimlane_rt(p, batch, L, P, flags, cost_only)) {
+    // run-time-K dimension-in-lane body: persistent 2-wave workgroups, two per CU; the head steps beyond the register tail
+    // and the LDS step area go through a lane-coalesced workspace
+    const int nt = (int)((batch + rt->tpw - 1) / rt->tpw);
+    const int grid = std::min(nt, ctx->n_cu * 2);
+    const int kc_max = (p->K + 1) / 2;
+    const int ws_steps = std::max(0, kc_max - 1 - rt->r_steps - rt->l_steps);
+    double* rt_ws = nullptr;
+    if (ws_steps > 0) {
+      const size_t need = rt->step_bytes_per_lane * (size_t)(kc_max - 1 - rt->r_steps) * (size_t)grid * 2 * kWave;   // slots j - 1 of all head steps
+      if (p->user_ws) {
+        if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
+        rt_ws = p->user_ws;
+      } else {
+        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+        if (rc != MTG_OK) return rc;
+        rt_ws = p->ws;
+      }
+    }
+    if (rt->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, p->K, nt, rt_ws) != 0)
+      return set_err(ctx, MTG_ERR_DEVICE, "run-time-K dimension-in-lane launch set-up failed");
+    LaunchRecord r;
+    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.rt = rt; r.dl_ws = rt_ws;
+    p->last.push_back(r);
   } else if (const MtgDimlaneEntry* dl = dimlane_twin(p, pick_dimlane(p, batch, L, P, flags, cost_only), batch)) {
     // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
     const int nt = (int)((batch + dl->tpw - 1) / dl->tpw);
@@ -781,6 +825,7 @@ int mtg_plan_launch_form(const mtg_plan* p, int64_t batch, const mtg_layout* L, 
   if (!p || !L || batch <= 0 || (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY))) return MTG_ERR_INVALID_ARGUMENT;
   MtgParams P;
   fill_common(p, P, batch, L);   // (no d_free / cost output: coefficient output only)
+  if (pick_dimlane_rt(p, batch, L, P, flags, false)) return 6;
   if (pick_dimlane(p, batch, L, P, flags, false)) return 5;
   const MtgStaticEntry* var = pick_static(p, (int)((batch + kWave - 1) / kWave), flags, true);
   if (!var) return 0;
@@ -1355,6 +1400,11 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   MTG_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   for (int i = 0; i < iters; ++i) {
     for (const LaunchRecord& r : p->last) {
+      if (r.rt) {
+        r.rt->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status, r.params.tstatus,
+                     (int)r.params.B, r.params.K, r.ntiles, r.dl_ws);
+        continue;
+      }
       if (r.dl) {
         r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
                      r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws);

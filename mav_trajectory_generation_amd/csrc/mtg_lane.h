@@ -107,7 +107,7 @@ struct MtgCfg {
   // DLW_ > 0 (dimension-in-lane form, D_ == 1): the DLW_ dimension lanes of a trajectory compute identical G; each stores
   // every DLW_-th element (one row of the workspace holds DLW_ consecutive elements, one per dimension lane) and reads
   // the others from its sibling lanes' columns: 1/DLW_ of the G traffic.  g stays per lane.
-  static constexpr int DLW = kStatic ? DLW_ : 0;
+  static constexpr int DLW = (kStatic || kRolled) ? DLW_ : 0;   // (rolled: the run-time-K dimension-in-lane body, mtg_dimlane_rt.h)
   // LS_ > 0 (with DLW_): the LAST LS_ of the WS_ workspace steps (the ones next to the register steps) are kept in the
   // wave's LDS instead of global memory -- same row layout, row stride 64 lanes (MtgParams::lds_steps).
   static constexpr int LSJ = (kStatic && DLW_ > 0) ? LS_ : 0;
@@ -116,7 +116,7 @@ struct MtgCfg {
   // RS_ != 0 (with DLW_): the REGISTER steps keep G shared as well -- lane of dimension k holds elements k, DLW + k, ... of
   // G (GROWS doubles instead of up to H * H) and fetches its siblings' elements with ds_bpermute at back-substitution time
   // (the three lanes of a trajectory compute identical G): half the registers per step, i.e. twice the steps on chip.
-  static constexpr bool kRegShared = kStatic && DLW_ > 0 && RS_ != 0;
+  static constexpr bool kRegShared = (kStatic || kRolled) && DLW_ > 0 && RS_ != 0;
   static constexpr int GROWS = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW : 1;
   static constexpr int FULL = (1 << H_) - 1;
   // static mode: fixed-slot column prefix and the column range each direction touches
@@ -1058,7 +1058,14 @@ MTG_HD void mtg_rs_pack(int d, const double (&G)[C::H][C::H], int ml, int mr, do
       if ((mr >> q) & 1) continue;
       cand[cnt % DL] = G[p][q];
       ++cnt;
-      if (cnt % DL == 0) Gs[cnt / DL - 1] = mtg_pick<DL>(d, cand);
+      if (cnt % DL == 0) {
+        Gs[cnt / DL - 1] = mtg_pick<DL>(d, cand);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the share is materialised HERE: without the opaque use the selects are sunk to the back-substitution, and all of
+        // G stays live in between (measured in the run-time-K body: ~50 instead of ~20 registers per register step)
+        asm volatile("" : "+v"(Gs[cnt / DL - 1]));
+#endif
+      }
     }
   }
   if (cnt % DL != 0) {   // last, partial row: the lanes beyond it keep a duplicate that is never read
@@ -1066,6 +1073,9 @@ MTG_HD void mtg_rs_pack(int d, const double (&G)[C::H][C::H], int ml, int mr, do
     for (int k = 1; k < DL; ++k)
       if (k >= cnt % DL) cand[k] = cand[0];
     Gs[cnt / DL] = mtg_pick<DL>(d, cand);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(Gs[cnt / DL]));
+#endif
   }
 }
 #if defined(__HIP_DEVICE_COMPILE__)

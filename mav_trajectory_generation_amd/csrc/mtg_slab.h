@@ -302,4 +302,204 @@ struct MtgSlabOut {
   }
 };
 
+
+// ---- run-time chain length ---------------------------------------------------------------------------------------------
+// The same output scheme for kernels whose number of segments K is a RUN-TIME value (mtg_dimlane_rt.h: one body per N for
+// every chain length).  Dimension-in-lane layout only (LPT lanes per trajectory, one dimension per lane), ring of two segment
+// slots per trajectory, row mapping (a store instruction covers RPI rows of CHP 16-byte chunk slots; CHP = the largest range
+// in chunks: 12 / 16 / 20 for N = 8 / 10 / 12 with three dimensions).  Ranges are 64-byte aligned relative to the trajectory's
+// piece; when K * S is not a multiple of 64 bytes (N = 10: K mod 4 != 0; N = 12: odd K) they are misaligned in memory for
+// some rows -- every byte is still written exactly once, those rows' sectors just take two stores (the static variants'
+// phase mapping is not reproduced here).
+template <int N_, int LPT, int DIR, int AUX, bool PEND = true>
+struct MtgSlabOutRt {
+  static constexpr int N = N_;
+  static constexpr int LB = N * 8;                   // bytes one lane contributes per segment
+  static constexpr int S = LPT * LB;                 // bytes of one segment (all dimensions of the trajectory)
+  static constexpr int TPW = 64 / LPT;
+  static_assert(S >= 64, "ring layout needs segments of at least one sector");
+  static constexpr int MAXCH = (S % 64 == 0) ? S / 16 : (S / 64 + 1) * 4;   // chunks of the largest range (a range never exceeds S rounded up to 64)
+  static constexpr int RPI = 64 / MAXCH;             // trajectories per store instruction
+  static constexpr int MAXI = (TPW + RPI - 1) / RPI; // store instructions per range
+  static constexpr int ROWB = (((2 * S) / 16) | 1) * 16;   // two segment slots, odd number of 16-byte units
+  static constexpr int NPV = PEND ? MAXI + 1 : 1;   // (+ 1: the tail pass of direction B's last segment)
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  char* slab;
+  int lane, t, d;
+  int K, KA;            // run-time chain length; KA = (K + 1) / 2 segments belong to direction A
+  unsigned piece;       // K * S
+  __amdgpu_buffer_rsrc_t rsrc;
+  u4 pv[NPV];
+  unsigned pg[NPV];
+  int pn;
+  unsigned gl_row, gl_chunk, ll;   // this lane's (row, chunk) of a store instruction: row * piece is added per tile (piece is run-time)
+
+  static __device__ __forceinline__ int up64(int x) { return (x + 63) & ~63; }
+  static __device__ __forceinline__ int dn64(int x) { return x & ~63; }
+  __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_, int K_) {
+    slab = slab_; lane = lane_; t = t_; d = d_;
+    K = K_; KA = (K_ + 1) / 2;
+    piece = (unsigned)K_ * (unsigned)S;
+    pn = 0;
+    const unsigned tr = (unsigned)lane / (unsigned)MAXCH, rr = (unsigned)lane % (unsigned)MAXCH;
+    gl_row = tr;
+    gl_chunk = rr * 16u;
+    ll = tr * (unsigned)ROWB + rr * 16u;
+  }
+  __device__ __forceinline__ void begin_tile(double* coeffs, long long b0, long long B) {
+    char* gbase = reinterpret_cast<char*>(coeffs) + b0 * (long long)piece;
+    long long nvalid = B - b0;
+    if (nvalid > TPW) nvalid = TPW;
+    int nbytes = (int)nvalid * (int)piece;
+    const unsigned long long g = reinterpret_cast<unsigned long long>(gbase);
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)g);
+    const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(g >> 32));
+    gbase = reinterpret_cast<char*>(((unsigned long long)ghi << 32) | glo);
+    nbytes = __builtin_amdgcn_readfirstlane(nbytes);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
+    pn = 0;
+  }
+  __device__ __forceinline__ static void fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  __device__ __forceinline__ double* row(int seg) {
+    return reinterpret_cast<double*>(slab + t * ROWB + (seg & 1) * S + d * LB);
+  }
+  // the 64-byte-aligned range (relative to the piece) that segment `seg` completes; segments of direction A arrive
+  // KA-1, ..., 0 (the range grows downwards), of direction B KA, ..., K-1 (upwards)
+  __device__ __forceinline__ void range_of(int seg, int& lo, int& hi) const {
+    if (DIR > 0) {
+      lo = seg == 0 ? 0 : up64(seg * S);
+      hi = seg == KA - 1 ? KA * S : up64((seg + 1) * S);
+    } else {
+      lo = seg == KA ? KA * S : dn64(seg * S);
+      hi = dn64((seg + 1) * S);     // (the last segment's bytes beyond the last 64-byte boundary of the piece: tail pass)
+    }
+    if (hi < lo) hi = lo;
+  }
+  // Direction B, last segment: the piece ends K * S - dn64(K * S) bytes (0 .. 3 chunks) beyond the last 64-byte boundary; with
+  // them the range could exceed MAXCH chunks, so they go out in a pass of their own: lane -> (trajectory lane / 3, chunk
+  // lane % 3) -- 3 TPW <= 64 lanes, one store instruction.
+  __device__ __forceinline__ bool tail_chunk(int seg, unsigned& g, unsigned& loff) const {
+    if (DIR > 0 || seg != K - 1) return false;
+    const int at0 = dn64(K * S), ntail = (K * S - at0) >> 4;
+    if (ntail == 0) return false;                       // (wave-uniform)
+    const unsigned tt = (unsigned)lane / 3u, c = (unsigned)lane - tt * 3u;
+    const bool ok = tt < (unsigned)TPW && c < (unsigned)ntail;
+    const int at = at0 + (int)(c * 16u);
+    g = ok ? tt * piece + (unsigned)at : 0x7ffffff0u;
+    loff = ok ? tt * (unsigned)ROWB + (unsigned)((seg & 1) * S + at - seg * S) : 0u;
+    return true;
+  }
+  // LDS offset of chunk rr of range(seg) relative to ll: the chunks that belong to the neighbouring (earlier recovered)
+  // segment sit in the other ring slot
+  __device__ __forceinline__ unsigned slot_select(int seg, int lo, unsigned rr) const {
+    const int nb = DIR > 0 ? seg + 1 : seg - 1;
+    const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
+    const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
+    return (DIR > 0 ? (rr < (unsigned)cut) : (rr >= (unsigned)(cut > 0 ? cut : 0))) ? in_cur : in_nb;
+  }
+  __device__ __forceinline__ void chunk(int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
+    const unsigned rr = (unsigned)lane % (unsigned)MAXCH, tr = (unsigned)lane / (unsigned)MAXCH;
+    bool ok = rr < (unsigned)nch;
+    if (RPI * MAXCH < 64) ok = ok && tr < (unsigned)RPI;
+    if ((i + 1) * RPI > TPW) ok = ok && tr < (unsigned)(TPW - i * RPI);
+    g = ok ? (gl_row + (unsigned)(i * RPI)) * piece + gl_chunk + (unsigned)lo : 0x7ffffff0u;
+    loff = ll + sel + (unsigned)(i * RPI * ROWB);
+  }
+  __device__ __forceinline__ u4 lds_chunk(unsigned loff) const {
+    return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
+  }
+  __device__ __forceinline__ void store_pending() {
+    if constexpr (PEND) {
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) {
+        if (i < pn) __builtin_amdgcn_raw_buffer_store_b128(pv[i], rsrc, (int)pg[i], 0, AUX);
+      }
+      pn = 0;
+    } else {
+      if (pn == 0) return;
+      const int seg = pn - 1;
+      pn = 0;
+      int lo = 0, hi = 0;
+      range_of(seg, lo, hi);
+      const int nch = (hi - lo) >> 4;
+      const unsigned sel = slot_select(seg, lo, (unsigned)lane % (unsigned)MAXCH);
+      fence();
+      constexpr int G = 4;
+      if (hi > lo) {      // (wave-uniform)
+#pragma unroll
+        for (int i0 = 0; i0 < MAXI; i0 += G) {
+          u4 v[G];
+          unsigned g[G];
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            if (i0 + i < MAXI) {
+              unsigned loff = 0;
+              chunk(lo, nch, sel, i0 + i, g[i], loff);
+              v[i] = lds_chunk(loff);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            if (i0 + i < MAXI) __builtin_amdgcn_raw_buffer_store_b128(v[i], rsrc, (int)g[i], 0, AUX);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      {
+        unsigned g = 0, loff = 0;
+        if (tail_chunk(seg, g, loff)) __builtin_amdgcn_raw_buffer_store_b128(lds_chunk(loff), rsrc, (int)g, 0, AUX);
+      }
+      fence();
+    }
+  }
+  __device__ __forceinline__ void commit(const MtgParams&, int seg) {
+    fence();
+    if constexpr (PEND) {
+      int lo = 0, hi = 0;
+      range_of(seg, lo, hi);
+      __builtin_amdgcn_sched_barrier(0);
+      pn = 0;
+      if (hi > lo) {       // (wave-uniform)
+        const int nch = (hi - lo) >> 4;
+        const unsigned sel = slot_select(seg, lo, (unsigned)lane % (unsigned)MAXCH);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+          unsigned loff = 0;
+          chunk(lo, nch, sel, i, pg[i], loff);
+          pv[i] = lds_chunk(loff);
+        }
+        pn = MAXI;
+      }
+      {
+        unsigned g = 0, loff = 0;
+        if (tail_chunk(seg, g, loff)) {
+          if (pn == 0) {     // (no main range: unused slots store out of range)
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) pg[i] = 0x7ffffff0u;
+          }
+          pg[MAXI] = g;
+          pv[MAXI] = lds_chunk(loff);
+          pn = MAXI + 1;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fence();
+    } else {
+      pn = seg + 1;
+    }
+  }
+  __device__ __forceinline__ void drain(const MtgParams&) {
+    __builtin_amdgcn_sched_barrier(0);
+    store_pending();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush(const MtgParams& P) { drain(P); }
+};
+
 #endif  // MTG_SLAB_H_

@@ -423,6 +423,29 @@ int main() {
       (void)ok;
     }
   }
+  {   // the batched entry: a batch in which SOME trajectories are under-constrained -- here all share the structure, so a
+      // position-only K = 1 batch: every trajectory goes through the host fallback; the call returns true like the reference
+    const std::vector<uint32_t> masks{1u, 1u};
+    PolynomialOptimizationBatch<10> batch(3, masks);
+    const size_t B = 5;
+    std::vector<double> times(B), fixed(B * 3 * 2), coeffs(B * 1 * 3 * 10, -1.0), cost(B, -1.0);
+    for (size_t b = 0; b < B; ++b) {
+      times[b] = 1.0 + 0.25 * b;
+      for (int d = 0; d < 3; ++d) { fixed[(b * 3 + d) * 2 + 0] = 0.5 * d - b; fixed[(b * 3 + d) * 2 + 1] = 2.0 + d + 0.1 * b; }
+    }
+    const bool ok = batch.solveLinear(B, times.data(), fixed.data(), coeffs.data(), nullptr, cost.data());
+    EXPECT(ok, "batched rank-deficient solve returns true");
+    for (size_t b = 0; b < B; ++b) {
+      EXPECT(std::abs(cost[b]) < 1e-9, "batched rank-deficient cost %.3g", cost[b]);
+      for (int d = 0; d < 3; ++d) {
+        const double* c = &coeffs[(b * 3 + d) * 10];
+        double end = 0.0, tp = 1.0;
+        for (int j = 0; j < 10; ++j) { end += c[j] * tp; tp *= times[b]; }
+        EXPECT(std::abs(c[0] - fixed[(b * 3 + d) * 2]) < 1e-9 && std::abs(end - fixed[(b * 3 + d) * 2 + 1]) < 1e-8,
+               "batched rank-deficient end points b=%zu d=%d: %.12g %.12g", b, d, c[0], end);
+      }
+    }
+  }
   {   // a full-rank problem still goes through the library (rank == n_free)
     Vertex::Vector v = createRandomVertices(derivative_order::SNAP, 3, Eigen::VectorXd::Constant(3, -5.0),
                                             Eigen::VectorXd::Constant(3, 5.0), 11);

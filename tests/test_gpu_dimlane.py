@@ -264,3 +264,103 @@ def test_default_form_cross_over_is_pinned(ctx):
     odd = m.Plan(ctx, 10, 3, 8, 4, [31, 3, 1, 1, 7, 1, 1, 1, 31])     # ragged masks: the generic kernel
     assert odd.launch_form(5000) == "generic"
     odd.close()
+
+
+# ---- the run-time-K body (csrc/mtg_dimlane_rt.h): one kernel per polynomial order for every chain length ------------------
+@pytest.fixture(scope="module")
+def ctx_rt():
+    """A context that takes the run-time-K dimension-in-lane body even where a static variant exists (MTG_DL_RT=1 is read at
+    context creation)."""
+    import mav_trajectory_generation_amd as m
+    old = os.environ.get("MTG_DL_RT")
+    os.environ["MTG_DL_RT"] = "1"
+    try:
+        c = m.Context(0)
+    finally:
+        if old is None:
+            del os.environ["MTG_DL_RT"]
+        else:
+            os.environ["MTG_DL_RT"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [8, 10, 12])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 7, 8, 12, 13, 16, 21, 27, 32, 33, 40, 50, 51, 64, 100])
+@pytest.mark.parametrize("bsz", [1, 21, 22, 64, 300])
+def test_runtime_k_body(ctx, ctx_rt, n, k, bsz):
+    """Every chain length through ONE body per N: half-chains shorter than the register tail (skipped tail positions), chains
+    that fill the registers + the LDS step area exactly, chains that spill into the global workspace (K = 100: 50 steps per
+    direction), odd K (the two directions differ by one step), ragged batch sizes around the tile width; against the oracle
+    and -- where a static variant exists -- against that variant (same per-step arithmetic)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    d = n // 2 - 1
+    masks = m.ends_full_masks(n, k, 1)
+    t, f = m.random_waypoint_batch(bsz, k, 3, n, masks, seed=100 * n + k, device="cuda", layout="soa")
+    plan_rt = m.Plan(ctx_rt, n, 3, k, d, masks)
+    assert plan_rt.launch_form(bsz) == "dimlane_rt"
+    co = torch.full((bsz, k, 3, n), float("nan"), dtype=torch.float64, device="cuda")
+    plan_rt.solve(t, f, layout="soa", coeffs=co)
+    ctx_rt.sync()
+    assert torch.isfinite(co).all()
+    plan = m.Plan(ctx, n, 3, k, d, masks)
+    ref, _, _ = plan.solve(t, f, layout="soa")
+    ctx.sync()
+    rel, _ = ctx.compare_coefficients(co, ref)
+    assert rel < (1e-12 if n <= 10 else 1e-10), (plan.launch_form(bsz), rel)
+    nb = min(bsz, 6)
+    th, fh = t.t()[:nb].contiguous().cpu().numpy(), f.permute(2, 0, 1)[:nb].contiguous().cpu().numpy()
+    c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
+    assert helpers.poly_relerr(co[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    plan_rt.close()
+    plan.close()
+
+
+@pytest.mark.parametrize("n,k", [(8, 6), (10, 9), (10, 40), (12, 24), (12, 50)])
+def test_runtime_k_body_four_dimensions(ctx, n, k):
+    """x, y, z, yaw with position-only interior vertices: no static variant beyond K = 8 -- the run-time-K body by default."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    d = n // 2 - 1
+    masks = m.ends_full_masks(n, k, 1)
+    t, f = m.random_waypoint_batch(700, k, 4, n, masks, seed=9 * n + k, device="cuda", layout="soa", yaw_dim=True)
+    plan = m.Plan(ctx, n, 4, k, d, masks)
+    assert plan.launch_form(700) == "dimlane_rt"
+    co, _, _ = plan.solve(t, f, layout="soa")
+    ref, _, _ = plan.solve(t, f, layout="soa", dims="fused")
+    ctx.sync()
+    rel, _ = ctx.compare_coefficients(co, ref)
+    assert rel < (1e-11 if n <= 10 else 1e-9)
+    th, fh = t.t()[:5].contiguous().cpu().numpy(), f.permute(2, 0, 1)[:5].contiguous().cpu().numpy()
+    c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
+    assert helpers.poly_relerr(co[:5].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    plan.close()
+
+
+def test_runtime_k_body_is_the_default_beyond_the_static_variants(ctx):
+    import mav_trajectory_generation_amd as m
+    for (n, k, want) in ((12, 50, "dimlane_rt"), (10, 100, "dimlane_rt"), (8, 33, "dimlane_rt"), (10, 32, "dimlane"), (10, 50, "dimlane")):
+        plan = m.Plan(ctx, n, 3, k, n // 2 - 1, m.ends_full_masks(n, k, 1))
+        assert plan.launch_form(2500) == want, (n, k)
+        plan.close()
+
+
+def test_runtime_k_body_status(ctx_rt):
+    """Bad segment times are flagged per trajectory by the run-time-K body as well (head, LDS and tail steps)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 40)
+    plan = m.Plan(ctx_rt, 10, 3, 40, 4, masks)
+    t, f = m.random_waypoint_batch(100, 40, 3, 10, masks, seed=3, device="cuda", layout="soa")
+    bad = {5: 0, 17: 3, 44: 19, 63: 20, 99: 39}          # trajectory -> segment with a non-positive time
+    for b, seg in bad.items():
+        t[seg, b] = 0.0
+    st = torch.full((100,), 77, dtype=torch.int32, device="cuda")
+    plan.solve(t, f, layout="soa", traj_status=st)
+    with pytest.raises(m.MtgError) as e:
+        ctx_rt.sync()
+    assert e.value.code == -2
+    got = st.cpu().numpy()
+    assert sorted(np.nonzero(got & 1)[0].tolist()) == sorted(bad)
+    plan.close()

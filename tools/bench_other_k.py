@@ -6,11 +6,12 @@ import torch
 import mav_trajectory_generation_amd as m
 ctx = m.Context(0)
 NN = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for K in (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 20, 24, 27, 31, 50, 100):
+KS = [int(x) for x in os.environ["KS"].split(",")] if os.environ.get("KS") else (3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 17, 20, 24, 27, 31, 50, 100)
+for K in KS:
     masks = m.ends_full_masks(NN, K, 1)
     plan = m.Plan(ctx, NN, 3, K, NN // 2 - 1, masks)
     for B in (2500, 100_000):
-        if K * B > 3_000_000:
+        if K * B > int(os.environ.get("MAXKB", 3_000_000)):
             continue
         with torch.cuda.stream(ctx.stream):
             t, f = m.random_waypoint_batch(B, K, 3, NN, masks, seed=11, device="cuda", layout="soa")

@@ -81,3 +81,4 @@ with open(os.path.join(out, f"{tag}_kernel_trace_solve_launches.csv"), "w") as f
                     r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")),
                     r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""), r.get("SGPR_Count", "")])
 PY
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_calf $OUT/${TAG}_calw   # (raw traces: gpurun_out/ is capped at 64 MiB)

@@ -26,3 +26,4 @@ json.dump(res, open(os.path.join(out, f"{tag}_next_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 head -12 $OUT/${TAG}_next_kernel_stats.csv | cut -c1-160
+rm -rf $OUT/${TAG}_next_stats $OUT/${TAG}_next_FETCH_SIZE $OUT/${TAG}_next_WRITE_SIZE $OUT/${TAG}_next_SQ_INSTS_VALU $OUT/${TAG}_next_SQ_WAIT_INST_ANY   # (raw traces: gpurun_out/ is capped at 64 MiB)
