@@ -112,19 +112,23 @@ def cpu_baseline(n_sample, seed):
     return out
 
 
-def profile_traffic(batch):
-    """HBM bytes per launch as measured by the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json): evidence
-    from a separate profiling run of the same command, NOT measured in this run -- hence its own key and the file name."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        if d.get("batch") == batch:
-            return {"file": os.path.relpath(path, ROOT), "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
-                    "note": d.get("note", "separate rocprofv3 --pmc run of this command")}
-    return None
+def profile_traffic(batch, config):
+    """HBM bytes per STEP (one batch / one mixed request) as measured by the committed rocprofv3 PMC passes
+    (profiles/r03_*_pmc_traffic.json): evidence from a separate profiling run of this command, NOT measured in this run --
+    hence its own key and the file name."""
+    name = {2: "r03_driver_args_pmc_traffic.json", 4: "r03_config4_pmc_traffic.json"}.get(config)
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("batch") != batch:
+        return None
+    return {"file": os.path.relpath(path, ROOT), "hbm_bytes_per_step": d.get("hbm_bytes_per_step"),
+            "algorithmic_bytes_per_step": d.get("algorithmic_bytes_per_step"), "bench_args_of_the_profile": d.get("bench_args"),
+            "note": d.get("note", "separate rocprofv3 --pmc run of this command")}
 
 
 class SolveLoop:
@@ -171,20 +175,27 @@ class SolveLoop:
 
 class MixedLoop:
     """BASELINE config 4: one step = ONE mixed request of 12 buckets (N in {8, 10, 12} x K in {4, 8, 16, 32}, D = 3) x
-    `per_bucket` trajectories = one mtg_multi_solve call (one cross-structure kernel launch); rotating over the buffer sets
-    (each set = its own inputs and outputs for all twelve buckets)."""
+    `per_bucket` trajectories, rotating over the buffer sets (each set = its own inputs and outputs for all twelve buckets).
+    per_step_call=True: one mtg_multi_solve call (one cross-structure kernel launch) per step -- the latency form.
+    per_step_call=False (default, the analogue of the queue of config 2): the K independent requests of a timed region are
+    handed to the library as ONE request of 12 K items (mtg_multi_create takes any number of items), i.e. one cross-structure
+    launch whose persistent workgroups are assigned the units of all K requests by the longest-processing-time schedule."""
 
     SHAPES = [(n, d, k) for (n, d) in ((8, 3), (10, 4), (12, 5)) for k in (4, 8, 16, 32)]
 
-    def __init__(self, m, ctx, per_bucket, nsets, dev, seed):
+    def __init__(self, m, ctx, per_bucket, nsets, dev, seed, per_step_call=False):
         self.solver = m.MixedBatchSolver(ctx, n_streams=1)
-        self.reqs, self.bytes_per_step = [], 0
+        self.per_step_call = per_step_call
+        self.sets, self.reqs, self.merged = [], [], {}
+        import torch
         for s in range(nsets):
             buckets = []
             for (n, d, k) in self.SHAPES:
                 masks = m.ends_full_masks(n, k, 1)
                 t, f = m.random_waypoint_batch(per_bucket, k, 3, n, masks, seed=seed + 1000 * s + k + n, device=dev, layout="soa")
-                buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
+                co = torch.zeros((per_bucket, k, 3, n), dtype=torch.float64, device=dev)
+                buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa", coeffs=co))
+            self.sets.append(buckets)
             self.reqs.append(self.solver.merged(buckets))
         # SURVEY 8(d): position-only interior vertices => n_fixed = N + K - 1
         self.bytes_per_step = sum(per_bucket * 8 * (k + 3 * (n + k - 1) + k * 3 * n) for (n, _, k) in self.SHAPES)
@@ -192,20 +203,37 @@ class MixedLoop:
         self.launches_per_step = self.reqs[0].launch_count
 
     def prepare(self, steps, first=0):
-        pass
+        """The merged request of a (steps, first) sequence is created once, outside any timed region (plan lookups, unit
+        schedule, two small uploads)."""
+        if self.per_step_call or steps <= 0:
+            return
+        key = (steps, first % len(self.sets))
+        if key not in self.merged:
+            n = len(self.sets)
+            items = [b for i in range(steps) for b in self.sets[(first + i) % n]]
+            self.merged[key] = self.solver.merged(items)
+
+    def launches(self, steps):
+        return steps * self.launches_per_step if self.per_step_call else self.launches_per_step
 
     def run(self, steps, first=0, start_event=None, stop_event=None):
+        if steps <= 0:
+            return
         stream = self.solver.ctx.stream
+        self.prepare(steps, first)
         if start_event is not None:
             start_event.record(stream)
-        n = len(self.reqs)
-        for i in range(steps):
-            self.reqs[(first + i) % n].solve()
+        if self.per_step_call:
+            n = len(self.reqs)
+            for i in range(steps):
+                self.reqs[(first + i) % n].solve()
+        else:
+            self.merged[(steps, first % len(self.sets))].solve()
         if stop_event is not None:
             stop_event.record(stream)
 
     def outputs(self):
-        return [co for r in self.reqs for (co, _) in r.out]
+        return [b["coeffs"] for s in self.sets for b in s]
 
 
 def next_rows(m, ctx, plan, sets, B, K, D, N):
@@ -334,7 +362,7 @@ def main():
 
     with torch.cuda.stream(ctx.stream):
         if mixed:
-            loop = MixedLoop(m, ctx, B, nsets, dev, 1234 + rank)
+            loop = MixedLoop(m, ctx, B, nsets, dev, 1234 + rank, per_step_call=per_batch)
             sets = None
             bytes_per_step, traj_per_step = loop.bytes_per_step, loop.per_step
             set_bytes = bytes_per_step
@@ -391,8 +419,14 @@ def main():
 
         extra, fill_us = {}, None
         if rank == 0 and not args.no_extras and mixed:
-            us, wall = side_run(loop, 200)
-            extra["rotating_buffers_200_steps"] = side_entry(us, wall, 200, nsets)
+            us, wall = side_run(loop, 96, warm=16)
+            extra["rotating_buffers_96_steps"] = side_entry(us, wall, 96, nsets)
+            other = MixedLoop(m, ctx, B, nsets, dev, 1234 + rank, per_step_call=not per_batch)
+            other.run(nsets)
+            us, wall = side_run(other, 96, warm=16)
+            extra["one_launch_per_request" if not per_batch else "requests_merged_into_one_launch"] = dict(
+                side_entry(us, wall, 96, nsets), note="one mtg_multi_solve call (one cross-structure launch) per mixed request"
+                if not per_batch else "the 96 requests as one 12 x 96-item request")
         if rank == 0 and not args.no_extras and not mixed:
             big = set_bytes * nsets > 8 * 2**30          # config 3: keep the extras short
             long_steps = 200 if big else 2000
@@ -506,12 +540,16 @@ def main():
     if rank == 0:
         achieved = bytes_per_step / (step_us * 1e-6) / 1e9
         if mixed:
-            form = (f"ONE library call (mtg_multi_solve) = {loop.launches_per_step} cross-structure kernel launch(es) per step")
+            form = (f"ONE library call (mtg_multi_solve) = {loop.launches_per_step} cross-structure kernel launch(es) per step"
+                    if per_batch else
+                    f"the {args.steps} timed steps are {args.steps} independent requests handed to the library as ONE request of "
+                    f"{12 * args.steps} items (mtg_multi_create / mtg_multi_solve) = {loop.launches_per_step} cross-structure kernel "
+                    f"launch(es); one launch per request: extra.one_launch_per_request")
             what = (f"mixed request of {traj_per_step} random-waypoint trajectories per GPU per step ({cfg['name']}): 12 buckets = "
                     f"N in {{8 jerk, 10 snap, 12}} x K in {{4, 8, 16, 32}} segments x {B} trajectories, dim=3; {form}; rotating "
                     f"over {nsets} independent input/output buffer sets ({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; "
                     f"inputs SOA, coeffs [B][K][D][N] per bucket")
-            launches, batches_per_launch = args.steps * loop.launches_per_step, None
+            launches, batches_per_launch = loop.launches(args.steps), (None if per_batch else args.steps)
         else:
             queue = not per_batch
             launches = (args.steps + 95) // 96 if queue else args.steps
@@ -541,7 +579,7 @@ def main():
                        "trajectories_per_step": traj_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_from_profile": profile_traffic(traj_per_step),
+                         "traffic_from_profile": profile_traffic(traj_per_step, args.config),
                          "kernel_us": step_us * args.steps / launches, "launches": launches,
                          "batches_per_launch": batches_per_launch,
                          "bytes_per_launch": bytes_per_step * args.steps / launches,

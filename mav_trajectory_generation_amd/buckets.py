@@ -160,7 +160,7 @@ class ConcurrentRequest:
             layout = b.get("layout", "aos")
             dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
             plan = solver.plan_for(int(b["n_coeffs"]), dim, len(b["masks"]) - 1, int(b["derivative"]), b["masks"], 0)
-            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout))
+            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout, coeffs=b.get("coeffs")))   # (caller-owned output tensor, optional)
         self.multi = MultiSolve(solver.ctx, items, want_cost=want_cost, dims="concurrent")
         self.out = [(it["coeffs"], it["cost"]) for it in self.multi.items]
         self.launch_count = self.multi.launch_count
@@ -190,7 +190,7 @@ class MergedRequest:
             layout = b.get("layout", "aos")
             dim = b["d_fixed"].shape[1] if layout == "aos" else b["d_fixed"].shape[0]
             plan = solver.plan_for(int(b["n_coeffs"]), dim, len(b["masks"]) - 1, int(b["derivative"]), b["masks"], 0)
-            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout))
+            items.append(dict(plan=plan, times=b["times"], d_fixed=b["d_fixed"], layout=layout, coeffs=b.get("coeffs")))   # (caller-owned output tensor, optional)
         # launch geometry (dims = 'auto'): the library looks at the whole request
         ms = MultiSolve(solver.ctx, items, want_cost=want_cost, dims=dims)
         self.multis: List[MultiSolve] = [ms]

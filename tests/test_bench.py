@@ -86,6 +86,8 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     assert "resident_buffers" in out["extra"]
     one = out["extra"]["one_launch_per_batch"]          # the latency form: reported beside, never as `value`
     assert one["steps"] == 200 and one["us_per_step"] > rf["device_us_per_step"]
+    nx = out["extra"]["next"]                           # SURVEY 8(f) rows in the default line
+    assert nx["sample"]["roofline"]["frac"] > 0 and nx["extrema"]["us"] > 0 and nx["mellinger"]["us"] > 0 and nx["time_scaling"]["us"] > 0
 
 
 @pytest.mark.gpu
@@ -102,4 +104,6 @@ def test_latency_form_and_config4_lines():
     want = sum(2500 * 8 * (k + 3 * (n + k - 1) + k * 3 * n) for n in (8, 10, 12) for k in (4, 8, 16, 32))
     assert out["config"]["baseline_config"] == 4 and out["config"]["trajectories_per_step"] == 30_000
     assert out["roofline"]["bytes_per_step"] == want and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["launches"] == 1 and out["roofline"]["batches_per_launch"] == 10     # 10 requests, one launch
+    assert out["extra"]["one_launch_per_request"]["us_per_step"] > 0
     assert "cpu_baseline" not in out
