@@ -206,13 +206,14 @@ template <class C, int DL>
 __host__ __device__ constexpr size_t mtg_rt_half_bytes() {
   constexpr int fmid = C::H - C::popc(C::MI);
   constexpr size_t xch = (size_t)(fmid * (fmid + 1) / 2 + fmid) * kWave * sizeof(double);
-  constexpr size_t slab = ((size_t)MtgSlabOutRt<C::N, DL, 1, 0>::TPW * MtgSlabOutRt<C::N, DL, 1, 0>::ROWB + 15) / 16 * 16;
+  constexpr size_t slab = ((size_t)MtgSlabOutRt<C::N, DL, 1, 0, false>::TPW * MtgSlabOutRt<C::N, DL, 1, 0, false>::ROWB + 15) / 16 * 16;
   return slab > xch ? slab : xch;
 }
 template <class C, int DL, int L>
 __host__ __device__ constexpr size_t mtg_rt_lds_bytes() { return 2 * mtg_rt_half_bytes<C, DL>() + 2 * (size_t)L * mtg_rt_step_bytes<C>(); }
 
-template <class C, int DL, int R, int L, int AUX>
+// PHASE: instantiation for chain lengths whose K * (DL N 8)-byte pieces are not a multiple of 64 bytes (MtgSlabOutRt)
+template <class C, int DL, int R, int L, int AUX, bool PHASE>
 __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const double* __restrict__ times, const double* __restrict__ dfix,
                                                                      double* __restrict__ coeffs, int* status, int* traj_status,
                                                                      int B, int K, int ntiles, double* ws, int ws_steps) {
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const dou
   (void)ws_steps;
   double* mine = reinterpret_cast<double*>(lds_raw + (size_t)(1 - dir) * half) + lane;
   const double* other = reinterpret_cast<const double*>(my_slab) + lane;
-  MtgSlabOutRt<C::N, DL, 1, AUX> ioA;
-  MtgSlabOutRt<C::N, DL, -1, AUX> ioB;
+  MtgSlabOutRt<C::N, DL, 1, AUX, PHASE> ioA;
+  MtgSlabOutRt<C::N, DL, -1, AUX, PHASE> ioB;
   ioA.init(my_slab, lane, t, d, K);
   ioB.init(my_slab, lane, t, d, K);
   MtgLane<C> ln;

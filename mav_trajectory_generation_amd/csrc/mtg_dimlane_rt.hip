@@ -9,17 +9,24 @@ template <class C, int DL, int R, int L>
 int launch_rt(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status, int* traj_status,
               int B, int K, int ntiles, double* ws) {
   constexpr size_t lds = mtg_rt_lds_bytes<C, DL, L>();
-  static bool attr_set[kMaxDevices] = {};
+  static bool attr_set[2][kMaxDevices] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
-  auto kern = mtg_solve_dl_rt_kernel<C, DL, R, L, 18>;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    attr_set[dev] = true;
+  // two instantiations: pieces of K * DL * N * 8 bytes that are a multiple of 64 bytes, and the others (per-row phase maps)
+  const bool phase = ((long long)K * DL * C::N * 8) % 64 != 0;
+  auto go = [&](auto kern, bool& done) -> int {
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, times, dfix, coeffs, status, traj_status, B, K,
+                       ntiles, ws, 0);
+    return 0;
+  };
+  if constexpr ((DL * C::N * 8) % 64 != 0) {
+    if (phase) return go(mtg_solve_dl_rt_kernel<C, DL, R, L, 18, true>, attr_set[1][dev]);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, times, dfix, coeffs, status, traj_status, B, K,
-                     ntiles, ws, 0);
-  return 0;
+  return go(mtg_solve_dl_rt_kernel<C, DL, R, L, 18, false>, attr_set[0][dev]);
 }
 #define MTG_RTCFG(H, MS, MI, ME, DV, DL) MtgCfg<H, 1, -1, MS, MI, ME, DV, 0, 0, DL, 0, 1>
 #define MTG_RT(H, MS, MI, ME, DV, DL, R, L)                                                                      \

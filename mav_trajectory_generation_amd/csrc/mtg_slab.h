@@ -2,6 +2,8 @@
 // mtg_dimlane.h, and the slab-output instantiations of the fused kernel, mtg_kernels.h).
 #ifndef MTG_SLAB_H_
 #define MTG_SLAB_H_
+#include <type_traits>
+
 #include "mtg_lane.h"
 
 // Coefficient output of one wave (one chain direction of TPW trajectories, all dimensions) through an LDS slab.
@@ -306,34 +308,44 @@ struct MtgSlabOut {
 // ---- run-time chain length ---------------------------------------------------------------------------------------------
 // The same output scheme for kernels whose number of segments K is a RUN-TIME value (mtg_dimlane_rt.h: one body per N for
 // every chain length).  Dimension-in-lane layout only (LPT lanes per trajectory, one dimension per lane), ring of two segment
-// slots per trajectory, row mapping (a store instruction covers RPI rows of CHP 16-byte chunk slots; CHP = the largest range
-// in chunks: 12 / 16 / 20 for N = 8 / 10 / 12 with three dimensions).  Ranges are 64-byte aligned relative to the trajectory's
-// piece; when K * S is not a multiple of 64 bytes (N = 10: K mod 4 != 0; N = 12: odd K) they are misaligned in memory for
-// some rows -- every byte is still written exactly once, those rows' sectors just take two stores (the static variants'
-// phase mapping is not reproduced here).
-template <int N_, int LPT, int DIR, int AUX, bool PEND = true>
+// slots per trajectory, row mapping (a store instruction covers RPI rows of MAXCH 16-byte chunk slots; MAXCH = the largest
+// range in chunks: 12 / 16 / 20 for N = 8 / 10 / 12 with three dimensions).
+// When K * S is not a multiple of 64 bytes (N = 10: K mod 4 != 0; N = 12: odd K) consecutive trajectories' pieces shift against
+// the 64-byte grid, and ranges aligned relative to the piece would be misaligned in memory for most rows (partial sectors:
+// measured 1.2x -> 1.5x the static variants' time for those K).  As in MtgSlabOut's phase mapping every row's ranges are then
+// aligned in MEMORY: row r of the tile has phase phi = ((b0 + r) * (K S mod 64)) mod 64 and its ranges are [up64(seg S + phi)
+// - phi, ...); the piece's misaligned head (direction A, segment 0) / tail (direction B, last segment; also the < 64 bytes
+// beyond the last boundary when the piece is aligned) go out in a pass of their own.  A wave-uniform branch: aligned pieces
+// (phase 0 everywhere) keep the cheaper maps.
+// PHASE: compiled for pieces that are NOT a multiple of 64 bytes (the per-row phase maps); false: aligned pieces only.  Two
+// instantiations of the kernel instead of a run-time branch: with both maps in one body the aligned chain lengths lost 4-10 %.
+template <int N_, int LPT, int DIR, int AUX, bool PHASE, bool PEND = true>
 struct MtgSlabOutRt {
   static constexpr int N = N_;
   static constexpr int LB = N * 8;                   // bytes one lane contributes per segment
   static constexpr int S = LPT * LB;                 // bytes of one segment (all dimensions of the trajectory)
   static constexpr int TPW = 64 / LPT;
   static_assert(S >= 64, "ring layout needs segments of at least one sector");
+  static_assert(3 * TPW <= 64, "the head / tail pass maps lane -> (trajectory lane / 3, chunk lane % 3)");
   static constexpr int MAXCH = (S % 64 == 0) ? S / 16 : (S / 64 + 1) * 4;   // chunks of the largest range (a range never exceeds S rounded up to 64)
   static constexpr int RPI = 64 / MAXCH;             // trajectories per store instruction
   static constexpr int MAXI = (TPW + RPI - 1) / RPI; // store instructions per range
   static constexpr int ROWB = (((2 * S) / 16) | 1) * 16;   // two segment slots, odd number of 16-byte units
-  static constexpr int NPV = PEND ? MAXI + 1 : 1;   // (+ 1: the tail pass of direction B's last segment)
+  static constexpr int NPV = PEND ? MAXI + 1 : 1;    // (+ 1: the head / tail pass)
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   char* slab;
   int lane, t, d;
   int K, KA;            // run-time chain length; KA = (K + 1) / 2 segments belong to direction A
   unsigned piece;       // K * S
+  int pmod;             // piece mod 64: 0 = every row aligned
   __amdgpu_buffer_rsrc_t rsrc;
   u4 pv[NPV];
   unsigned pg[NPV];
   int pn;
-  unsigned gl_row, gl_chunk, ll;   // this lane's (row, chunk) of a store instruction: row * piece is added per tile (piece is run-time)
+  unsigned gl_row, gl, ll;   // this lane's row of a store instruction; its (row, chunk) part of the global / LDS byte offset
+  unsigned ph0;         // (first trajectory of the tile) mod 4
+  int phi_l;            // phase of this lane's row of pass 0
 
   static __device__ __forceinline__ int up64(int x) { return (x + 63) & ~63; }
   static __device__ __forceinline__ int dn64(int x) { return x & ~63; }
@@ -341,10 +353,12 @@ struct MtgSlabOutRt {
     slab = slab_; lane = lane_; t = t_; d = d_;
     K = K_; KA = (K_ + 1) / 2;
     piece = (unsigned)K_ * (unsigned)S;
+    pmod = (int)(piece & 63u);
     pn = 0;
+    ph0 = 0; phi_l = 0;
     const unsigned tr = (unsigned)lane / (unsigned)MAXCH, rr = (unsigned)lane % (unsigned)MAXCH;
     gl_row = tr;
-    gl_chunk = rr * 16u;
+    gl = tr * piece + rr * 16u;
     ll = tr * (unsigned)ROWB + rr * 16u;
   }
   __device__ __forceinline__ void begin_tile(double* coeffs, long long b0, long long B) {
@@ -359,6 +373,8 @@ struct MtgSlabOutRt {
     nbytes = __builtin_amdgcn_readfirstlane(nbytes);
     rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, nbytes, 0x00020000);
     pn = 0;
+    ph0 = (unsigned)(b0 & 3);
+    phi_l = (int)(((ph0 + gl_row) * (unsigned)pmod) & 63u);
   }
   __device__ __forceinline__ static void fence() {
     asm volatile("" ::: "memory");
@@ -368,47 +384,62 @@ struct MtgSlabOutRt {
   __device__ __forceinline__ double* row(int seg) {
     return reinterpret_cast<double*>(slab + t * ROWB + (seg & 1) * S + d * LB);
   }
-  // the 64-byte-aligned range (relative to the piece) that segment `seg` completes; segments of direction A arrive
-  // KA-1, ..., 0 (the range grows downwards), of direction B KA, ..., K-1 (upwards)
-  __device__ __forceinline__ void range_of(int seg, int& lo, int& hi) const {
+  // the range that segment `seg` completes for a row of phase phi, relative to the row's piece: 64-byte aligned in memory.
+  // Segments of direction A arrive KA-1, ..., 0 (the range grows downwards), of direction B KA, ..., K-1 (upwards).  The
+  // piece's head [0, (64 - phi) mod 64) and tail [dn64(K S + phi) - phi, K S) are NOT part of the first / last range.
+  __device__ __forceinline__ void range_of(int seg, int phi, int& lo, int& hi) const {
     if (DIR > 0) {
-      lo = seg == 0 ? 0 : up64(seg * S);
-      hi = seg == KA - 1 ? KA * S : up64((seg + 1) * S);
+      lo = ((seg * S + phi + 63) & ~63) - phi;
+      hi = seg == KA - 1 ? KA * S : (((seg + 1) * S + phi + 63) & ~63) - phi;
     } else {
-      lo = seg == KA ? KA * S : dn64(seg * S);
-      hi = dn64((seg + 1) * S);     // (the last segment's bytes beyond the last 64-byte boundary of the piece: tail pass)
+      lo = seg == KA ? KA * S : ((seg * S + phi) & ~63) - phi;
+      hi = (((seg + 1) * S + phi) & ~63) - phi;
     }
     if (hi < lo) hi = lo;
   }
-  // Direction B, last segment: the piece ends K * S - dn64(K * S) bytes (0 .. 3 chunks) beyond the last 64-byte boundary; with
-  // them the range could exceed MAXCH chunks, so they go out in a pass of their own: lane -> (trajectory lane / 3, chunk
-  // lane % 3) -- 3 TPW <= 64 lanes, one store instruction.
-  __device__ __forceinline__ bool tail_chunk(int seg, unsigned& g, unsigned& loff) const {
-    if (DIR > 0 || seg != K - 1) return false;
-    const int at0 = dn64(K * S), ntail = (K * S - at0) >> 4;
-    if (ntail == 0) return false;                       // (wave-uniform)
-    const unsigned tt = (unsigned)lane / 3u, c = (unsigned)lane - tt * 3u;
-    const bool ok = tt < (unsigned)TPW && c < (unsigned)ntail;
-    const int at = at0 + (int)(c * 16u);
-    g = ok ? tt * piece + (unsigned)at : 0x7ffffff0u;
-    loff = ok ? tt * (unsigned)ROWB + (unsigned)((seg & 1) * S + at - seg * S) : 0u;
-    return true;
-  }
-  // LDS offset of chunk rr of range(seg) relative to ll: the chunks that belong to the neighbouring (earlier recovered)
-  // segment sit in the other ring slot
+  // LDS offset of chunk rr of a range starting at lo, relative to ll: the chunks that belong to the neighbouring (earlier
+  // recovered) segment sit in the other ring slot
   __device__ __forceinline__ unsigned slot_select(int seg, int lo, unsigned rr) const {
     const int nb = DIR > 0 ? seg + 1 : seg - 1;
     const int cut = DIR > 0 ? ((seg + 1) * S - lo) >> 4 : (seg * S - lo) >> 4;   // first chunk of the upper segment
     const unsigned in_cur = (unsigned)((seg & 1) * S + lo - seg * S), in_nb = (unsigned)((nb & 1) * S + lo - nb * S);
     return (DIR > 0 ? (rr < (unsigned)cut) : (rr >= (unsigned)(cut > 0 ? cut : 0))) ? in_cur : in_nb;
   }
-  __device__ __forceinline__ void chunk(int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
+  // store instruction i of range(seg): global byte offset (out of range for lanes without a chunk) and LDS byte offset.
+  // PHASE = false: aligned pieces, the range [lo, lo + 16 nch) and the slot selection `sel` are the same for every row;
+  // PHASE = true: per-row ranges.
+  __device__ __forceinline__ void chunk(int seg, int lo, int nch, unsigned sel, int i, unsigned& g, unsigned& loff) const {
     const unsigned rr = (unsigned)lane % (unsigned)MAXCH, tr = (unsigned)lane / (unsigned)MAXCH;
-    bool ok = rr < (unsigned)nch;
+    bool ok = true;
     if (RPI * MAXCH < 64) ok = ok && tr < (unsigned)RPI;
     if ((i + 1) * RPI > TPW) ok = ok && tr < (unsigned)(TPW - i * RPI);
-    g = ok ? (gl_row + (unsigned)(i * RPI)) * piece + gl_chunk + (unsigned)lo : 0x7ffffff0u;
-    loff = ll + sel + (unsigned)(i * RPI * ROWB);
+    if constexpr (!PHASE) {
+      ok = ok && rr < (unsigned)nch;
+      g = ok ? gl + (unsigned)(i * RPI) * piece + (unsigned)lo : 0x7ffffff0u;      // (pass offset and lo: scalar)
+      loff = ll + sel + (unsigned)(i * RPI * ROWB);
+    } else {
+      const int phi = (int)(((unsigned)phi_l + (unsigned)(i * RPI) * (unsigned)pmod) & 63u);   // phase of row tr + i RPI
+      int lo_l, hi_l;
+      range_of(seg, phi, lo_l, hi_l);
+      ok = ok && (int)(rr * 16u) < hi_l - lo_l;
+      g = ok ? gl + (unsigned)(i * RPI) * piece + (unsigned)lo_l : 0x7ffffff0u;
+      loff = ll + slot_select(seg, lo_l, rr) + (unsigned)(i * RPI * ROWB);
+    }
+  }
+  // The head (direction A, segment 0) / tail (direction B, last segment) of every row's piece: up to 3 chunks per row,
+  // lane -> (trajectory lane / 3, chunk lane % 3) -- one store instruction.  false: this segment has no such pass.
+  __device__ __forceinline__ bool edge_chunk(int seg, unsigned& g, unsigned& loff) const {
+    if (!(DIR > 0 ? seg == 0 : seg == K - 1)) return false;            // (wave-uniform)
+    if constexpr (!PHASE) return false;                                // aligned pieces have neither head nor tail
+    const unsigned tt = (unsigned)lane / 3u, c = (unsigned)lane - tt * 3u;
+    const int ph = (int)(((ph0 + tt) * (unsigned)pmod) & 63u);
+    const int start = DIR > 0 ? 0 : ((K * S + ph) & ~63) - ph;
+    const int end = DIR > 0 ? ((64 - ph) & 63) : K * S;
+    const int at = start + (int)(c * 16u);
+    const bool ok = tt < (unsigned)TPW && at < end;
+    g = ok ? tt * piece + (unsigned)at : 0x7ffffff0u;
+    loff = ok ? tt * (unsigned)ROWB + (unsigned)((seg & 1) * S + at - seg * S) : 0u;
+    return true;
   }
   __device__ __forceinline__ u4 lds_chunk(unsigned loff) const {
     return __builtin_bit_cast(u4, *reinterpret_cast<const d2*>(slab + loff));
@@ -425,12 +456,13 @@ struct MtgSlabOutRt {
       const int seg = pn - 1;
       pn = 0;
       int lo = 0, hi = 0;
-      range_of(seg, lo, hi);
+      range_of(seg, 0, lo, hi);
       const int nch = (hi - lo) >> 4;
       const unsigned sel = slot_select(seg, lo, (unsigned)lane % (unsigned)MAXCH);
       fence();
       constexpr int G = 4;
-      if (hi > lo) {      // (wave-uniform)
+      auto pass = [&](auto phase) {
+        (void)phase;
 #pragma unroll
         for (int i0 = 0; i0 < MAXI; i0 += G) {
           u4 v[G];
@@ -439,7 +471,7 @@ struct MtgSlabOutRt {
           for (int i = 0; i < G; ++i) {
             if (i0 + i < MAXI) {
               unsigned loff = 0;
-              chunk(lo, nch, sel, i0 + i, g[i], loff);
+              chunk(seg, lo, nch, sel, i0 + i, g[i], loff);
               v[i] = lds_chunk(loff);
             }
           }
@@ -450,10 +482,11 @@ struct MtgSlabOutRt {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+      };
+      if (PHASE || hi > lo) pass(std::integral_constant<bool, PHASE>());      // (wave-uniform)
       {
         unsigned g = 0, loff = 0;
-        if (tail_chunk(seg, g, loff)) __builtin_amdgcn_raw_buffer_store_b128(lds_chunk(loff), rsrc, (int)g, 0, AUX);
+        if (edge_chunk(seg, g, loff)) __builtin_amdgcn_raw_buffer_store_b128(lds_chunk(loff), rsrc, (int)g, 0, AUX);
       }
       fence();
     }
@@ -462,23 +495,23 @@ struct MtgSlabOutRt {
     fence();
     if constexpr (PEND) {
       int lo = 0, hi = 0;
-      range_of(seg, lo, hi);
+      range_of(seg, 0, lo, hi);
       __builtin_amdgcn_sched_barrier(0);
       pn = 0;
-      if (hi > lo) {       // (wave-uniform)
+      if (PHASE || hi > lo) {       // (wave-uniform)
         const int nch = (hi - lo) >> 4;
-        const unsigned sel = slot_select(seg, lo, (unsigned)lane % (unsigned)MAXCH);
+        const unsigned sel = PHASE ? 0u : slot_select(seg, lo, (unsigned)lane % (unsigned)MAXCH);
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
           unsigned loff = 0;
-          chunk(lo, nch, sel, i, pg[i], loff);
+          chunk(seg, lo, nch, sel, i, pg[i], loff);
           pv[i] = lds_chunk(loff);
         }
         pn = MAXI;
       }
       {
         unsigned g = 0, loff = 0;
-        if (tail_chunk(seg, g, loff)) {
+        if (edge_chunk(seg, g, loff)) {
           if (pn == 0) {     // (no main range: unused slots store out of range)
 #pragma unroll
             for (int i = 0; i < MAXI; ++i) pg[i] = 0x7ffffff0u;
