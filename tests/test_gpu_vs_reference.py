@@ -272,7 +272,7 @@ def test_queue_and_cross_structure_launches_vs_live_reference(ctx):
         masks = m.ends_full_masks(n, k, 1)
         _, times, d_fixed = helpers.reference_batch(bsz, k, n, 3, 1618 + k + n, masks)
         refs.append(ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())[0])
-        inputs[(n, k)] = (times, d_fixed)
+        inputs[(n, k)] = (masks, times, d_fixed)
         t = torch.from_numpy(np.ascontiguousarray(times)).cuda().t().contiguous()
         f = torch.from_numpy(np.ascontiguousarray(d_fixed)).cuda().permute(1, 2, 0).contiguous()
         buckets.append(dict(n_coeffs=n, derivative=d, masks=masks, times=t, d_fixed=f, layout="soa"))
@@ -283,6 +283,6 @@ def test_queue_and_cross_structure_launches_vs_live_reference(ctx):
     torch.cuda.synchronize()
     solver.sync()
     for (n, d, k), (co, _), ref_c in zip(CONFIG4, out, refs):
-        assert_close_to_reference(n, d, masks, *inputs[(n, k)], co.cpu().numpy(), ref_c)
+        assert_close_to_reference(n, d, *inputs[(n, k)], co.cpu().numpy(), ref_c)
     req.close()
     solver.close()
