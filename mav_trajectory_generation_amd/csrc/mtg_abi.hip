@@ -111,6 +111,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
+  int knob_dl_grid_per_cu = 8;       // MTG_DL_GRID_PER_CU: workgroups per CU of a (non-workspace) dimension-in-lane launch
   int knob_dl_rt = -1;               // MTG_DL_RT: 1 = the run-time-K body even where a static variant exists, 0 = never (default: where none exists)
   int knob_dl_occ2 = -1;             // MTG_DL_OCC2: 1 always / 0 never use the two-waves-per-SIMD twins (default: by launch size)
   bool knob_dl_any_rr = false;       // MTG_DL_ANY_SCHED=rr: round 2's unit schedule of the cross-structure launch
@@ -264,6 +265,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
   if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
   if (const char* e = getenv("MTG_DL_RT")) ctx->knob_dl_rt = atoi(e);
+  if (const char* e = getenv("MTG_DL_GRID_PER_CU")) ctx->knob_dl_grid_per_cu = std::max(1, atoi(e));
   if (const char* e = getenv("MTG_DL_ANY_SCHED")) ctx->knob_dl_any_rr = std::string(e) == "rr";
   if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
   if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
@@ -701,7 +703,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
     const int nt = (int)((batch + dl->tpw - 1) / dl->tpw);
     const int units = (nt + dl->np - 1) / dl->np;
-    int grid = std::min(units, ctx->n_cu * 8);
+    int grid = std::min(units, ctx->n_cu * ctx->knob_dl_grid_per_cu);
     const int policy = ctx->knob_dl_policy >= 0 ? ctx->knob_dl_policy : 0;
     double* dl_ws = nullptr;
     if (dl->ws_per_lane) {

@@ -34,7 +34,7 @@ int launch_rt(void* stream, int grid, const double* times, const double* dfix, d
    (size_t)MTG_RTCFG(H, MS, MI, ME, DV, DL)::WSE * sizeof(double), launch_rt<MTG_RTCFG(H, MS, MI, ME, DV, DL), DL, R, L>},
 const MtgDimlaneRtEntry kRtTable[] = {
     // (R, L) = the largest register / LDS step counts without scratch spills / with two workgroups per CU (probed with
-    // hipcc -Rpass-analysis=kernel-resource-usage): half-chains of up to 1 + R + L steps stay on chip -- K <= 66 / 34 / 20
+    // hipcc -Rpass-analysis=kernel-resource-usage): half-chains of up to 1 + R + L steps stay on chip -- K <= 66 / 34 / 18 (D = 3)
     MTG_RT(4, 15, 1, 15, 3, 3, 24, 8)
     MTG_RT(5, 31, 1, 31, 4, 3, 11, 5)
     MTG_RT(6, 63, 1, 63, 5, 3, 5, 3)
