@@ -334,7 +334,8 @@ int mtg_device_group_gather_coeffs(mtg_device_group* group, int64_t batch, const
 /* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
 /* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the
  * context's stream, bracketed by hipEvents recorded on that same stream; returns the mean
- * kernel-side duration per launch in microseconds.                                        */
+ * kernel-side duration per launch in microseconds.  (Queue launches of mtg_solve_linear_sequence
+ * are not recorded: MTG_ERR_INVALID_ARGUMENT after one -- time those with the _events form.)   */
 int mtg_time_last_solve(mtg_plan* plan, int iters, double* mean_us);
 /* Accuracy self-test of the device reciprocal used by the LDL^T pivots: max relative error
  * of rcp(x) vs 1/x over n pseudo-random positive doubles.  (n < 0: diagnostic -- |n| samples with

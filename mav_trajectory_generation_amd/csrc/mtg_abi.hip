@@ -681,9 +681,8 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     const int nt = (int)((batch + rt->tpw - 1) / rt->tpw);
     const int grid = std::min(nt, ctx->n_cu * 2);
     const int kc_max = (p->K + 1) / 2;
-    const int ws_steps = std::max(0, kc_max - 1 - rt->r_steps - rt->l_steps);
     double* rt_ws = nullptr;
-    if (ws_steps > 0) {
+    if (kc_max - 1 - rt->r_steps - rt->l_steps > 0) {      // head steps beyond the register tail and the LDS step area
       const size_t need = rt->step_bytes_per_lane * (size_t)(kc_max - 1 - rt->r_steps) * (size_t)grid * 2 * kWave;   // slots j - 1 of all head steps
       if (p->user_ws) {
         if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");

@@ -216,7 +216,7 @@ __host__ __device__ constexpr size_t mtg_rt_lds_bytes() { return 2 * mtg_rt_half
 template <class C, int DL, int R, int L, int AUX, bool PHASE>
 __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const double* __restrict__ times, const double* __restrict__ dfix,
                                                                      double* __restrict__ coeffs, int* status, int* traj_status,
-                                                                     int B, int K, int ntiles, double* ws, int ws_steps) {
+                                                                     int B, int K, int ntiles, double* ws) {
   static_assert(C::DLW == DL && DL >= 1 && DL <= 4, "lanes per trajectory");
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -249,7 +249,6 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const dou
   st.lds_col = (unsigned)(size_t)(lds_raw + 2 * half + (size_t)dir * L * mtg_rt_step_bytes<C>()) + (unsigned)lane * 8u;
   st.share = P.ws_share;
   st.nh = kc - R;
-  (void)ws_steps;
   double* mine = reinterpret_cast<double*>(lds_raw + (size_t)(1 - dir) * half) + lane;
   const double* other = reinterpret_cast<const double*>(my_slab) + lane;
   MtgSlabOutRt<C::N, DL, 1, AUX, PHASE> ioA;

@@ -20,7 +20,7 @@ int launch_rt(void* stream, int grid, const double* times, const double* dfix, d
       done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, times, dfix, coeffs, status, traj_status, B, K,
-                       ntiles, ws, 0);
+                       ntiles, ws);
     return 0;
   };
   if constexpr ((DL * C::N * 8) % 64 != 0) {
