@@ -42,6 +42,10 @@ const MtgDimlaneRtEntry kRtTable[] = {
     MTG_RT(4, 15, 1, 15, 3, 4, 24, 8)
     MTG_RT(5, 31, 1, 31, 4, 4, 13, 5)
     MTG_RT(6, 63, 1, 63, 5, 4, 6, 3)
+    // N = 10 with more fixed at the interior vertices: position + velocity (+ acceleration: BASELINE config 5's pattern, any K)
+    MTG_RT(5, 31, 7, 31, 4, 4, 24, 8)
+    MTG_RT(5, 31, 7, 31, 4, 3, 24, 8)
+    MTG_RT(5, 31, 3, 31, 4, 3, 20, 6)
 };
 }  // namespace
 

@@ -338,6 +338,27 @@ def test_runtime_k_body_four_dimensions(ctx, n, k):
     plan.close()
 
 
+@pytest.mark.parametrize("k,dim,interior", [(5, 4, 7), (24, 4, 7), (57, 4, 7), (12, 3, 7), (40, 3, 7), (10, 3, 3), (33, 3, 3)])
+def test_runtime_k_body_other_interior_masks(ctx, k, dim, interior):
+    """N = 10 with velocity (and acceleration) fixed at the interior vertices as well -- BASELINE config 5's constraint pattern
+    at chain lengths other than 16: the run-time-K body by default."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, k, interior)
+    t, f = m.random_waypoint_batch(500, k, dim, 10, masks, seed=31 * k + dim, device="cuda", layout="soa", yaw_dim=(dim == 4))
+    plan = m.Plan(ctx, 10, dim, k, 4, masks)
+    assert plan.launch_form(500) == "dimlane_rt"
+    co, _, _ = plan.solve(t, f, layout="soa")
+    ref, _, _ = plan.solve(t, f, layout="soa", dims="fused")
+    ctx.sync()
+    rel, _ = ctx.compare_coefficients(co, ref)
+    assert rel < 1e-11
+    th, fh = t.t()[:5].contiguous().cpu().numpy(), f.permute(2, 0, 1)[:5].contiguous().cpu().numpy()
+    c_lit, _, _ = onp.solve_batch(10, 4, masks, th, fh)
+    assert helpers.poly_relerr(co[:5].cpu().numpy(), c_lit) < 1e-9
+    plan.close()
+
+
 def test_runtime_k_body_is_the_default_beyond_the_static_variants(ctx):
     import mav_trajectory_generation_amd as m
     for (n, k, want) in ((12, 50, "dimlane_rt"), (10, 100, "dimlane_rt"), (8, 33, "dimlane_rt"), (10, 32, "dimlane"), (10, 50, "dimlane")):
