@@ -110,6 +110,7 @@ struct mtg_context {
   bool knob_no_dimlane = false;      // MTG_NO_DIMLANE: never pick the dimension-in-lane form
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
+  bool knob_no_slab_extra = false;   // MTG_NO_SLAB_EXTRA: extra outputs (cost / d_P) through the older fused kernel
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
   int knob_dl_grid_per_cu = 8;       // MTG_DL_GRID_PER_CU: workgroups per CU of a (non-workspace) dimension-in-lane launch
   int knob_dl_rt = -1;               // MTG_DL_RT: 1 = the run-time-K body even where a static variant exists, 0 = never (default: where none exists)
@@ -153,6 +154,7 @@ struct mtg_plan {
   const MtgDimlaneRtEntry* dimlane_rt = nullptr;   // run-time-K dimension-in-lane body (mtg_dimlane_rt.h): any chain length of the standard shapes
   bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
   bool slab_queue_attr_set = false;
+  bool slab_extra_attr_set = false;
   double* ws = nullptr;
   size_t ws_bytes = 0;
   double* pert_cost = nullptr;      // [(K + 1)][batch] costs of mtg_mellinger_cost_gradient's virtual problems
@@ -262,6 +264,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
+  ctx->knob_no_slab_extra = getenv("MTG_NO_SLAB_EXTRA") != nullptr;
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
   if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
   if (const char* e = getenv("MTG_DL_RT")) ctx->knob_dl_rt = atoi(e);
@@ -740,7 +743,22 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
       // fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
       const MtgSlabEntry* slab = nullptr;
-      if (!wc && !cost_only && !pert) slab = pick_slab(p, var);
+      if (!cost_only && !pert) slab = pick_slab(p, var);
+      if (slab && wc && (!slab->extra || ctx->knob_no_slab_extra)) slab = nullptr;
+      if (slab && wc) {
+        // extra outputs (cost / d_P) through the slab-output kernel as well (round 3; the older fused kernel's 240-byte
+        // pieces complete most sectors from two store instructions: 80-83 us at B = 125k with rotating buffers)
+        const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);
+        if (!p->slab_extra_attr_set) {
+          MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->extra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
+          p->slab_extra_attr_set = true;
+        }
+        hipLaunchKernelGGL(slab->extra, dim3(sgrid), dim3(kBlock), slab->lds, st, Q, ntiles);
+        LaunchRecord r;
+        r.valid = true; r.fn = slab->extra; r.params = Q; r.ntiles = ntiles; r.grid = sgrid; r.gridy = 1; r.lds = slab->lds;
+        p->last.push_back(r);
+        break;
+      }
       if (slab) {
         const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
         const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD

@@ -251,7 +251,7 @@ struct MtgSeqQueue {
   MtgSeqItem item[kSeqMax];
 };
 
-template <class C, int AUX, bool QUEUE>
+template <class C, int AUX, bool QUEUE, int OUT = 0>
 __device__ __forceinline__ void mtg_solve_slab_body(const MtgParams& P, int ntiles, const MtgSeqQueue* q) {
   static_assert(C::kStatic && C::KT >= 2 && !C::kPert, "slab-output form: static configurations, K >= 2");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -311,10 +311,10 @@ __device__ __forceinline__ void mtg_solve_slab_body(const MtgParams& P, int ntil
     __syncthreads();
     if (dir == 0) {
       ioA.begin_tile(Pc.coeffs, b0, P.B);
-      mtg_lane_finish<C, 1, 0>(Pc, b, ln, nullptr, other, kWave, ioA, active);
+      mtg_lane_finish<C, 1, OUT>(Pc, b, ln, nullptr, other, kWave, ioA, active);
     } else {
       ioB.begin_tile(Pc.coeffs, b0, P.B);
-      mtg_lane_finish<C, -1, 0>(Pc, b, ln, nullptr, other, kWave, ioB, active);
+      mtg_lane_finish<C, -1, OUT>(Pc, b, ln, nullptr, other, kWave, ioB, active);
     }
     if (has_next) {
 #pragma unroll
@@ -331,9 +331,10 @@ __device__ __forceinline__ void mtg_solve_slab_body(const MtgParams& P, int ntil
   }
 }
 
-template <class C, int AUX>
+// OUT: as for mtg_solve_kernel (bit 0: cost, bit 1: d_P output)
+template <class C, int AUX, int OUT = 0>
 __global__ __launch_bounds__(kBlock, 1) void mtg_solve_slab_kernel(MtgParams P, int ntiles) {
-  mtg_solve_slab_body<C, AUX, false>(P, ntiles, nullptr);
+  mtg_solve_slab_body<C, AUX, false, OUT>(P, ntiles, nullptr);
 }
 
 template <class C, int AUX>
@@ -457,6 +458,7 @@ struct MtgSlabEntry {
   size_t lds;
   SolveFn fn[2];   // coefficient store policy: [0] write-back, [1] nt sc1
   SolveQueueFn queue;   // the same (nt sc1) over a queue of batches: mtg_solve_linear_sequence
+  SolveFn extra;        // nt sc1 with the extra outputs (OUT = 3: cost and / or d_P), round 3
 };
 const MtgSlabEntry* mtg_find_slab(int h, int d, int k, int deriv, const int* mask);
 

@@ -65,7 +65,8 @@ SolveMultiFn mtg_multi_any_fn(int dg, int variant) {
   {H, D, K, MS, MI, ME, DV, mtg_slab_lds_bytes<MtgCfg<H, D, K, MS, MI, ME, DV>>(),      \
    {(SolveFn)mtg_solve_slab_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 0>,                \
     (SolveFn)mtg_solve_slab_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 18>},               \
-   (SolveQueueFn)mtg_solve_slab_queue_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 18>},
+   (SolveQueueFn)mtg_solve_slab_queue_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 18>,     \
+   (SolveFn)mtg_solve_slab_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 18, 3>},
 static const MtgSlabEntry kSlabTable[] = {
     MTG_SLAB(5, 3, 8, 31, 1, 31, 4)   // BASELINE configs 2/3
     MTG_SLAB(4, 3, 8, 15, 1, 15, 3)
