@@ -674,7 +674,13 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       MtgParams Q = P;
       Q.dim0 = dim0;
       const int grid = std::min(ntiles, ctx->n_cu * 16);
-      const size_t lds = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+      size_t lds = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+      // whole-sector output (mtg_update_slab_kernel) for the rolled form; MTG_NO_SLAB keeps the per-segment staging
+      const int phase = ((size_t)p->K * p->D * p->N * 8) % 64 != 0 ? 1 : 0;
+      if (uv && !ctx->knob_no_slab && uv->upd_slab[wc ? 1 : 0][phase] && uv->upd_slab_lds <= 64 * 1024) {
+        fn = uv->upd_slab[wc ? 1 : 0][phase];
+        lds = uv->upd_slab_lds;
+      }
       hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, st, Q, ntiles);
       if (uv) break;
     }

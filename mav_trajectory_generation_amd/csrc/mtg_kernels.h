@@ -435,6 +435,30 @@ __global__ __launch_bounds__(kWave) void mtg_update_kernel(MtgParams P, int ntil
 }
 
 
+// setFreeConstraints path with whole-sector output (round 3): the same lanes and arithmetic as mtg_update_kernel, the
+// coefficients leave through MtgSlabOutRt (run-time K, one lane per trajectory with all D dimensions, every segment in ascending
+// order: "direction B with KA = 0") instead of the per-segment staging whose 240-byte pieces complete most sectors from two store
+// instructions.  PHASE: instantiation for pieces of K * D * N * 8 bytes that are not a multiple of 64 bytes.
+template <class C>
+__host__ __device__ constexpr size_t mtg_update_slab_lds_bytes() {
+  return ((size_t)64 * MtgSlabOutRt<C::N, 1, -1, 0, false, false, C::D>::ROWB + 15) / 16 * 16;
+}
+template <class C, int OUT, bool PHASE>
+__global__ __launch_bounds__(kWave) void mtg_update_slab_kernel(MtgParams P, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int lane = threadIdx.x;
+  MtgSlabOutRt<C::N, 1, -1, 18, PHASE, false, C::D> io;
+  io.init(lds_raw, lane, lane, 0, P.K, 0);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b0 = (long long)tile * kWave;
+    const long long bl = b0 + lane;
+    const bool active = bl < P.B;
+    io.begin_tile(P.coeffs, b0, P.B);
+    mtg_lane_update<C, OUT>(P, active ? bl : P.B - 1, io, active);
+    __builtin_amdgcn_s_barrier();     // (one wave: orders the slab's reuse against the flush's LDS reads)
+  }
+}
+
 using SolveFn = void (*)(MtgParams, int);
 using UpdateFn = void (*)(MtgParams, int);
 using SolveMultiFn = void (*)(const MtgParams*, const MtgTileRef*, int);
@@ -449,6 +473,8 @@ struct MtgStaticEntry {
   int heavy;       // static variant that spills: prefer a rolled variant for large launches
   SolveFn fn[5];   // [extra outputs (cost / d_free)] + 2 * [write-through stores]; [4] = cost only (OUT 9)
   void (*upd[2])(MtgParams, int);   // rolled entries: setFreeConstraints kernel [with cost]; static entries: null
+  void (*upd_slab[2][2])(MtgParams, int);   // rolled entries with all plan dimensions: the same with whole-sector output, [with cost][piece not a multiple of 64 bytes]
+  size_t upd_slab_lds;
   SolveMultiFn multi[4];            // rolled entries: several plans in one launch, [extra outputs] + 2 * [write-through]
 };
 const MtgStaticEntry* mtg_find_static(int h, int d, int k, int deriv, const int* mask, bool rolled_only = false);

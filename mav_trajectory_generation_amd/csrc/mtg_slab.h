@@ -319,19 +319,21 @@ struct MtgSlabOut {
 // (phase 0 everywhere) keep the cheaper maps.
 // PHASE: compiled for pieces that are NOT a multiple of 64 bytes (the per-row phase maps); false: aligned pieces only.  Two
 // instantiations of the kernel instead of a run-time branch: with both maps in one body the aligned chain lengths lost 4-10 %.
-template <int N_, int LPT, int DIR, int AUX, bool PHASE, bool PEND = true>
+// DPL: dimensions per lane (1: dimension-in-lane kernels; D with LPT = 1: the one-lane-per-trajectory update kernel, whose
+// segments all arrive in ascending order -- direction B with KA = 0, init()'s last argument).
+template <int N_, int LPT, int DIR, int AUX, bool PHASE, bool PEND = true, int DPL = 1>
 struct MtgSlabOutRt {
   static constexpr int N = N_;
-  static constexpr int LB = N * 8;                   // bytes one lane contributes per segment
+  static constexpr int LB = DPL * N * 8;             // bytes one lane contributes per segment
   static constexpr int S = LPT * LB;                 // bytes of one segment (all dimensions of the trajectory)
   static constexpr int TPW = 64 / LPT;
   static_assert(S >= 64, "ring layout needs segments of at least one sector");
-  static_assert(3 * TPW <= 64, "the head / tail pass maps lane -> (trajectory lane / 3, chunk lane % 3)");
   static constexpr int MAXCH = (S % 64 == 0) ? S / 16 : (S / 64 + 1) * 4;   // chunks of the largest range (a range never exceeds S rounded up to 64)
   static constexpr int RPI = 64 / MAXCH;             // trajectories per store instruction
   static constexpr int MAXI = (TPW + RPI - 1) / RPI; // store instructions per range
   static constexpr int ROWB = (((2 * S) / 16) | 1) * 16;   // two segment slots, odd number of 16-byte units
-  static constexpr int NPV = PEND ? MAXI + 1 : 1;    // (+ 1: the head / tail pass)
+  static constexpr int EI = (3 * TPW + 63) / 64;     // store instructions of the head / tail pass (3 chunk slots per trajectory)
+  static constexpr int NPV = PEND ? MAXI + EI : 1;
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   char* slab;
@@ -349,9 +351,9 @@ struct MtgSlabOutRt {
 
   static __device__ __forceinline__ int up64(int x) { return (x + 63) & ~63; }
   static __device__ __forceinline__ int dn64(int x) { return x & ~63; }
-  __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_, int K_) {
+  __device__ __forceinline__ void init(char* slab_, int lane_, int t_, int d_, int K_, int KA_ = -1) {
     slab = slab_; lane = lane_; t = t_; d = d_;
-    K = K_; KA = (K_ + 1) / 2;
+    K = K_; KA = KA_ >= 0 ? KA_ : (K_ + 1) / 2;
     piece = (unsigned)K_ * (unsigned)S;
     pmod = (int)(piece & 63u);
     pn = 0;
@@ -428,10 +430,11 @@ struct MtgSlabOutRt {
   }
   // The head (direction A, segment 0) / tail (direction B, last segment) of every row's piece: up to 3 chunks per row,
   // lane -> (trajectory lane / 3, chunk lane % 3) -- one store instruction.  false: this segment has no such pass.
-  __device__ __forceinline__ bool edge_chunk(int seg, unsigned& g, unsigned& loff) const {
+  __device__ __forceinline__ bool edge_chunk(int seg, int e, unsigned& g, unsigned& loff) const {
     if (!(DIR > 0 ? seg == 0 : seg == K - 1)) return false;            // (wave-uniform)
     if constexpr (!PHASE) return false;                                // aligned pieces have neither head nor tail
-    const unsigned tt = (unsigned)lane / 3u, c = (unsigned)lane - tt * 3u;
+    const unsigned o = (unsigned)(e * 64 + lane);
+    const unsigned tt = o / 3u, c = o - tt * 3u;
     const int ph = (int)(((ph0 + tt) * (unsigned)pmod) & 63u);
     const int start = DIR > 0 ? 0 : ((K * S + ph) & ~63) - ph;
     const int end = DIR > 0 ? ((64 - ph) & 63) : K * S;
@@ -484,9 +487,10 @@ struct MtgSlabOutRt {
         }
       };
       if (PHASE || hi > lo) pass(std::integral_constant<bool, PHASE>());      // (wave-uniform)
-      {
+#pragma unroll
+      for (int e = 0; e < EI; ++e) {
         unsigned g = 0, loff = 0;
-        if (edge_chunk(seg, g, loff)) __builtin_amdgcn_raw_buffer_store_b128(lds_chunk(loff), rsrc, (int)g, 0, AUX);
+        if (edge_chunk(seg, e, g, loff)) __builtin_amdgcn_raw_buffer_store_b128(lds_chunk(loff), rsrc, (int)g, 0, AUX);
       }
       fence();
     }
@@ -509,16 +513,17 @@ struct MtgSlabOutRt {
         }
         pn = MAXI;
       }
-      {
+#pragma unroll
+      for (int e = 0; e < EI; ++e) {
         unsigned g = 0, loff = 0;
-        if (edge_chunk(seg, g, loff)) {
+        if (edge_chunk(seg, e, g, loff)) {
           if (pn == 0) {     // (no main range: unused slots store out of range)
 #pragma unroll
             for (int i = 0; i < MAXI; ++i) pg[i] = 0x7ffffff0u;
           }
-          pg[MAXI] = g;
-          pv[MAXI] = lds_chunk(loff);
-          pn = MAXI + 1;
+          pg[MAXI + e] = g;
+          pv[MAXI + e] = lds_chunk(loff);
+          pn = MAXI + e + 1;
         }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -11,6 +11,7 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV>, 7>,          \
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, K, MS, MI, ME, DV, 1>, 9>},         \
    {nullptr, nullptr},                                                      \
+   {{nullptr, nullptr}, {nullptr, nullptr}}, 0,                             \
    {nullptr, nullptr, nullptr, nullptr}},
 #define MTG_ROLLED(H, D, MS, MI, ME, DV)                                    \
   {H, D, -1, MS, MI, ME, DV, 0,                                             \
@@ -21,6 +22,11 @@
     (SolveFn)mtg_solve_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV, 1>, 9>},        \
    {(UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>,       \
     (UpdateFn)mtg_update_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1>},      \
+   {{(UpdateFn)mtg_update_slab_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0, false>,  \
+     (UpdateFn)mtg_update_slab_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0, true>},  \
+    {(UpdateFn)mtg_update_slab_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1, false>,  \
+     (UpdateFn)mtg_update_slab_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 1, true>}}, \
+   mtg_update_slab_lds_bytes<MtgCfg<H, D, -1, MS, MI, ME, DV>>(),           \
    {(SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 0>, \
     (SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 3>, \
     (SolveMultiFn)mtg_solve_multi_kernel<MtgCfg<H, D, -1, MS, MI, ME, DV>, 4>, \

@@ -436,6 +436,44 @@ def test_update_from_free_large_batch(ctx):
     plan.close()
 
 
+@pytest.mark.parametrize("n,d,k,dim,interior,bsz", [
+    (10, 4, 8, 3, 1, 777),      # piece 1920 B: aligned
+    (10, 4, 7, 3, 1, 1000),     # piece 1680 B: phases 0 / 16 / 32 / 48
+    (10, 4, 1, 3, 1, 200), (10, 4, 2, 3, 1, 65), (10, 4, 3, 3, 1, 64), (10, 4, 33, 3, 1, 130),
+    (8, 3, 5, 3, 1, 321), (8, 3, 16, 3, 1, 500), (12, 5, 3, 3, 1, 259), (12, 5, 8, 3, 1, 300),
+    (10, 4, 5, 4, 7, 333), (10, 4, 8, 4, 7, 140),
+    (8, 3, 7, 1, 1, 500), (10, 4, 9, 1, 1, 129), (12, 5, 4, 1, 1, 400), (10, 4, 3, 1, 7, 97),
+])
+def test_update_from_free_whole_sector_output(ctx, n, d, k, dim, interior, bsz, monkeypatch):
+    """setFreeConstraints path, rolled form with whole-sector output (mtg_update_slab_kernel): coefficients rebuilt from the
+    solver's own d_P equal the solve's, and equal -- bit for bit -- the per-segment staging kernel's (MTG_NO_SLAB context);
+    ragged batches, aligned and unaligned pieces, one / three / four dimensions."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(n, k, interior)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=k + n, device="cuda")
+    co, fr, cost = plan.solve(t, f, want_free=True, want_cost=True)
+    co2, cost2 = plan.update_from_free(t, f, fr, want_cost=True)
+    co3 = plan.update_from_free(t, f, fr)
+    if isinstance(co3, tuple):
+        co3 = co3[0]
+    ctx.sync()
+    den = co.abs().amax(dim=-1).clamp_min(1e-300)
+    assert float(((co - co2).abs().amax(dim=-1) / den).max()) < (1e-11 if n < 12 else 1e-9)
+    assert torch.allclose(cost, cost2, rtol=1e-9)
+    assert torch.equal(co2, co3)
+    plan.close()
+    monkeypatch.setenv("MTG_NO_SLAB", "1")
+    ctx2 = m.Context(0)
+    plan2 = m.Plan(ctx2, n, dim, k, d, masks)
+    co4, cost4 = plan2.update_from_free(t, f, fr, want_cost=True)
+    ctx2.sync()
+    assert torch.equal(co2, co4) and torch.equal(cost2, cost4)
+    plan2.close()
+    ctx2.close()
+
+
 def test_cost_only_and_mellinger_gradient(ctx):
     """MTG_FLAG_COST_ONLY and the batched Mellinger cost/gradient step (K+1 perturbed-time solves per trajectory in
     one launch) against a literal restatement of getCostAndGradientMellinger
