@@ -88,7 +88,8 @@ enum {
                                      /* (polynomial_optimization_nonlinear_impl.h:313-359,    */
                                      /* :569-571) need J = computeCost(), not the segments    */
   MTG_FLAG_DIMLANE = 1u << 5,        /* force the dimension-in-lane launch form where the     */
-                                     /* plan and the call are eligible (SoA inputs, coeffs    */
+                                     /* plan and the call are eligible (canonical SoA or AoS  */
+                                     /* inputs -- mtg_layout_soa / mtg_layout_aos --, coeffs  */
                                      /* only); default: chosen from the batch size            */
   MTG_FLAG_HOST_BACKEND = 1u << 6,   /* with MTG_FLAG_HOST_POINTERS and batch <=               */
                                      /* MTG_HOST_BACKEND_MAX_BATCH: solve on the calling      */
@@ -263,7 +264,7 @@ int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coef
  * What a caller of the reference does with a list of independent PolynomialOptimization<N>
  * problems of different structure (BASELINE config 4: N in {8, 10, 12}, 4..32 segments): each
  * structure is a plan + a batch.  A mixed request is created once -- items with canonical SoA
- * inputs (times[K][B], d_fixed[D][n_fixed][B]) and coefficient output only whose plan has a
+ * (times[K][B], d_fixed[D][n_fixed][B]) or AoS inputs and coefficient output only whose plan has a
  * static dimension-in-lane configuration (the config-4 shapes: N = 8 / 10 / 12, K = 4 / 8 / 16 /
  * 32, D = 3) join ONE cross-structure launch whatever their N and K; of the others, items that
  * share D, the start / interior / end constraint pattern and the derivative (any K >= 2; N = 8 /

@@ -4,7 +4,7 @@ PolynomialOptimization<N> problems.
 
 A bucket of a few thousand trajectories fills only a fraction of the 256 CUs, and twelve back-to-back launches each pay
 their own latency chain.  The fast path is `MixedBatchSolver.merged(buckets)`: ONE library call per request
-(mtg_multi_*), which runs every bucket with canonical SoA inputs inside one cross-structure kernel launch (config 4, 30k
+(mtg_multi_*), which runs every bucket with canonical SoA or AoS inputs inside one cross-structure kernel launch (config 4, 30k
 trajectories: 63-65 us against ~320 us for per-bucket launches from Python).  `solve_device` / `capture` spread per-bucket
 launches over `n_streams` HIP streams (one library context per stream, forked from / joined onto the caller's stream,
 longest chains first) -- kept for requests the merged path does not cover, but on this runtime kernels of different

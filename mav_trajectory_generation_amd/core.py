@@ -234,7 +234,8 @@ class Plan:
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
         dims: launch form -- 'auto', 'fused', 'split' (one dimension group per workgroup) or 'dimlane' (all dimensions of
-        a trajectory in one wavefront; SoA inputs, coefficient output only -- falls back to 'auto' where not eligible).
+        a trajectory in one wavefront; canonical SoA or AoS inputs, coefficient output only -- falls back to 'auto' where
+        not eligible).
         traj_status: optional int32 CUDA tensor [B] that receives the per-trajectory status bits (1 bad time, 2 singular).
         ordered=False skips the automatic ordering against torch's current stream (the caller forks / joins the
         context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors

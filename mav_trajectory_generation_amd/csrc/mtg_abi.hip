@@ -137,6 +137,7 @@ struct LaunchRecord {
   const MtgDimlaneEntry* dl = nullptr;   // dimension-in-lane launch (mtg_dimlane.h): uses params.{times,dfix,coeffs,status,tstatus,B}
   const MtgDimlaneRtEntry* rt = nullptr; // run-time-K dimension-in-lane launch (mtg_dimlane_rt.h)
   int dl_policy = 0;
+  int dl_aos = 0;                        // input layout kind of a dimension-in-lane launch (dimlane_input_kind)
   double* dl_ws = nullptr;
 };
 
@@ -485,13 +486,24 @@ static bool dimlane_is_default(const mtg_plan* p, const MtgDimlaneEntry* dl, int
   return hi == 0 || 2 * units <= (int64_t)hi * cus;
 }
 
+// Input layout kinds the dimension-in-lane kernels read: 0 = canonical SoA (times[K][B], d_fixed[D][n_fixed][B]), 1 = canonical
+// AoS (times[B][K], d_fixed[B][D][n_fixed]: the reference's natural order), -1 = anything else (fused / generic kernels).
+static int dimlane_input_kind(const mtg_plan* p, const mtg_layout* L, int64_t batch) {
+  if (L->times_stride_b == 1 && L->times_stride_k == batch && L->fixed_stride_b == 1 && L->fixed_stride_c == batch &&
+      L->fixed_stride_d == (int64_t)p->n_fixed * batch)
+    return 0;
+  if (L->times_stride_b == p->K && L->times_stride_k == 1 && L->fixed_stride_b == (int64_t)p->D * p->n_fixed &&
+      L->fixed_stride_c == 1 && L->fixed_stride_d == p->n_fixed)
+    return 1;
+  return -1;
+}
+
 static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P,
                                            uint32_t flags, bool cost_only) {
   const MtgDimlaneEntry* dl = p->dimlane;
   if (!dl || p->ctx->knob_no_dimlane || cost_only || P.dfree || P.cost) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
-  if (L->times_stride_b != 1 || L->times_stride_k != batch) return nullptr;
-  if (L->fixed_stride_b != 1 || L->fixed_stride_c != batch || L->fixed_stride_d != (int64_t)p->n_fixed * batch) return nullptr;
+  if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
   if (flags & MTG_FLAG_DIMLANE) return dl;
   return dimlane_is_default(p, dl, batch) ? dl : nullptr;
@@ -506,8 +518,7 @@ static const MtgDimlaneRtEntry* pick_dimlane_rt(const mtg_plan* p, int64_t batch
   if (!rt || p->ctx->knob_dl_rt == 0 || p->ctx->knob_no_dimlane || cost_only || P.dfree || P.cost) return nullptr;
   if (p->dimlane && p->ctx->knob_dl_rt != 1) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
-  if (L->times_stride_b != 1 || L->times_stride_k != batch) return nullptr;
-  if (L->fixed_stride_b != 1 || L->fixed_stride_c != batch || L->fixed_stride_d != (int64_t)p->n_fixed * batch) return nullptr;
+  if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
   return rt;
 }
 
@@ -702,10 +713,11 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         rt_ws = p->ws;
       }
     }
-    if (rt->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, p->K, nt, rt_ws) != 0)
+    const int aos = dimlane_input_kind(p, L, batch);
+    if (rt->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, p->K, nt, rt_ws, aos) != 0)
       return set_err(ctx, MTG_ERR_DEVICE, "run-time-K dimension-in-lane launch set-up failed");
     LaunchRecord r;
-    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.rt = rt; r.dl_ws = rt_ws;
+    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.rt = rt; r.dl_ws = rt_ws; r.dl_aos = aos;
     p->last.push_back(r);
   } else if (const MtgDimlaneEntry* dl = dimlane_twin(p, pick_dimlane(p, batch, L, P, flags, cost_only), batch)) {
     // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
@@ -728,10 +740,11 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
         dl_ws = p->ws;
       }
     }
-    if (dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws) != 0)
+    const int aos = dimlane_input_kind(p, L, batch);
+    if (dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws, aos) != 0)
       return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
     LaunchRecord r;
-    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws;
+    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws; r.dl_aos = aos;
     p->last.push_back(r);
   } else {
     // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
@@ -894,8 +907,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
   if (slab && (!slab->queue || ((batch + kWave - 1) / kWave) * (int64_t)n_launch >= (1ll << 31))) slab = nullptr;
   const MtgDimlaneEntry* dl = p->dimlane;
   if (dl && (!dl->launch_queue || ctx->knob_no_dimlane || (flags & MTG_FLAG_FUSED_DIMS))) dl = nullptr;
-  if (dl && (L->times_stride_b != 1 || L->times_stride_k != batch || L->fixed_stride_b != 1 || L->fixed_stride_c != batch ||
-             L->fixed_stride_d != (int64_t)p->n_fixed * batch ||
+  if (dl && (dimlane_input_kind(p, L, batch) < 0 ||
              batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32) ||
              ((batch + dl->tpw - 1) / dl->tpw) * (int64_t)n_launch >= (1ll << 31)))
     dl = nullptr;
@@ -940,7 +952,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
           dl_ws = p->ws;
         }
       }
-      if (dl->launch_queue((void*)ctx->stream, grid, &q, ctx->d_status, (int)batch, ntiles, dl_ws) != 0)
+      if (dl->launch_queue((void*)ctx->stream, grid, &q, ctx->d_status, (int)batch, ntiles, dl_ws, dimlane_input_kind(p, L, batch)) != 0)
         return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane queue launch set-up failed");
     } else {
       const int grid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // two workgroups per CU, one wave per SIMD (as the single-batch launch)
@@ -1158,8 +1170,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
       const mtg_plan* p = it.plan;
       if (it.batch <= 0 || it.cost || (it.d_free && p->n_free > 0) || mtg_dl_any_index(p->dimlane) < 0) continue;
       const mtg_layout& L = it.layout;
-      if (L.times_stride_b != 1 || L.times_stride_k != it.batch) continue;
-      if (L.fixed_stride_b != 1 || L.fixed_stride_c != it.batch || L.fixed_stride_d != (int64_t)p->n_fixed * it.batch) continue;
+      if (dimlane_input_kind(p, &L, it.batch) < 0) continue;
       if (it.batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) continue;
       cand.push_back(i);
     }
@@ -1174,7 +1185,8 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
         const mtg_multi_item& it = items[cand[bi]];
         taken[cand[bi]] = 1;
         const int tpw = it.plan->dimlane->tpw;
-        table[bi] = MtgDlAnyItem{it.times, it.d_fixed, it.coeffs, (int)it.batch, mtg_dl_any_index(it.plan->dimlane)};
+        table[bi] = MtgDlAnyItem{it.times, it.d_fixed, it.coeffs, (int)it.batch, mtg_dl_any_index(it.plan->dimlane),
+                                 dimlane_input_kind(it.plan, &it.layout, it.batch), 0};
         const int nt = (int)((it.batch + tpw - 1) / tpw);
         for (int t = 0; t < nt; ++t) units.push_back(MtgDlAnyUnit{(int)bi, t});
       }
@@ -1427,12 +1439,12 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
     for (const LaunchRecord& r : p->last) {
       if (r.rt) {
         r.rt->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status, r.params.tstatus,
-                     (int)r.params.B, r.params.K, r.ntiles, r.dl_ws);
+                     (int)r.params.B, r.params.K, r.ntiles, r.dl_ws, r.dl_aos);
         continue;
       }
       if (r.dl) {
         r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
-                     r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws);
+                     r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws, r.dl_aos);
         continue;
       }
       // (the cost accumulators are not re-zeroed between the timed launches: values are irrelevant here, and a memset

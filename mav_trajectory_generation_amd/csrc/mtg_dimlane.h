@@ -60,16 +60,21 @@ __host__ __device__ constexpr size_t mtg_dl_pair_bytes() {   // [slab A][slab B]
 template <class C, int DL, int NP>
 constexpr size_t mtg_dl_lds_bytes() { return NP * mtg_dl_pair_bytes<C, DL>(); }
 
-// Input loads of one lane's half-chain, canonical SoA (times[K][B], d_fixed[DL][n_fixed][B]): 32-bit byte offsets from
-// the two wave-uniform base pointers (global_load with an SGPR base), one add per load.  Needs 8 * B * (n_fixed * DL) < 4 GiB.
+// Input loads of one lane's half-chain: 32-bit byte offsets from the two wave-uniform base pointers (global_load with an
+// SGPR base), one add per load.  Needs 8 * B * (n_fixed * DL) < 4 GiB.  Two canonical layouts, chosen per launch
+// (wave-uniform `aos`): SoA (times[K][B], d_fixed[DL][n_fixed][B]: a wave's loads are contiguous) and AoS (times[B][K],
+// d_fixed[B][DL][n_fixed] -- the reference's natural order, one trajectory after the other: a lane's consecutive loads walk
+// through its own rows, the sectors are shared by the loads that follow).
 template <class C, int DIR>
 __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times, const double* __restrict__ dfix,
-                                               unsigned B, unsigned b, unsigned d, double (&T)[C::KCS], double (&fx)[1][C::NC]) {
+                                               unsigned B, unsigned b, unsigned d, unsigned dl, int aos,
+                                               double (&T)[C::KCS], double (&fx)[1][C::NC]) {
   constexpr int KC = DIR > 0 ? C::KA : C::KB;
   constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
   constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
-  const unsigned step = B * 8u;
-  unsigned ot = ((DIR > 0 ? 0u : (unsigned)(C::KT - 1)) * B + b) * 8u;
+  constexpr unsigned k0 = DIR > 0 ? 0u : (unsigned)(C::KT - 1);
+  const unsigned step = aos ? 8u : B * 8u;
+  unsigned ot = aos ? (b * (unsigned)C::KT + k0) * 8u : (k0 * B + b) * 8u;
   // Both directions write EVERY element of T and fx (zeros beyond their own count): with different store counts in the two
   // instantiations (odd K: KA = KB + 1, NCA = NCB + 1) the optimiser sinks the common tail of the two branches into one
   // block that stores through a phi of element POINTERS, and the arrays can no longer be promoted to registers (odd-K
@@ -83,7 +88,7 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
       T[j] = 0.0;
     }
   }
-  unsigned of = ((d * (unsigned)C::offFEnd + (unsigned)c0) * B + b) * 8u;
+  unsigned of = aos ? ((b * dl + d) * (unsigned)C::offFEnd + (unsigned)c0) * 8u : ((d * (unsigned)C::offFEnd + (unsigned)c0) * B + b) * 8u;
 #pragma unroll
   for (int c = 0; c < C::NC; ++c) {
     if (c < nc) {
@@ -110,7 +115,7 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
 template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE, int OCC = 1>
 __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ times, const double* __restrict__ dfix,
                                                   double* __restrict__ coeffs, int* status, int* traj_status, int B, int ntiles,
-                                                  int nwg, double* ws, const MtgSeqQueue* q
+                                                  int nwg, double* ws, int aos, const MtgSeqQueue* q
 #if defined(MTG_LAB_TIMING)
                                                   , long long* tdbg_base
 #endif
@@ -130,8 +135,8 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   const bool dup = d >= DL;            // surplus lanes (64 % DL) duplicate the last lane's work, outputs suppressed
   if (dup) { d = DL - 1; t = TPW - 1; }
   MtgParams P;
-  P.times = times; P.ts_b = 1; P.ts_k = B;
-  P.dfix = dfix; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)C::offFEnd * B;
+  P.times = times; P.ts_b = aos ? C::KT : 1; P.ts_k = aos ? 1 : B;
+  P.dfix = dfix; P.fs_b = aos ? DL * C::offFEnd : 1; P.fs_c = aos ? 1 : B; P.fs_d = aos ? C::offFEnd : (long long)C::offFEnd * B;
   P.coeffs = coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
   P.cost = nullptr; P.ws = ws; P.ws_stride = (long long)nwg * (NP * 2 * kWave);
@@ -176,8 +181,8 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   auto fetch = [&](const Where& w, double (&T_)[C::KCS], double (&fx_)[1][C::NC]) {
     unsigned bb = (unsigned)w.local * TPW + t;
     if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, T_, fx_);
-    else mtg_dl_preload<C, -1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, T_, fx_);
+    if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
+    else mtg_dl_preload<C, -1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
   };
   // Input prefetch (MTG_DL_PREFETCH, off by default -- see there): the NEXT tile's inputs requested before the current tile
   // is solved instead of after its coefficient stores (loads retire behind stores in the in-order vmcnt counter).
@@ -270,12 +275,12 @@ __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const
                                                                             const double* __restrict__ dfix,
                                                                             double* __restrict__ coeffs, int* status,
                                                                             int* traj_status, int B, int ntiles, int nwg,
-                                                                            double* ws
+                                                                            int aos, double* ws   // (aos: the 14th dword, still preloaded; ws is first needed late)
 #if defined(MTG_LAB_TIMING)
                                                                             , long long* tdbg_base
 #endif
 ) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, nullptr
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr
 #if defined(MTG_LAB_TIMING)
                                                 , tdbg_base
 #endif
@@ -286,8 +291,8 @@ __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const
 // the queue form: same body, the batches' pointer triples in the kernel arguments (mtg_solve_linear_sequence)
 template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
 __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
-                                                                                  double* ws, MtgSeqQueue q) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true, OCC>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, &q);
+                                                                                  int aos, double* ws, MtgSeqQueue q) {
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true, OCC>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, aos, &q);
 }
 #endif
 
@@ -312,8 +317,9 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   if (dup) { d = DL - 1; t = TPW - 1; }
   const int B = it.B;
   MtgParams P;
-  P.times = it.times; P.ts_b = 1; P.ts_k = B;
-  P.dfix = it.dfix; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)C::offFEnd * B;
+  const int aos = it.aos;
+  P.times = it.times; P.ts_b = aos ? C::KT : 1; P.ts_k = aos ? 1 : B;
+  P.dfix = it.dfix; P.fs_b = aos ? DL * C::offFEnd : 1; P.fs_c = aos ? 1 : B; P.fs_d = aos ? C::offFEnd : (long long)C::offFEnd * B;
   P.coeffs = it.coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
   P.cost = nullptr; P.ws = nullptr; P.ws_stride = ws_stride;
@@ -328,8 +334,8 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   const long long bl = b0 + t;
   const bool active = bl < B && !dup;
   const long long b = bl < B ? bl : B - 1;
-  if (dir == 0) mtg_dl_preload<C, 1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
-  else mtg_dl_preload<C, -1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, ln.T, ln.fx);
+  if (dir == 0) mtg_dl_preload<C, 1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx);
+  else mtg_dl_preload<C, -1>(it.times, it.dfix, (unsigned)B, (unsigned)b, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx);
   constexpr int mm = C::MI;
   constexpr size_t half = mtg_dl_half_bytes<C, DL>();
   char* my_slab = lds_raw + (size_t)dir * half;

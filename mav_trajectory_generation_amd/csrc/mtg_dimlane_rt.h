@@ -216,7 +216,7 @@ __host__ __device__ constexpr size_t mtg_rt_lds_bytes() { return 2 * mtg_rt_half
 template <class C, int DL, int R, int L, int AUX, bool PHASE>
 __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const double* __restrict__ times, const double* __restrict__ dfix,
                                                                      double* __restrict__ coeffs, int* status, int* traj_status,
-                                                                     int B, int K, int ntiles, double* ws) {
+                                                                     int B, int K, int ntiles, int aos, double* ws) {
   static_assert(C::DLW == DL && DL >= 1 && DL <= 4, "lanes per trajectory");
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const dou
   if (dup) { d = DL - 1; t = TPW - 1; }
   const int n_fixed = C::popc(C::MS) + (K - 1) * C::popc(C::MI) + C::popc(C::ME);
   MtgParams P;
-  P.times = times; P.ts_b = 1; P.ts_k = B;
-  P.dfix = dfix; P.fs_b = 1; P.fs_c = B; P.fs_d = (long long)n_fixed * B;
+  // inputs: canonical SoA (times[K][B], d_fixed[DL][n_fixed][B]) or, aos, canonical AoS (times[B][K], d_fixed[B][DL][n_fixed])
+  P.times = times; P.ts_b = aos ? K : 1; P.ts_k = aos ? 1 : B;
+  P.dfix = dfix; P.fs_b = aos ? DL * n_fixed : 1; P.fs_c = aos ? 1 : B; P.fs_d = aos ? n_fixed : (long long)n_fixed * B;
   P.coeffs = coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
   P.cost = nullptr; P.ws = ws; P.ws_stride = (long long)gridDim.x * (2 * kWave);
@@ -294,7 +295,7 @@ struct MtgDimlaneRtEntry {
   size_t lds;
   size_t step_bytes_per_lane;   // workspace bytes per head step and resident lane
   int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status, int* traj_status,
-                int B, int K, int ntiles, double* ws);
+                int B, int K, int ntiles, double* ws, int aos);
 };
 const MtgDimlaneRtEntry* mtg_find_dimlane_rt(int h, int dl, int k, int deriv, const int* mask);
 #endif  // MTG_DIMLANE_RT_H_

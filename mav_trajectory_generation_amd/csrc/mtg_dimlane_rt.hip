@@ -7,7 +7,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 template <class C, int DL, int R, int L>
 int launch_rt(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status, int* traj_status,
-              int B, int K, int ntiles, double* ws) {
+              int B, int K, int ntiles, double* ws, int aos) {
   constexpr size_t lds = mtg_rt_lds_bytes<C, DL, L>();
   static bool attr_set[2][kMaxDevices] = {};
   int dev = 0;
@@ -20,7 +20,7 @@ int launch_rt(void* stream, int grid, const double* times, const double* dfix, d
       done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kWave), lds, (hipStream_t)stream, times, dfix, coeffs, status, traj_status, B, K,
-                       ntiles, ws);
+                       ntiles, aos, ws);
     return 0;
   };
   if constexpr ((DL * C::N * 8) % 64 != 0) {

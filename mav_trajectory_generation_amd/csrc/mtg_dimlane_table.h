@@ -8,7 +8,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 template <class C, int DL, int NP, int OCC = 1>
 int launch_dl(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
-              int* traj_status, int B, int ntiles, int policy, double* ws) {
+              int* traj_status, int B, int ntiles, int policy, double* ws, int aos) {
   constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
   // (the attribute is a property of the function ON A DEVICE: one flag per device for processes that drive several GPUs)
   static bool attr_set[3][kMaxDevices] = {};
@@ -21,7 +21,7 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
       attr_set[slot][dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid, ws);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid, aos, ws);
     return 0;
   };
 #if !defined(MTG_DL_SINGLE_POLICY)
@@ -36,7 +36,7 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
 #if !defined(MTG_DL_SINGLE_POLICY)
 // the queue form (mtg_solve_linear_sequence): nt sc1 stores, main table only
 template <class C, int DL, int NP, int OCC = 1>
-int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws) {
+int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws, int aos) {
   constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
@@ -46,7 +46,7 @@ int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, i
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, (hipStream_t)stream, status, B, ntiles, grid, ws, *q);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, (hipStream_t)stream, status, B, ntiles, grid, aos, ws, *q);
   return 0;
 }
 #define MTG_DL_QUEUE_FN(...) launch_dl_queue<__VA_ARGS__>

@@ -496,12 +496,13 @@ struct MtgDimlaneEntry {
   size_t lds;         // dynamic LDS per workgroup
   size_t ws_per_lane; // long-chain variants (MtgCfg::WSJ > 0): workspace bytes per resident lane (grid * np * 128 lanes), else 0
   // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
-  // cache policy (0 nt sc1, 1 sc1, 2 write-back); returns 0 or -1 (attribute / launch set-up failed)
+  // cache policy (0 nt sc1, 1 sc1, 2 write-back); aos: input layout (0 canonical SoA, 1 canonical AoS); returns 0 or -1
+  // (attribute / launch set-up failed)
   int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
-                int* traj_status, int B, int ntiles, int policy, double* ws);
+                int* traj_status, int B, int ntiles, int policy, double* ws, int aos);
   // a queue of batches in one launch (mtg_solve_linear_sequence; main-table variants only, else null): ntiles = tiles of
   // all batches (q->n * q->tiles_per_batch)
-  int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws);
+  int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws, int aos);
   int occ;            // waves per SIMD the kernel's registers allow: 1, or 2 for the throughput twins (MTG_DLO)
 };
 // cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
@@ -512,10 +513,11 @@ const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const i
 
 // cross-structure dimension-in-lane launches (mtg_dimlane.h: mtg_solve_dl_any_kernel)
 struct MtgDlAnyItem {     // one bucket
-  const double* times;    // [K][B]
-  const double* dfix;     // [DL][n_fixed][B]
+  const double* times;    // [K][B] (aos: [B][K])
+  const double* dfix;     // [DL][n_fixed][B] (aos: [B][DL][n_fixed])
   double* coeffs;         // [B][K][DL][N]
   int B, cfg;
+  int aos, pad_;          // input layout of this bucket: 0 canonical SoA, 1 canonical AoS
 };
 struct MtgDlAnyUnit { int item, tile; };
 int mtg_dl_any_index(const MtgDimlaneEntry* e);     // configuration index of a 3-dimensional variant, or -1

@@ -251,9 +251,11 @@ def test_default_form_cross_over_is_pinned(ctx):
     assert plan.launch_form(10_000) == "dimlane" and plan.launch_form(edge) == "dimlane"
     assert plan.launch_form(edge + 1) == "slab" and plan.launch_form(125_000) == "slab"
     assert plan.launch_form(125_000, dims="dimlane") == "dimlane" and plan.launch_form(10_000, dims="split") == "split"
-    # the dimension-in-lane form needs canonical SoA inputs; coefficient-only calls of a shape with a slab-output kernel
-    # never take the split form by default (partial sectors: 15.4 vs 10.4 us at 10k with rotating buffers)
-    assert plan.launch_form(10_000, layout="aos") == "slab" and plan.launch_form(20_000) == "slab"
+    # the dimension-in-lane form reads canonical SoA and canonical AoS inputs (same cross-over); coefficient-only calls of a
+    # shape with a slab-output kernel never take the split form by default (partial sectors: 15.4 vs 10.4 us at 10k with
+    # rotating buffers)
+    assert plan.launch_form(10_000, layout="aos") == "dimlane" and plan.launch_form(edge + 1, layout="aos") == "slab"
+    assert plan.launch_form(20_000) == "slab"
     plan.close()
     p5 = m.Plan(ctx, 10, 4, 16, 4, m.ends_full_masks(10, 16, 7))      # config 5: no upper limit
     assert p5.launch_form(12_500) == "dimlane" and p5.launch_form(1_000_000) == "dimlane"
@@ -385,3 +387,79 @@ def test_runtime_k_body_status(ctx_rt):
     got = st.cpu().numpy()
     assert sorted(np.nonzero(got & 1)[0].tolist()) == sorted(bad)
     plan.close()
+
+
+# ---- canonical AoS inputs (times[B][K], d_fixed[B][D][n_fixed]: the reference's natural order) through the same kernels ----
+AOS_SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 2, 3, 4, 1), (8, 7, 3, 3, 1), (12, 5, 3, 5, 1),
+              (10, 16, 4, 4, 7), (10, 16, 3, 4, 1), (10, 32, 3, 4, 1), (8, 32, 3, 3, 1), (12, 16, 3, 5, 1), (12, 32, 3, 5, 1),
+              (10, 27, 3, 4, 1), (12, 21, 3, 5, 1),
+              (10, 40, 3, 4, 1), (12, 50, 3, 5, 1), (8, 100, 3, 3, 1), (10, 9, 4, 4, 1), (10, 24, 4, 4, 7), (10, 33, 3, 4, 3)]   # run-time-K body
+
+
+@pytest.mark.parametrize("shape", AOS_SHAPES)
+@pytest.mark.parametrize("bsz", [1, 22, 300])
+def test_dimlane_reads_aos_inputs(ctx, shape, bsz):
+    """The dimension-in-lane forms (static variants, long-chain hybrids with on-demand input loads, the run-time-K body) take
+    canonical AoS inputs as well: same lanes, same arithmetic, only the load addresses differ -> bit-identical coefficients."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, d, mi = shape
+    masks = m.ends_full_masks(n, k, mi)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    ta, fa = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=31 * n + k, device="cuda", layout="aos")
+    ts, fs = ta.t().contiguous(), fa.permute(1, 2, 0).contiguous()
+    form = plan.launch_form(bsz, "aos", "dimlane")
+    assert form in ("dimlane", "dimlane_rt") and form == plan.launch_form(bsz, "soa", "dimlane")
+    co_a = torch.full((bsz + 1, k, dim, n), 7.0, dtype=torch.float64, device="cuda")
+    plan.solve(ta, fa, layout="aos", coeffs=co_a[:bsz], dims="dimlane")
+    co_s, _, _ = plan.solve(ts, fs, layout="soa", dims="dimlane")
+    ctx.sync()
+    assert float(co_a[bsz].min()) == 7.0 and float(co_a[bsz].max()) == 7.0
+    assert torch.equal(co_a[:bsz], co_s)
+    nb = min(bsz, 4)
+    c_lit, _, _ = onp.solve_batch(n, d, masks, ta[:nb].cpu().numpy(), fa[:nb].cpu().numpy())
+    assert helpers.poly_relerr(co_a[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    plan.close()
+
+
+def test_aos_inputs_through_queue_mixed_request_and_host_pointers(ctx):
+    """AoS inputs on the other entry points that run dimension-in-lane kernels: mtg_solve_linear_sequence's queue launch,
+    mtg_multi_solve's cross-structure launch, and a host-pointer call (the C++ veneer's layout)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    # queue (config 5 shape: dimension-in-lane only)
+    masks = m.ends_full_masks(10, 16, 7)
+    plan = m.Plan(ctx, 10, 4, 16, 4, masks)
+    sets_a, sets_s = [], []
+    for s in range(3):
+        ta, fa = m.random_waypoint_batch(700, 16, 4, 10, masks, seed=900 + s, device="cuda", layout="aos")
+        sets_a.append((ta, fa, torch.zeros((700, 16, 4, 10), dtype=torch.float64, device="cuda")))
+        sets_s.append((ta.t().contiguous(), fa.permute(1, 2, 0).contiguous(), torch.zeros((700, 16, 4, 10), dtype=torch.float64, device="cuda")))
+    plan.solve_sequence(sets_a, layout="aos")
+    plan.solve_sequence(sets_s, layout="soa")
+    ctx.sync()
+    for a, s_ in zip(sets_a, sets_s):
+        assert float(a[2].abs().max()) > 0 and torch.equal(a[2], s_[2])
+    # host pointers, AoS numpy (the veneer's batch call): dimension-in-lane is the default form at this size
+    assert plan.launch_form(700, "aos") == "dimlane"
+    co_h, _, _ = plan.solve_host(sets_a[0][0].cpu().numpy(), sets_a[0][1].cpu().numpy(), want_free=False, want_cost=False)
+    ctx.sync()
+    assert np.array_equal(co_h, sets_a[0][2].cpu().numpy())
+    plan.close()
+    # cross-structure launch: buckets in mixed layouts
+    buckets_a, buckets_s = [], []
+    for i, (n, k) in enumerate(((8, 4), (10, 8), (12, 16), (10, 32))):
+        mk = m.ends_full_masks(n, k, 1)
+        ta, fa = m.random_waypoint_batch(333, k, 3, n, mk, seed=77 + i, device="cuda", layout="aos")
+        ts, fs = ta.t().contiguous(), fa.permute(1, 2, 0).contiguous()
+        mixed = (ta, fa, "aos") if i % 2 == 0 else (ts, fs, "soa")
+        buckets_a.append(dict(n_coeffs=n, derivative=n // 2 - 1, masks=mk, times=mixed[0], d_fixed=mixed[1], layout=mixed[2]))
+        buckets_s.append(dict(n_coeffs=n, derivative=n // 2 - 1, masks=mk, times=ts, d_fixed=fs, layout="soa"))
+    solver = m.MixedBatchSolver(ctx, n_streams=1)
+    ra, rs = solver.merged(buckets_a), solver.merged(buckets_s)
+    assert ra.launch_count == 1 and rs.launch_count == 1
+    out_a, out_s = ra.solve(), rs.solve()
+    solver.sync()
+    ctx.sync()
+    for (ca, _), (cs, _) in zip(out_a, out_s):
+        assert torch.equal(ca, cs)

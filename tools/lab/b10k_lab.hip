@@ -209,7 +209,7 @@ int main(int argc, char** argv) {
     auto go = [=, &dt, &df, &dc](int i) {
       const int s = rot_in ? i % NSETS : 0, so = rot_out ? i % NSETS : 0;
       hipLaunchKernelGGL(kern, dim3(nwg_dl), dim3(256), lds_dl, st, (const double*)dt[s], (const double*)df[s], dc[so],
-                         dstat, (int*)nullptr, B, ntiles_dl, nwg_dl, (double*)nullptr
+                         dstat, (int*)nullptr, B, ntiles_dl, nwg_dl, 0, (double*)nullptr
 #if defined(MTG_LAB_TIMING)
                          , dbg
 #endif

@@ -23,7 +23,7 @@ def resources(H, K, WS, LS, RS=0, full=False):
     src = f"/tmp/search_ws_{H}_{K}_{WS}_{LS}_{RS}.hip"
     with open(src, "w") as f:
         f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<' + cfg +
-                ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, double*);\n')
+                ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, int, double*);\n')
     p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
                         "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-mllvm",
                         "-pragma-unroll-threshold=1000000", "--cuda-device-only", "-c", src, "-o", src + ".o",
