@@ -101,6 +101,8 @@ enum {
                                      /* own best launch, spread over the context's side       */
                                      /* streams (longest chains first), forked from and       */
                                      /* joined back onto the context's stream                 */
+  MTG_FLAG_QUERY_EXTRA_OUTPUTS = 1u << 9, /* mtg_plan_launch_form only: the form of a call that */
+                                     /* also asks for the cost and / or d_free                */
   MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 1u << 8 /* mtg_solve_linear_sequence: never merge   */
                                      /* the queue into one persistent launch (latency of the  */
                                      /* single launches; A/B measurements)                    */
@@ -127,7 +129,7 @@ int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
  * used from another thread than their creator synchronise THIS context, not their own thread's.                     */
 mtg_context* mtg_plan_context(const mtg_plan* plan);
 /* Which kernel form a device-pointer mtg_solve_linear(plan, batch, layout, ..., flags) call with coefficient output only
- * takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
+ * (with MTG_FLAG_QUERY_EXTRA_OUTPUTS: a call that also returns the cost / d_free) takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
  * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane (one unrolled body per chain length), 6 dimension-in-lane
  * with a run-time chain length (one body per polynomial order).  Negative: mtg_status.                                 */
 int mtg_plan_launch_form(const mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint32_t flags);

@@ -106,6 +106,7 @@ FLAG_DIMLANE = 32
 FLAG_HOST_BACKEND = 64
 FLAG_CONCURRENT_ITEMS = 128
 FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 256
+FLAG_QUERY_EXTRA_OUTPUTS = 512
 
 _lib = None
 

@@ -350,10 +350,13 @@ class Plan:
 
     LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane", 6: "dimlane_rt"}
 
-    def launch_form(self, batch: int, layout: str = "soa", dims: str = "auto") -> str:
-        """Kernel form a coefficient-only device-pointer solve of `batch` trajectories takes (mtg_plan_launch_form)."""
+    def launch_form(self, batch: int, layout: str = "soa", dims: str = "auto", extra_outputs: bool = False) -> str:
+        """Kernel form a coefficient-only device-pointer solve of `batch` trajectories takes (mtg_plan_launch_form);
+        extra_outputs: of a solve that also returns the cost / d_free."""
         lay = self.layout(batch, layout)
         flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        if extra_outputs:
+            flags |= L.FLAG_QUERY_EXTRA_OUTPUTS
         rc = self.lib.mtg_plan_launch_form(self.handle, batch, ctypes.byref(lay), flags)
         if rc < 0:
             _check(self.lib, rc, self.ctx.handle)

@@ -111,6 +111,7 @@ struct mtg_context {
   int dl_max_units_per_cu = -1;      // MTG_DL_MAX_UNITS: overrides the variants' upper limit (workgroups <= this x CUs; 0: none)
   bool knob_no_slab = false;         // MTG_NO_SLAB: fused form without the slab-output kernel
   bool knob_no_slab_extra = false;   // MTG_NO_SLAB_EXTRA: extra outputs (cost / d_P) through the older fused kernel
+  bool knob_no_dl_extra = false;     // MTG_NO_DL_EXTRA: extra outputs never through the dimension-in-lane kernels
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
   int knob_dl_grid_per_cu = 8;       // MTG_DL_GRID_PER_CU: workgroups per CU of a (non-workspace) dimension-in-lane launch
   int knob_dl_rt = -1;               // MTG_DL_RT: 1 = the run-time-K body even where a static variant exists, 0 = never (default: where none exists)
@@ -119,7 +120,7 @@ struct mtg_context {
   bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
-  int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back)
+  int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
@@ -266,6 +267,7 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
   ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
   ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
   ctx->knob_no_slab_extra = getenv("MTG_NO_SLAB_EXTRA") != nullptr;
+  ctx->knob_no_dl_extra = getenv("MTG_NO_DL_EXTRA") != nullptr;
   ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
   if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
   if (const char* e = getenv("MTG_DL_RT")) ctx->knob_dl_rt = atoi(e);
@@ -501,7 +503,10 @@ static int dimlane_input_kind(const mtg_plan* p, const mtg_layout* L, int64_t ba
 static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P,
                                            uint32_t flags, bool cost_only) {
   const MtgDimlaneEntry* dl = p->dimlane;
-  if (!dl || p->ctx->knob_no_dimlane || cost_only || P.dfree || P.cost) return nullptr;
+  if (!dl || p->ctx->knob_no_dimlane || cost_only) return nullptr;
+  // extra outputs (cost / d_P): the main-table variants have a kernel for them (round 3; MTG_NO_DL_EXTRA: as before, through
+  // the fused kernels)
+  if ((P.dfree || P.cost) && (!dl->launch_extra || p->ctx->knob_no_dl_extra)) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
   if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
@@ -741,8 +746,11 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
       }
     }
     const int aos = dimlane_input_kind(p, L, batch);
-    if (dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws, aos) != 0)
-      return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
+    const int lrc = (P.dfree || P.cost)
+                        ? dl->launch_extra((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, dl_ws, aos, P.dfree, P.cost,
+                                           P.ps_b, P.ps_d, P.ps_c)
+                        : dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws, aos);
+    if (lrc != 0) return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
     LaunchRecord r;
     r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws; r.dl_aos = aos;
     p->last.push_back(r);
@@ -862,12 +870,18 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
 int mtg_plan_launch_form(const mtg_plan* p, int64_t batch, const mtg_layout* L, uint32_t flags) {
   if (!p || !L || batch <= 0 || (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY))) return MTG_ERR_INVALID_ARGUMENT;
   MtgParams P;
-  fill_common(p, P, batch, L);   // (no d_free / cost output: coefficient output only)
+  fill_common(p, P, batch, L);   // (no d_free / cost output: coefficient output only ...
+  const bool extra = (flags & MTG_FLAG_QUERY_EXTRA_OUTPUTS) != 0;
+  static double cost_stands_for_any_extra_output = 0.0;
+  if (extra) P.cost = &cost_stands_for_any_extra_output;   // ... unless asked for the form of a call with extra outputs; never dereferenced)
+  flags &= ~(uint32_t)MTG_FLAG_QUERY_EXTRA_OUTPUTS;
   if (pick_dimlane_rt(p, batch, L, P, flags, false)) return 6;
   if (pick_dimlane(p, batch, L, P, flags, false)) return 5;
-  const MtgStaticEntry* var = pick_static(p, (int)((batch + kWave - 1) / kWave), flags, true);
+  const MtgStaticEntry* var = pick_static(p, (int)((batch + kWave - 1) / kWave), flags, !extra);
   if (!var) return 0;
-  if (pick_slab(p, var)) return 4;
+  if (const MtgSlabEntry* slab = pick_slab(p, var)) {
+    if (!extra || (slab->extra && !p->ctx->knob_no_slab_extra)) return 4;
+  }
   if (var->k < 0) return 3;
   return var->d == p->D ? 1 : 2;
 }
@@ -1443,8 +1457,13 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
         continue;
       }
       if (r.dl) {
-        r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
-                     r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws, r.dl_aos);
+        if (r.params.dfree || r.params.cost)
+          r.dl->launch_extra((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
+                             r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_ws, r.dl_aos, r.params.dfree, r.params.cost,
+                             r.params.ps_b, r.params.ps_d, r.params.ps_c);
+        else
+          r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
+                       r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws, r.dl_aos);
         continue;
       }
       // (the cost accumulators are not re-zeroed between the timed launches: values are irrelevant here, and a memset

@@ -112,12 +112,16 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
 // QUEUE (mtg_solve_dl_queue_kernel, mtg_solve_linear_sequence): `ntiles` counts the tiles of ALL batches of the queue
 // (batch-major, q->tiles_per_batch each); a wave's tile index -> (batch, tile inside it) is advanced incrementally
 // (wave-uniform) and the batch's pointer triple comes from the kernel arguments.
+// extra outputs of a launch (OUT bits 0 / 1: cost, d_P): destination pointers (either may be null) and the d_P strides
+struct MtgDlExtra { double* dfree; double* cost; long long ps_b, ps_d, ps_c; };
+
 template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE, int OCC = 1>
 __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ times, const double* __restrict__ dfix,
                                                   double* __restrict__ coeffs, int* status, int* traj_status, int B, int ntiles,
-                                                  int nwg, double* ws, int aos, const MtgSeqQueue* q
+                                                  int nwg, double* ws, int aos, const MtgSeqQueue* q,
+                                                  const MtgDlExtra* xo = nullptr
 #if defined(MTG_LAB_TIMING)
-                                                  , long long* tdbg_base
+                                                  , long long* tdbg_base = nullptr
 #endif
 ) {
   static_assert(C::kStatic && C::D == 1 && C::KT >= 2, "dimension-in-lane form: static one-dimension configurations");
@@ -140,6 +144,10 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   P.coeffs = coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
   P.cost = nullptr; P.ws = ws; P.ws_stride = (long long)nwg * (NP * 2 * kWave);
+  if constexpr ((OUT & 3) != 0) {     // cost: per-lane partial sums (dimension lane x direction) added atomically to cost[b] (zeroed by the host)
+    P.dfree = xo->dfree; P.ps_b = xo->ps_b; P.ps_d = xo->ps_d; P.ps_c = xo->ps_c;
+    P.cost = xo->cost;
+  }
   double* wsl0 = C::WSJ > 0 ? ws + (size_t)blockIdx.x * (NP * 2 * kWave) + threadIdx.x : nullptr;   // long chains (C::WSJ): this lane's workspace column
   P.ws_share = (long long)t - lane;   // (dup lanes: their clamped trajectory's columns)
   P.status = status; P.tstatus = traj_status;
@@ -230,7 +238,8 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if constexpr (QUEUE) { P.times = cur.t; P.dfix = cur.f; P.coeffs = cur.c; }
     const long long b0 = (long long)cur.local * TPW;
     const long long bl = b0 + t;
-    const bool active = bl < B && !dup;
+    // (the surplus unit of an odd tile count, NP == 2, repeats the last tile: same coefficients, but no second cost term)
+    const bool active = bl < B && !dup && NP * it + pair < ntiles;
     const long long b = bl < B ? bl : B - 1;
     // the workspace column pointer is re-defined opaquely per tile: otherwise every one of the ~(f*f + f) * WSJ store and
     // load addresses derived from it is loop-invariant, gets hoisted out of the tile loop and spills (measured: 233
@@ -243,12 +252,23 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     MTG_DL_STAMP(2);
     __syncthreads();
     MTG_DL_STAMP(3);
+    [[maybe_unused]] double part = 0.0;
     if (dir == 0) {
       ioA.begin_tile(cur.c, b0, B);
-      mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active);
+      mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active, (OUT & 1) ? &part : nullptr);
     } else {
       ioB.begin_tile(cur.c, b0, B);
-      mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active);
+      mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active, (OUT & 1) ? &part : nullptr);
+    }
+    if constexpr ((OUT & 1) != 0) {
+      // cost of this half-chain: the DL dimension lanes of a trajectory summed in a fixed order by the dimension-0 lane,
+      // then ONE atomic add per direction onto the zeroed cost[b] -- 0 + a + b in either order: bit-reproducible
+#if defined(__HIP_DEVICE_COMPILE__)
+      double sum = part;
+#pragma unroll
+      for (int k = 1; k < DL; ++k) sum += mtg_bperm(4 * ((lane_io + k * TPW) & 63), part);
+      if (P.cost != nullptr && active && lane_io < TPW) atomicAdd(P.cost + b, sum);
+#endif
     }
 #if defined(MTG_LAB_TIMING)
     MTG_DL_STAMP(4);
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const
                                                                             , long long* tdbg_base
 #endif
 ) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr
 #if defined(MTG_LAB_TIMING)
                                                 , tdbg_base
 #endif
@@ -288,6 +308,17 @@ __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const
 }
 
 #if !defined(MTG_LAB_TIMING)
+// solves that also return the cost and / or d_P (OUT = 3; round 3): same body, the cost as per-lane partial sums (dimension
+// lane x direction) added atomically to cost[b], d_P written by the lane that owns the vertex and the dimension
+template <class C, int DL, int NP, int AUX>
+__global__ __launch_bounds__(NP * 2 * kWave, 1) void mtg_solve_dl_extra_kernel(const double* __restrict__ times,
+                                                                              const double* __restrict__ dfix,
+                                                                              double* __restrict__ coeffs, int* status,
+                                                                              int* traj_status, int B, int ntiles, int nwg,
+                                                                              int aos, double* ws, MtgDlExtra xo) {
+  mtg_solve_dl_body<C, DL, NP, 3, AUX, false, 1>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, &xo);
+}
+
 // the queue form: same body, the batches' pointer triples in the kernel arguments (mtg_solve_linear_sequence)
 template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
 __global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,

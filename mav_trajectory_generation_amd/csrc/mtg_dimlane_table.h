@@ -24,7 +24,9 @@ int launch_dl(void* stream, int grid, const double* times, const double* dfix, d
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, st, times, dfix, coeffs, status, traj_status, B, ntiles, grid, aos, ws);
     return 0;
   };
-#if !defined(MTG_DL_SINGLE_POLICY)
+#if defined(MTG_DL_ALL_POLICIES) && !defined(MTG_DL_SINGLE_POLICY)
+  // (round 2's store-policy experiments, profiles/r02_lab_*.txt; not part of the default build since round 3: the main
+  // table's build time goes to the extra-output kernels instead)
   if constexpr (OCC == 1) {
     if (policy == 1) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 16>, 1);
     if (policy == 2) return go(mtg_solve_dl_kernel<C, DL, NP, 0, 0>, 2);
@@ -50,8 +52,28 @@ int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, i
   return 0;
 }
 #define MTG_DL_QUEUE_FN(...) launch_dl_queue<__VA_ARGS__>
+// solves with extra outputs (cost / d_P): nt sc1 stores, main table only
+template <class C, int DL, int NP, int OCC = 1>
+int launch_dl_extra(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
+                    int* traj_status, int B, int ntiles, double* ws, int aos, double* dfree, double* cost, long long ps_b,
+                    long long ps_d, long long ps_c) {
+  constexpr size_t lds = mtg_dl_lds_bytes<C, DL, NP>();
+  static bool attr_set[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+  auto kern = mtg_solve_dl_extra_kernel<C, DL, NP, 18>;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2 * kWave), lds, (hipStream_t)stream, times, dfix, coeffs, status, traj_status, B,
+                     ntiles, grid, aos, ws, MtgDlExtra{dfree, cost, ps_b, ps_d, ps_c});
+  return 0;
+}
+#define MTG_DL_EXTRA_FN(...) launch_dl_extra<__VA_ARGS__>
 #else
 #define MTG_DL_QUEUE_FN(...) nullptr
+#define MTG_DL_EXTRA_FN(...) nullptr
 #endif
 }  // namespace
 
@@ -64,7 +86,8 @@ int launch_dl_queue(void* stream, int grid, const MtgSeqQueue* q, int* status, i
    (size_t)(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSJ - MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::LSJ) *           \
        MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS)::WSE * sizeof(double),                                                   \
    launch_dl<MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC>,                                                    \
-   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC), OCC},
+   MTG_DL_QUEUE_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC), OCC,                                          \
+   MTG_DL_EXTRA_FN(MTG_DLCFG(H, K, MS, MI, ME, DV, DL, WS, LS, RS), DL, NP, OCC)},
 #define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 0, 1)
 #define MTG_DLR(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 1, 1)
 #define MTG_DLO(H, K, MS, MI, ME, DV, DL, NP, RS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, 0, 0, 0, 0, RS, 2)

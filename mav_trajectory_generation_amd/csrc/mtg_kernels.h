@@ -504,6 +504,11 @@ struct MtgDimlaneEntry {
   // all batches (q->n * q->tiles_per_batch)
   int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws, int aos);
   int occ;            // waves per SIMD the kernel's registers allow: 1, or 2 for the throughput twins (MTG_DLO)
+  // solves that also return the cost and / or d_P (either pointer may be null; cost zeroed by the caller; ps_*: d_P strides
+  // in doubles); main-table variants only, else null
+  int (*launch_extra)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
+                      int* traj_status, int B, int ntiles, double* ws, int aos, double* dfree, double* cost, long long ps_b,
+                      long long ps_d, long long ps_c);
 };
 // cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
 // dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])

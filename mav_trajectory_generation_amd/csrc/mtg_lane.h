@@ -1215,7 +1215,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
 // are suppressed; every lane still takes part in the cooperative coefficient flush).
 template <class C, int DIR, int OUT, class IO>
 MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
-                            const double* other, int stride, IO& io, bool active) {
+                            const double* other, int stride, IO& io, bool active, double* cost_out = nullptr) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
@@ -1327,7 +1327,9 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   }
   io.flush(P);
   if constexpr ((OUT & 1) != 0) {
-    if (P.cost != nullptr && active) {
+    if (cost_out != nullptr) {        // the caller combines the lanes' partial sums (dimension-in-lane form)
+      *cost_out = cost;
+    } else if (P.cost != nullptr && active) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(P.cost + b, cost);
 #else

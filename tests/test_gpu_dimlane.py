@@ -463,3 +463,47 @@ def test_aos_inputs_through_queue_mixed_request_and_host_pointers(ctx):
     ctx.sync()
     for (ca, _), (cs, _) in zip(out_a, out_s):
         assert torch.equal(ca, cs)
+
+
+# ---- solves that also return the cost / d_P through the dimension-in-lane kernels (mtg_solve_dl_extra_kernel) ------------
+EXTRA_SHAPES = [(10, 8, 3, 4, 1), (10, 8, 4, 4, 1), (10, 8, 1, 4, 1), (10, 4, 3, 4, 1), (10, 2, 3, 4, 1), (8, 4, 3, 3, 1),
+                (8, 8, 3, 3, 1), (12, 4, 3, 5, 1), (12, 8, 3, 5, 1), (10, 16, 4, 4, 7), (8, 16, 3, 3, 1), (10, 16, 3, 4, 1),
+                (12, 16, 3, 5, 1), (10, 32, 3, 4, 1), (8, 32, 3, 3, 1), (12, 32, 3, 5, 1)]
+
+
+@pytest.mark.parametrize("shape", EXTRA_SHAPES)
+@pytest.mark.parametrize("bsz,layout", [(1, "soa"), (22, "aos"), (300, "soa"), (1000, "aos")])
+def test_dimlane_extra_outputs(ctx, shape, bsz, layout):
+    """cost and d_P from the dimension-in-lane kernels: against the fused kernels' (same lane arithmetic; the cost is summed
+    in another order) and the oracle; bit-reproducible from run to run (the dimension lanes are summed in a fixed order, one
+    atomic per chain direction); coefficients bit-identical to the coefficient-only launch."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, d, mi = shape
+    masks = m.ends_full_masks(n, k, mi)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    assert plan.launch_form(bsz, layout, extra_outputs=True) == "dimlane"
+    t, f = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=17 * n + k, device="cuda", layout=layout)
+    co, fr, cost = plan.solve(t, f, layout=layout, want_free=True, want_cost=True)
+    co2, fr2, cost2 = plan.solve(t, f, layout=layout, want_free=True, want_cost=True)
+    co0, _, _ = plan.solve(t, f, layout=layout, dims="dimlane")
+    _, _, cost_only = plan.solve(t, f, layout=layout, want_cost=True)
+    cf, ff, jf = plan.solve(t, f, layout=layout, want_free=True, want_cost=True, dims="fused")
+    ctx.sync()
+    assert torch.equal(co, co2) and torch.equal(fr, fr2) and torch.equal(cost, cost2) and torch.equal(cost, cost_only)
+    assert torch.equal(co, co0)
+    tol = 1e-12 if n <= 10 else 1e-10
+    rel, _ = ctx.compare_coefficients(co, cf)
+    assert rel < tol
+    assert torch.allclose(cost, jf, rtol=1e-11 if n <= 10 else 1e-9, atol=0)
+    scale = ff.abs().amax().clamp_min(1e-300)
+    assert float((fr - ff).abs().amax() / scale) < tol
+    nb = min(bsz, 4)
+    ta = t[:nb] if layout == "aos" else t.t()[:nb]
+    fa = f[:nb] if layout == "aos" else f.permute(2, 0, 1)[:nb]
+    fra = fr[:nb] if layout == "aos" else fr.permute(2, 0, 1)[:nb]
+    c_lit, f_lit, j_lit = onp.solve_batch(n, d, masks, ta.contiguous().cpu().numpy(), fa.contiguous().cpu().numpy())
+    assert helpers.poly_relerr(co[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    assert np.allclose(cost[:nb].cpu().numpy(), j_lit, rtol=1e-6)
+    assert np.allclose(fra.contiguous().cpu().numpy(), f_lit, rtol=1e-6, atol=1e-6 * np.abs(f_lit).max())
+    plan.close()

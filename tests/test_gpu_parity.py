@@ -638,8 +638,8 @@ def test_cross_structure_dimlane_request(ctx):
     """mtg_multi_*: items with canonical SoA inputs whose plans have a static dimension-in-lane configuration join ONE
     cross-structure launch (mtg_solve_dl_any_kernel), whatever their N and K -- BASELINE config 4's twelve buckets in one
     launch, back-substitution data in registers.  Bit-for-bit equal to the per-bucket dimension-in-lane launches; ragged
-    bucket sizes (tile tails), two buckets of one plan, an AoS bucket (-> the rolled merged path) in the same request,
-    re-solve with new values, bad segment time reported through the context status."""
+    bucket sizes (tile tails), two buckets of one plan, an AoS bucket (round 3: part of the same launch; a strided one -> its
+    own ordinary launch) in the same request, re-solve with new values, bad segment time reported through the context status."""
     import torch
     import mav_trajectory_generation_amd as m
     buckets, sizes = [], [700, 21, 1, 64, 333, 2500, 43, 700, 700, 22, 640, 100]
@@ -659,7 +659,7 @@ def test_cross_structure_dimlane_request(ctx):
                         d_fixed=torch.from_numpy(d_fixed).cuda()))
     solver = m.MixedBatchSolver(ctx, n_streams=1)
     req = solver.merged(buckets)
-    assert req.launch_count == 2        # the cross-structure launch + the AoS bucket's ordinary launch
+    assert req.launch_count == 1        # ONE cross-structure launch, the AoS bucket included
 
     def reference():
         out = []
