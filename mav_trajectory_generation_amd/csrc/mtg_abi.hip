@@ -507,6 +507,9 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   // extra outputs (cost / d_P): the main-table variants have a kernel for them (round 3; MTG_NO_DL_EXTRA: as before, through
   // the fused kernels)
   if ((P.dfree || P.cost) && (!dl->launch_extra || p->ctx->knob_no_dl_extra)) return nullptr;
+  // (N = 12 / K = 32 with extra outputs spills 544 registers: 110 vs 128 us at 10k, but 542 vs 443 us at 50k against the
+  // rolled fused kernel -- profiles/r03r_k32_extra_outputs.jsonl)
+  if ((P.dfree || P.cost) && dl->h == 6 && dl->k == 32 && batch > 20000 && !(flags & MTG_FLAG_DIMLANE)) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
   if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
   if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;

@@ -6,10 +6,14 @@ import torch
 import mav_trajectory_generation_amd as m
 nsets = 6
 ctx = m.Context(0)
-for (N, K, d, D, mi) in ((10, 8, 4, 3, 1), (10, 16, 4, 4, 7), (12, 16, 5, 3, 1), (10, 32, 4, 3, 1), (8, 16, 3, 3, 1)):
+SHAPES = ((10, 8, 4, 3, 1), (10, 16, 4, 4, 7), (12, 16, 5, 3, 1), (10, 32, 4, 3, 1), (8, 16, 3, 3, 1))
+if os.environ.get("SHAPES"):      # e.g. SHAPES="12,32,5,3,1;8,32,3,3,1"  (N, K, derivative, D, interior mask)
+    SHAPES = tuple(tuple(int(x) for x in s_.split(",")) for s_ in os.environ["SHAPES"].split(";"))
+BATCHES = tuple(int(x) for x in os.environ.get("BATCHES", "10000,100000").split(","))
+for (N, K, d, D, mi) in SHAPES:
     masks = m.ends_full_masks(N, K, mi)
     plan = m.Plan(ctx, N, D, K, d, masks)
-    for B in (10_000, 100_000):
+    for B in BATCHES:
         if K * B > 2_000_000:
             continue
         row = dict(N=N, K=K, D=D, B=B, form=plan.launch_form(B, "soa"))
