@@ -378,9 +378,12 @@ def main():
         e0.record(ctx.stream)   # (creates the underlying hipEvent_t handles: torch makes them on first record)
         e1.record(ctx.stream)
 
+        stamps = {}
+
         def finish():
             while not e1.query():   # spin on the end event (a blocking synchronize alone wakes up ~30 us late) ...
                 pass
+            stamps["done"] = time.perf_counter()
             barrier()               # ... then the contract's barrier + torch.cuda.synchronize()
 
         def timed(loop_, steps, warmup):
@@ -390,8 +393,14 @@ def main():
             barrier()
             t0 = time.perf_counter()
             loop_.run(steps, first=warmup, start_event=e0, stop_event=e1)   # events recorded around the launches
+            stamps["enqueued"] = time.perf_counter()
             finish()
-            return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e3 / steps   # wall seconds, device us per step
+            t1 = time.perf_counter()
+            # where the wall clock of the timed region goes (host side): the library call that enqueues the launch(es), the wait
+            # for the stop event, the contract's barrier + synchronize
+            stamps["breakdown_us"] = {"enqueue_call": (stamps["enqueued"] - t0) * 1e6, "until_stop_event": (stamps["done"] - stamps["enqueued"]) * 1e6,
+                                      "barrier_and_synchronize": (t1 - stamps["done"]) * 1e6, "wall": (t1 - t0) * 1e6}
+            return t1 - t0, e0.elapsed_time(e1) * 1e3 / steps   # wall seconds, device us per step
 
         def side_run(loop_, steps, warm=20):
             """(device us per step, wall s) of `steps` steps outside the contract's timed region (extras)."""
@@ -413,6 +422,7 @@ def main():
         loop.run(nsets)
         torch.cuda.synchronize()
         dt, step_us = timed(loop, args.steps, args.warmup)
+        wall_breakdown = dict(stamps["breakdown_us"])
         ctx.sync()  # raises if any trajectory flagged bad time / singular
         for co in (loop.outputs() if mixed else [x[2] for x in sets]):
             assert torch.isfinite(co).all()
@@ -588,6 +598,7 @@ def main():
                                          "last launch of the timed steps / launches (max over ranks)",
                          "output_fill_only_us": fill_us},
             "ranks_seen": ranks_seen, "rank_devices": rank_devices,
+            "timed_region_wall_us": wall_breakdown,      # (this rank's host clock; `value` = units / max-over-ranks wall)
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
