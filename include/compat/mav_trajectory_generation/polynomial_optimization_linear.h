@@ -20,6 +20,7 @@
 #include <memory>
 #include <string>
 #include <numeric>
+#include <ostream>
 #include <vector>
 
 #include <map>
@@ -446,6 +447,17 @@ class PolynomialOptimization {
         (*M)(s * N + N / 2 + p, col[(s + 1) * (N / 2) + p]) = 1.0;
       }
     }
+  }
+  // LIN:382-385: the constraint reordering ("mapping") matrix M, rows separated by newlines, entries by blanks
+  void printReorderingMatrix(std::ostream& stream) const {
+    Eigen::MatrixXd M;
+    getM(&M);
+    stream << "Mapping matrix:\n";
+    for (std::ptrdiff_t r = 0; r < M.rows(); ++r) {
+      for (std::ptrdiff_t c = 0; c < M.cols(); ++c) stream << (c ? " " : "") << M(r, c);
+      if (r + 1 < M.rows()) stream << "\n";
+    }
+    stream << std::endl;
   }
   void getMpinv(Eigen::MatrixXd* M_pinv) const {   // M^T with every row normalised by its sum
     CHECK_NOTNULL(M_pinv);

@@ -8,6 +8,7 @@
 #include <numeric>
 #include <memory>
 #include <thread>
+#include <sstream>
 #include <vector>
 
 #include <mav_trajectory_generation/polynomial_optimization_linear.h>
@@ -113,6 +114,18 @@ int main() {
     opt.getFreeConstraints(&free_c);
     Eigen::MatrixXd M, A_inv, A, M_pinv;
     opt.getM(&M); opt.getAInverse(&A_inv); opt.getA(&A); opt.getMpinv(&M_pinv);
+    {   // printReorderingMatrix (LIN:382-385): header line + one text row per row of M, every row with exactly one 1
+      std::ostringstream os;
+      opt.printReorderingMatrix(os);
+      const std::string txt = os.str();
+      EXPECT(txt.rfind("Mapping matrix:\n", 0) == 0, "printReorderingMatrix header");
+      size_t rows = 0, ones = 0;
+      for (size_t i = std::string("Mapping matrix:\n").size(); i < txt.size(); ++i) {
+        if (txt[i] == '\n') ++rows;
+        if (txt[i] == '1') ++ones;
+      }
+      EXPECT(rows == (size_t)M.rows() && ones == (size_t)M.rows(), "printReorderingMatrix: %zu rows, %zu ones for a %d-row M", rows, ones, (int)M.rows());
+    }
     for (int d = 0; d < D; ++d) {
       Eigen::VectorXd d_all(fixed[d].size() + free_c[d].size());
       for (int i = 0; i < fixed[d].size(); ++i) d_all[i] = fixed[d][i];
