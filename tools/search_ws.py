@@ -20,10 +20,14 @@ REG_STEPS = {4: 9, 5: 6, 6: 2}                                          # where 
 def resources(H, K, WS, LS, RS=0, full=False):
     ms, mi, me, dv = SHAPES[H]
     cfg = f"MtgCfg<{H},1,{K},{ms},{mi},{me},{dv},0,{WS},{3 if (WS > 0 or RS) else 0},{LS},{RS}>"
-    src = f"/tmp/search_ws_{H}_{K}_{WS}_{LS}_{RS}.hip"
+    src = f"/tmp/search_ws_{os.environ.get('SEARCH_KERNEL', 'plain')}_{H}_{K}_{WS}_{LS}_{RS}.hip"
     with open(src, "w") as f:
-        f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<' + cfg +
-                ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, int, double*);\n')
+        if os.environ.get("SEARCH_KERNEL") == "extra":      # the extra-output kernel (cost / d_P) of the same configuration
+            f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_extra_kernel<' + cfg +
+                    ', 3, 1, 18>(const double*, const double*, double*, int*, int*, int, int, int, int, double*, MtgDlExtra);\n')
+        else:
+            f.write('#include "mtg_dimlane.h"\ntemplate __global__ void mtg_solve_dl_kernel<' + cfg +
+                    ', 3, 1, 0, 18>(const double*, const double*, double*, int*, int*, int, int, int, int, double*);\n')
     p = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
                         "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-mllvm",
                         "-pragma-unroll-threshold=1000000", "--cuda-device-only", "-c", src, "-o", src + ".o",
