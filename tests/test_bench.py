@@ -83,6 +83,12 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     assert rf["bytes_per_launch"] == 20 * 10_000 * 2392 and rf["bytes_per_step"] == 10_000 * 2392
     assert abs(rf["achieved"] - rf["bytes_per_step"] / rf["device_us_per_step"] * 1e-3) < 1e-6 * rf["achieved"]
     assert out["ranks_seen"] == 1
+    # the wall clock of the timed region is broken down, and the region a fresh process measures FIRST (idle GPU) is kept
+    # beside the one after the settle phase
+    w = out["timed_region_wall_us"]
+    assert abs(w["enqueue_call"] + w["until_stop_event"] + w["barrier_and_synchronize"] - w["wall"]) < 1e-6 * w["wall"]
+    assert out["settle_ms"] == 50.0 and out["cold_start"]["kernel_us_per_step"] > 0 and 0 < out["cold_start"]["frac"] < 1
+    assert "cold_start" in out["config"]["workload"]
     assert "resident_buffers" in out["extra"]
     one = out["extra"]["one_launch_per_batch"]          # the latency form: reported beside, never as `value`
     assert one["steps"] == 200 and one["us_per_step"] > rf["device_us_per_step"]
