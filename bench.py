@@ -117,9 +117,9 @@ def cpu_baseline(n_sample, seed):
 
 def profile_traffic(batch, config):
     """HBM bytes per STEP (one batch / one mixed request) as measured by the committed rocprofv3 PMC passes
-    (profiles/r03_*_pmc_traffic.json): evidence from a separate profiling run of this command, NOT measured in this run --
+    (profiles/r03z_*_pmc_traffic.json): evidence from a separate profiling run of this command, NOT measured in this run --
     hence its own key and the file name."""
-    name = {2: "r03_driver_args_pmc_traffic.json", 4: "r03_config4_pmc_traffic.json"}.get(config)
+    name = {2: "r03z_driver_args_pmc_traffic.json", 4: "r03z_config4_pmc_traffic.json"}.get(config)
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
         return None
