@@ -112,6 +112,50 @@ __global__ void k_fma_half(double* out, long long* cyc, int iters, double a, dou
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// fma with THREE per-lane (VGPR) 64-bit operands: acc[i] += y[i] * z[j] -- the shape of nearly every FMA of the solve kernels
+// (the kernels above have at most two VGPR operands; a and b are uniform)
+template <int CHAINS>
+__global__ void k_fma_vvv(double* out, long long* cyc, int iters, double a, double b) {
+  double x[CHAINS], y[CHAINS], z[CHAINS];
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) { x[i] = threadIdx.x * 1e-3 + i; y[i] = 1.0 + threadIdx.x * 1e-9 * (i + 1); z[i] = a * (threadIdx.x + i + 1) * 1e-12 + b; }
+  long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int i = 0; i < CHAINS; ++i) x[i] = __builtin_fma(y[i], z[(i + r) % CHAINS], x[i]);
+    }
+  }
+  long long t1 = clock64();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) s += x[i] + y[i] + z[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+// v_mul_f64 with two per-lane operands into a fresh destination (no accumulator read)
+template <int CHAINS>
+__global__ void k_mul_vv(double* out, long long* cyc, int iters, double a, double b) {
+  double x[CHAINS], y[CHAINS], z[CHAINS];
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) { x[i] = 0.0; y[i] = 1.0 + threadIdx.x * 1e-9 * (i + 1); z[i] = a * (threadIdx.x + i + 1) * 1e-12 + b; }
+  long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int i = 0; i < CHAINS; ++i) { x[i] = y[i] * z[(i + r) % CHAINS]; asm volatile("" : "+v"(x[i])); }
+    }
+  }
+  long long t1 = clock64();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) s += x[i] + y[i] + z[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <class K, class... A>
 double run(const char* name, K kern, int blocks, int threads, int per_iter, int iters, A... args) {
   double* out; long long* cyc;
@@ -150,6 +194,10 @@ int main() {
   run("mul dep x1", k_mul<1>, 1024, 64, 8 * 1, iters, 1.0000001);
   run("mul x8 indep", k_mul<8>, 1024, 64, 8 * 8, iters, 1.0000001);
   run("fma vvs x8 (sgpr addend)", k_fma_sgpr<8>, 1024, 64, 8 * 8, iters, 1e-9, 0.0);
+  run("fma vvv x8 (three VGPR operands)", k_fma_vvv<8>, 1024, 64, 8 * 8, iters, 1.0000001, 1e-9);
+  run("fma vvv x16", k_fma_vvv<16>, 1024, 64, 8 * 16, iters, 1.0000001, 1e-9);
+  run("fma vvv x8 (2 waves/SIMD)", k_fma_vvv<8>, 2048, 64, 8 * 8, iters, 1.0000001, 1e-9);
+  run("mul vv x8 (two VGPR operands)", k_mul_vv<8>, 1024, 64, 8 * 8, iters, 1.0000001, 1e-9);
   run("rcp dep x1", k_rcp<1>, 1024, 64, 8 * 1, iters);
   run("rcp x8 indep", k_rcp<8>, 1024, 64, 8 * 8, iters);
   run("fma x8 indep, 1 wave total", k_fma<8>, 1, 64, 8 * 8, iters, 1.0000001, 1e-9);
