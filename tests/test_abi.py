@@ -81,3 +81,14 @@ def test_multi_entry_points_validate_arguments_without_a_device():
     assert lib.mtg_multi_launch_count(None) == 0
     assert lib.mtg_multi_destroy(None) == 0
     assert ctypes.sizeof(_lib.MultiItem) == 8 + 8 + 8 * 8 + 5 * 8     # plan, batch, layout (8 strides), 5 pointers
+
+
+def test_python_flag_constants_match_the_header():
+    """_lib.py's FLAG_* constants are hand-written copies of the header's enum: every MTG_FLAG_* of include/mtg_hip.h must
+    exist there with the same bit."""
+    from mav_trajectory_generation_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "mtg_hip.h")).read()
+    flags = dict(re.findall(r"\bMTG_(FLAG_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", txt))
+    assert len(flags) >= 10
+    for name, bit in flags.items():
+        assert getattr(_lib, name) == 1 << int(bit), name
