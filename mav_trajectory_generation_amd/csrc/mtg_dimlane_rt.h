@@ -17,6 +17,9 @@
 // what limited the static long-chain variants (K = 32: 34 doubles per lane).
 #ifndef MTG_DIMLANE_RT_H_
 #define MTG_DIMLANE_RT_H_
+#ifndef MTG_RT_INPUT_DEPTH
+#define MTG_RT_INPUT_DEPTH 3      // steps the on-demand input loads run ahead of their use (beyond the next step)
+#endif
 #include "mtg_kernels.h"
 
 // C: rolled configuration (KT_ < 0) with D == 1, DLW = DL, RS = 1.  R: register steps, L: LDS steps.
@@ -71,22 +74,40 @@ __device__ __forceinline__ void mtg_lane_forward_rt(const MtgParams& P, long lon
 #pragma unroll
     for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
   }
-  // Issue order per step (as in the rolled kernels of mtg_lane.h): inputs of step j + 1, arithmetic of step j, then step j's
-  // back-substitution stores.
+  // Issue order per step: inputs of step j + 1 + PD, arithmetic of step j, then step j's back-substitution stores.  The segment
+  // time and the fixed values of the right vertex are requested PD + 1 steps ahead (a ring of PD entries: 1 + popc(MI) doubles
+  // each): one step of arithmetic (~0.7 us) does not cover the latency of a load that goes to HBM behind a store stream.
+  constexpr int PD = MTG_RT_INPUT_DEPTH;
   double T_cur = mtg_step_time<C, DIR>(P, b, 0, ln);
   double fl[1][H], fr[1][H], fn[1][H];
+  double Tq[PD], fq[PD][1][H];
   mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, 0), M0, ln, fl);
   mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, 0), C::MI, ln, fr);
-  auto prefetch = [&](int j, double& T_nxt) {       // segment time and right vertex of step j + 1 (last step: harmless reload)
-    const int jn = j + 1 < kc ? j + 1 : j;
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    const int jn = i + 1 < kc ? i + 1 : kc - 1;
+    Tq[i] = mtg_step_time<C, DIR>(P, b, jn, ln);
+    mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, jn), C::MI, ln, fq[i]);
+  }
+  auto prefetch = [&](int j, double& T_nxt) {       // segment time and right vertex of step j + 1 + PD (chain end: harmless reload)
+    const int jn = j + 1 + PD < kc ? j + 1 + PD : kc - 1;
     const long long bt = mtg_rt_tie(b, ln.Sc[H - 1][H - 1]);     // not before the previous step's arithmetic
     T_nxt = mtg_step_time<C, DIR>(P, bt, jn, ln);
     mtg_load_vals<C, DIR>(P, bt, mtg_vr<DIR>(K, jn), C::MI, ln, fn);
   };
   auto shift = [&](double T_nxt) {
-    T_cur = T_nxt;
+    T_cur = Tq[0];
 #pragma unroll
-    for (int p = 0; p < H; ++p) { fl[0][p] = fr[0][p]; fr[0][p] = fn[0][p]; }
+    for (int p = 0; p < H; ++p) { fl[0][p] = fr[0][p]; fr[0][p] = fq[0][0][p]; }
+#pragma unroll
+    for (int i = 0; i + 1 < PD; ++i) {
+      Tq[i] = Tq[i + 1];
+#pragma unroll
+      for (int p = 0; p < H; ++p) fq[i][0][p] = fq[i + 1][0][p];
+    }
+    Tq[PD - 1] = T_nxt;
+#pragma unroll
+    for (int p = 0; p < H; ++p) fq[PD - 1][0][p] = fn[0][p];
   };
   {   // step 0: the trajectory end (fully fixed: nothing to keep)
     double G[H][H], g[1][H], T_nxt;
@@ -133,11 +154,33 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
   // one --, then recovery.
   double Gw[H][H], gw[1][H], fl[1][H], T_cur = 0.0;
   double tie_on = 0.0;                 // (set to the latest back-substitution result before every request)
-  auto request_inputs = [&](int j) {
+  // Segment time and left-vertex fixed values: requested PD + 1 steps ahead (ring of PD entries, as in the forward phase); the
+  // fully fixed end vertex (step 0, mask M0) has its own H values f0, requested when the ring reaches step 0.
+  constexpr int PD = MTG_RT_INPUT_DEPTH;
+  double Tq[PD], fq[PD][1][H], f0[1][H];
+#pragma unroll
+  for (int p = 0; p < H; ++p) f0[0][p] = 0.0;
+  auto fetch = [&](int j, double& T, double (&f)[1][H]) {      // inputs of step j (j < 0: nothing left to request)
     const long long bt = mtg_rt_tie(b, tie_on);
-    T_cur = mtg_step_time<C, DIR>(P, bt, j, ln);
-    if (j == 0) mtg_load_vals<C, DIR>(P, bt, mtg_vl<DIR>(K, 0), M0, ln, fl);
-    else mtg_load_vals<C, DIR>(P, bt, mtg_vl<DIR>(K, j), C::MI, ln, fl);
+    T = mtg_step_time<C, DIR>(P, bt, j > 0 ? j : 0, ln);
+    mtg_load_vals<C, DIR>(P, bt, mtg_vl<DIR>(K, j > 0 ? j : 1 < kc ? 1 : 0), C::MI, ln, f);      // (j <= 0: harmless reload, unused)
+    if (j == 0) mtg_load_vals<C, DIR>(P, bt, mtg_vl<DIR>(K, 0), M0, ln, f0);
+  };
+  auto request_inputs = [&](int j) {   // step j becomes the current one: its inputs leave the ring, step j - PD's are requested
+    double Tn, fn_[1][H];
+    fetch(j - PD, Tn, fn_);
+    T_cur = Tq[0];
+#pragma unroll
+    for (int p = 0; p < H; ++p) fl[0][p] = j == 0 ? f0[0][p] : fq[0][0][p];
+#pragma unroll
+    for (int i = 0; i + 1 < PD; ++i) {
+      Tq[i] = Tq[i + 1];
+#pragma unroll
+      for (int p = 0; p < H; ++p) fq[i][0][p] = fq[i + 1][0][p];
+    }
+    Tq[PD - 1] = Tn;
+#pragma unroll
+    for (int p = 0; p < H; ++p) fq[PD - 1][0][p] = fn_[0][p];
   };
   auto request_head = [&](int j) {     // j < nh: a head step (rows in LDS / workspace) or step 0 (no rows)
     if (j >= 1) {
@@ -149,6 +192,8 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
   const int nh = st.nh;
   // the first step processed: j = kc - 1 (a tail step when kc >= 2, else step 0)
   tie_on = xr[0][H - 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) fetch(kc - 1 - i, Tq[i], fq[i]);     // ring <- steps kc - 1, ..., kc - PD
   if (kc - 1 >= 1) {
     if (kc - 1 >= nh) { /* tail position R - 1: its G is unpacked in the loop below */ request_inputs(kc - 1); }
     else request_head(kc - 1);     // (R == 0 only)
