@@ -76,6 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--settle-ms", type=float, default=50.0, help="untimed set-up: milliseconds of the same work before the "
                     "contract's warm-up + timed steps (a fresh process starts on an idle GPU; 0: none). The line keeps the "
                     "region measured before it as `cold_start`")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity sample of the timed launch's outputs (the metric's "
+                    "second half: max coefficient rel-err vs the reference build / the port)")
+    ap.add_argument("--parity-samples", type=int, default=768, help="trajectories of the timed launch's outputs that are "
+                    "compared with the oracles (spread over >= 3 of the rotating buffer sets the TIMED launch wrote)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (profiling runs: the kernel statistics then cover the same launches as the metric)")
     return ap.parse_args(argv)
@@ -115,23 +119,150 @@ def cpu_baseline(n_sample, seed):
     return out
 
 
-def profile_traffic(batch, config):
-    """HBM bytes per STEP (one batch / one mixed request) as measured by the committed rocprofv3 PMC passes
-    (profiles/r03z_*_pmc_traffic.json): evidence from a separate profiling run of this command, NOT measured in this run --
-    hence its own key and the file name."""
-    name = {2: "r03z_driver_args_pmc_traffic.json", 4: "r03z_config4_pmc_traffic.json"}.get(config)
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if not path or not os.path.exists(path):
-        return None
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    if d.get("batch") != batch:
-        return None
-    return {"file": os.path.relpath(path, ROOT), "hbm_bytes_per_step": d.get("hbm_bytes_per_step"),
-            "algorithmic_bytes_per_step": d.get("algorithmic_bytes_per_step"), "bench_args_of_the_profile": d.get("bench_args"),
-            "note": d.get("note", "separate rocprofv3 --pmc run of this command")}
+def profile_traffic(batch, config, steps, warmup):
+    """HBM bytes per STEP (one batch / one mixed request) as measured by the committed rocprofv3 PMC passes of THIS command
+    (profiles/r04_config<N>_pmc_traffic.json, tools/gpu_profile3.sh: FETCH_SIZE / WRITE_SIZE in their own passes, calibrated in
+    the same visit): evidence from a separate profiling run, NOT measured in this run -- the file name travels with the number.
+    Only a profile of the same arguments (batch, --steps, --warmup) counts."""
+    for name in (f"r04_config{config}_pmc_traffic.json",
+                 {2: "r03z_driver_args_pmc_traffic.json", 4: "r03z_config4_pmc_traffic.json"}.get(config)):
+        path = os.path.join(ROOT, "profiles", name) if name else None
+        if not path or not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        pa = (d.get("bench_args") or "").split()
+        def arg(flag, default):
+            return int(pa[pa.index(flag) + 1]) if flag in pa else default
+        if d.get("batch") != batch or arg("--steps", 200) != steps or arg("--warmup", 20) != warmup:
+            continue
+        return {"file": os.path.relpath(path, ROOT), "hbm_bytes_per_step": d.get("hbm_bytes_per_step"),
+                "hbm_read_bytes_per_step": d.get("hbm_read_bytes_per_step"), "hbm_write_bytes_per_step": d.get("hbm_write_bytes_per_step"),
+                "algorithmic_bytes_per_step": d.get("algorithmic_bytes_per_step"), "bench_args_of_the_profile": d.get("bench_args"),
+                "note": d.get("note", "separate rocprofv3 --pmc run of this command")}
+    return None
+
+
+PARITY_TOL = 1e-9   # BASELINE.json north_star: coefficients within 1e-9 (relative, per polynomial) of the Eigen reference
+
+
+class ParitySample:
+    """The metric's second half ("max coeff rel-err vs Eigen"): rows of the coefficient buffers that the TIMED launch is
+    going to write are overwritten with NaN beforehand (set-up, a few hundred 2-KB rows), pulled to the host right after the
+    timed region together with their inputs, and compared -- in the cpu_baseline leg, the only place of this file that may
+    call oracle/ -- with the C++ restatement (`port`) and, where the prebuilt library travelled, the reference's own code
+    (oracle/_ref/libmtg_ref.so).  A row the timed launch did not write stays NaN and fails the check."""
+
+    def __init__(self, nsets, steps, warmup, n_rows, seed=20260925):
+        import numpy as np
+        timed_sets = [(warmup + i) % nsets for i in range(steps)]
+        warm_sets = {i % nsets for i in range(warmup)}
+        uniq = list(dict.fromkeys(timed_sets))
+        only_timed = [s for s in uniq if s not in warm_sets]
+        # sets nobody but the timed launch writes between the prefill and the read-back; else every set it writes
+        self.after_warmup = len(only_timed) < min(3, len(uniq))
+        pool = uniq if self.after_warmup else only_timed
+        k = min(len(pool), 4)
+        self.sets = [pool[(j * len(pool)) // k] for j in range(k)]
+        self.n_rows, self.rng, self.items = n_rows, np.random.default_rng(seed), []
+
+    def add(self, set_index, label, n, deriv, masks, t, f, co, layout):
+        """One (buffer set, problem shape) source; t / f / co are the device tensors of that set."""
+        import torch
+        B = co.shape[0]
+        cnt = min(B, self._per_item)
+        idx = torch.from_numpy(self.rng.choice(B, size=cnt, replace=False)).to(co.device).sort().values
+        self.items.append(dict(set=set_index, label=label, n=n, deriv=deriv, masks=list(masks), t=t, f=f, co=co, idx=idx,
+                               layout=layout))
+
+    def plan(self, n_sources_per_set):
+        self._per_item = max(1, -(-self.n_rows // max(1, len(self.sets) * n_sources_per_set)))
+
+    def prefill(self):
+        for it in self.items:
+            it["co"][it["idx"]] = float("nan")
+
+    def collect(self):
+        """Right after the timed region: the sampled rows and their inputs to the host (AoS, the oracles' layout)."""
+        for it in self.items:
+            idx = it["idx"]
+            t, f = it["t"], it["f"]
+            it["times_h"] = (t[:, idx].t() if it["layout"] == "soa" else t[idx]).contiguous().cpu().numpy()
+            it["fixed_h"] = (f[:, :, idx].permute(2, 0, 1) if it["layout"] == "soa" else f[idx]).contiguous().cpu().numpy()
+            it["coeffs_h"] = it["co"][idx].cpu().numpy()
+            for key in ("t", "f", "co"):
+                it[key] = None
+
+    def check(self):
+        """(cpu_baseline leg) compare with the oracles; returns the `parity` object of the line."""
+        import numpy as np
+        from oracle import cpu_ref, ref_linear
+        have_ref = ref_linear.available()
+
+        def relerr(c, cref):   # per trajectory: max over (segment, dimension) of ||c - cref||_inf / ||cref||_inf
+            num = np.abs(c - cref).max(axis=-1)
+            den = np.abs(cref).max(axis=-1)
+            e = num / np.where(den == 0, 1.0, den)
+            e = np.where(np.isfinite(e), e, np.inf)
+            return e.reshape(e.shape[0], -1).max(axis=1)
+
+        per_n, n_tot, unwritten = {}, 0, 0
+        for it in self.items:
+            c = it["coeffs_h"]
+            unwritten += int(np.isnan(c).any(axis=(1, 2, 3)).sum())
+            c_port = cpu_ref.solve_batch(it["n"], it["deriv"], it["masks"], it["times_h"], it["fixed_h"], want_free=False,
+                                         want_cost=False)[0]
+            e_port = relerr(c, c_port)
+            e_ref = None
+            if have_ref:
+                c_ref = ref_linear.solve_batch(it["n"], it["deriv"], it["masks"], it["times_h"], it["fixed_h"], want_free=False,
+                                               want_cost=False)[0]
+                e_ref = relerr(c, c_ref)
+            d = per_n.setdefault(it["n"], {"port": [], "ref": []})
+            d["port"].append(e_port)
+            if e_ref is not None:
+                d["ref"].append(e_ref)
+            n_tot += c.shape[0]
+        out_n, ok = {}, unwritten == 0
+        for n, d in sorted(per_n.items()):
+            ep = np.concatenate(d["port"])
+            er = np.concatenate(d["ref"]) if d["ref"] else None
+            row = {"n": int(ep.size), "max_rel_err_vs_port": float(ep.max()), "median_rel_err_vs_port": float(np.median(ep)),
+                   "max_rel_err_vs_reference_build": None if er is None else float(er.max()),
+                   "median_rel_err_vs_reference_build": None if er is None else float(np.median(er))}
+            if n <= 10:
+                row["tol"] = PARITY_TOL
+                row["ok"] = bool(ep.max() <= PARITY_TOL and (er is None or er.max() <= PARITY_TOL))
+            else:
+                # N = 12: cond(A) reaches 1e17; every float64 evaluation of the reference's formulas (the compiled reference
+                # included) sits ~1e-8 (worst trajectories 1e-6) from the 50-digit solution -- the tolerance is the reference's
+                # own distance to the truth (DESIGN.md section 1, tests/test_gpu_vs_reference.py: median < 1e-8, max < 1e-5)
+                row["tol"] = {"median": 1e-8, "max": 1e-5}
+                worst = er if er is not None else ep
+                row["ok"] = bool(np.median(worst) <= 1e-8 and worst.max() <= 1e-5)
+            ok = ok and row["ok"]
+            out_n[str(n)] = row
+        allp = np.concatenate([np.concatenate(d["port"]) for d in per_n.values()])
+        allr = [np.concatenate(d["ref"]) for d in per_n.values() if d["ref"]]
+        le10 = [k for k in per_n if k <= 10]
+        out = {"metric": "max over sampled trajectories, segments and dimensions of ||c_gpu - c_ref||_inf / ||c_ref||_inf "
+                         "(SURVEY.md 8(d) parity metric), outputs of the TIMED launch",
+               "n": n_tot, "buffer_sets_sampled": self.sets, "rows_prefilled_with_nan": True,
+               "prefilled": "after the warm-up steps" if self.after_warmup else "before the warm-up steps (sets the warm-up does not write)",
+               "rows_not_written_by_the_timed_launch": unwritten, "tol": PARITY_TOL,
+               "max_rel_err_vs_port": float(max(np.concatenate(per_n[k]["port"]).max() for k in le10)) if le10 else float(allp.max()),
+               "max_rel_err_vs_reference_build": (float(max(np.concatenate(per_n[k]["ref"]).max() for k in (le10 or per_n)))
+                                                  if allr else None),
+               "reference_build": "oracle/_ref/libmtg_ref.so (the reference's own code against the Eigen/glog stand-ins)" if have_ref
+                                  else "not shipped to this box",
+               "port": "oracle/cpu_ref.cpp (C++ restatement of the reference algorithm)",
+               "ok": bool(ok)}
+        if len(out_n) > 1 or any(k > 10 for k in per_n):
+            out["per_n"] = out_n
+            out["max_rel_err_is"] = "over the N <= 10 samples (the north-star tolerance); N = 12: per_n, with the tolerance the tests use"
+        return out
 
 
 class SolveLoop:
@@ -189,7 +320,7 @@ class MixedLoop:
     def __init__(self, m, ctx, per_bucket, nsets, dev, seed, per_step_call=False):
         self.solver = m.MixedBatchSolver(ctx, n_streams=1)
         self.per_step_call = per_step_call
-        self.sets, self.reqs, self.merged = [], [], {}
+        self.sets, self.reqs, self.merged, self.build_us = [], [], {}, {}
         import torch
         for s in range(nsets):
             buckets = []
@@ -214,7 +345,9 @@ class MixedLoop:
         if key not in self.merged:
             n = len(self.sets)
             items = [b for i in range(steps) for b in self.sets[(first + i) % n]]
+            t0 = time.perf_counter()
             self.merged[key] = self.solver.merged(items)
+            self.build_us[key] = (time.perf_counter() - t0) * 1e6   # host: plan lookups, unit schedule, two small uploads
 
     def launches(self, steps):
         return steps * self.launches_per_step if self.per_step_call else self.launches_per_step
@@ -389,10 +522,14 @@ def main():
             stamps["done"] = time.perf_counter()
             barrier()               # ... then the contract's barrier + torch.cuda.synchronize()
 
-        def timed(loop_, steps, warmup):
+        def timed(loop_, steps, warmup, parity_=None):
             loop_.prepare(warmup, 0)
             loop_.prepare(steps, warmup)
+            if parity_ is not None and not parity_.after_warmup:
+                parity_.prefill()       # NaN into the sampled output rows (sets the warm-up steps do not write)
             loop_.run(warmup)
+            if parity_ is not None and parity_.after_warmup:
+                parity_.prefill()
             barrier()
             t0 = time.perf_counter()
             loop_.run(steps, first=warmup, start_event=e0, stop_event=e1)   # events recorded around the launches
@@ -440,13 +577,45 @@ def main():
             while time.perf_counter() < t_end:
                 loop.run(nsets)
                 torch.cuda.synchronize()
-        dt, step_us = timed(loop, args.steps, args.warmup)
+        parity = None
+        if rank == 0 and not args.no_parity:
+            # (config 4: >= 512 sampled trajectories per polynomial order)
+            parity = ParitySample(nsets, args.steps, args.warmup, args.parity_samples * (3 if mixed else 1))
+            if mixed:
+                parity.plan(len(loop.SHAPES))
+                for si in parity.sets:
+                    for b in loop.sets[si]:
+                        parity.add(si, f"N={b['n_coeffs']} K={len(b['masks']) - 1}", b["n_coeffs"], b["derivative"], b["masks"],
+                                   b["times"], b["d_fixed"], b["coeffs"], "soa")
+            else:
+                parity.plan(1)
+                for si in parity.sets:
+                    parity.add(si, f"N={N} K={K} D={D}", N, d, masks, sets[si][0], sets[si][1], sets[si][2], args.layout)
+        dt, step_us = timed(loop, args.steps, args.warmup, parity)
         wall_breakdown = dict(stamps["breakdown_us"])
         ctx.sync()  # raises if any trajectory flagged bad time / singular
+        if parity is not None:
+            parity.collect()    # the sampled rows of the TIMED launch's outputs, before anything else rewrites the buffers
         for co in (loop.outputs() if mixed else [x[2] for x in sets]):
             assert torch.isfinite(co).all()
 
-        extra, fill_us = {}, None
+        extra, fill_us, peer = {}, None, None
+        if rank == 0 and not args.no_extras:
+            # The OTHER hand-over form of the same K steps under the same protocol (W warm-up steps, K timed steps, wall clock
+            # around them), reported as a PEER of `value`: one kernel launch per step (what a caller whose batches arrive one
+            # at a time gets) when `value` is the queue form, and vice versa.
+            other = (MixedLoop(m, ctx, B, nsets, dev, 1234 + rank, per_step_call=not per_batch) if mixed
+                     else SolveLoop(plan, sets, args.layout, args.dims, not per_batch))
+            if mixed:
+                other.run(nsets)
+            us, wall = side_run(other, args.steps, warm=args.warmup)
+            peer = {"sequence": "queue" if per_batch else "launches", "value": world * traj_per_step * args.steps / wall,
+                    "unit": "trajectories/s", "ms_per_step": wall / args.steps * 1e3, "device_us_per_step": us,
+                    "roofline_frac": bytes_per_step / us * 1e-3 / HBM_PEAK_GBS, "steps": args.steps, "warmup": args.warmup,
+                    "is": ("one library call and one kernel launch PER STEP, back to back on one stream -- the form a caller whose "
+                           "batches arrive one at a time can reproduce (this rank's clock)") if not per_batch else
+                          "the K steps handed to the library together (one persistent launch per <= 96 steps)"}
+            del other
         if rank == 0 and not args.no_extras and mixed:
             us, wall = side_run(loop, 96, warm=16)
             extra["rotating_buffers_96_steps"] = side_entry(us, wall, 96, nsets)
@@ -554,7 +723,9 @@ def main():
         mine = torch.tensor([dt, step_us], dtype=torch.float64, device=red_dev)
         allv = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
         dist.all_gather(allv, mine)
-        per_rank = [{"rank": r, "device": rank_devices[r], "wall_s": float(v[0]), "device_us_per_step": float(v[1])}
+        per_rank = [{"rank": r, "device": rank_devices[r], "wall_s": float(v[0]), "device_us_per_step": float(v[1]),
+                     "units_per_s": traj_per_step * args.steps / float(v[0]),
+                     "roofline_frac": bytes_per_step / float(v[1]) * 1e-3 / HBM_PEAK_GBS}   # each rank's own launch vs ITS HBM
                     for r, v in enumerate(allv)]
         vals = mine.clone()
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
@@ -591,6 +762,7 @@ def main():
                     f"dim={D}, snap" + (", velocity + acceleration fixed at interior vertices" if cfg["interior"] == 7 else "")
                     + f"; {form}; rotating over {nsets} independent input/output buffer sets "
                       f"({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; inputs {args.layout.upper()}, coeffs [B][K][D][N]")
+        traffic_prof = profile_traffic(traj_per_step, args.config, args.steps, args.warmup)
         if args.settle_ms > 0:
             what += (f"; set-up before the contract's warm-up + timed steps: {args.settle_ms:g} ms of the same work (a fresh process "
                      f"starts on an idle GPU; the timed region measured before that phase is reported as cold_start)")
@@ -610,8 +782,14 @@ def main():
                        "bytes_per_trajectory": None if mixed else plan.bytes_per_trajectory,
                        "trajectories_per_step": traj_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_from_profile": profile_traffic(traj_per_step, args.config),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # HBM bytes per LAUNCH from the PMC counters (the committed, calibrated profile of this command with
+                         # these arguments; null when there is none) and their ratio to the algorithmic bytes
+                         "traffic": (traffic_prof["hbm_bytes_per_step"] * args.steps / launches
+                                     if traffic_prof and traffic_prof.get("hbm_bytes_per_step") else None),
+                         "traffic_over_algorithmic": (traffic_prof["hbm_bytes_per_step"] / bytes_per_step
+                                                      if traffic_prof and traffic_prof.get("hbm_bytes_per_step") else None),
+                         "traffic_from_profile": traffic_prof,
                          "kernel_us": step_us * args.steps / launches, "launches": launches,
                          "batches_per_launch": batches_per_launch,
                          "bytes_per_launch": bytes_per_step * args.steps / launches,
@@ -622,7 +800,19 @@ def main():
             "ranks_seen": ranks_seen, "rank_devices": rank_devices,
             "timed_region_wall_us": wall_breakdown,      # (this rank's host clock; `value` = units / max-over-ranks wall)
             "settle_ms": args.settle_ms, "cold_start": cold,
+            # the same warm-up + timed region as the first thing a fresh process does (no settle phase in front of it)
+            "value_cold": None if cold is None else world * cold["units_per_s_this_rank"],
+            "value_other_form": peer,
         }
+        if mixed and not per_batch:
+            # the merged request of the timed region is built once, outside it (MixedLoop.prepare): say so, and what it costs
+            b_us = loop.build_us.get((args.steps, args.warmup % nsets))
+            out["request_build"] = {"outside_timed_region": True, "host_us": b_us,
+                                    "value_including_request_build": (world * traj_per_step * args.steps / (dt + b_us * 1e-6)
+                                                                      if b_us is not None else None),
+                                    "is": "mtg_multi_create of the 12 x K-item request (plan lookups, longest-processing-time unit "
+                                          "schedule, two uploads): `value` is an amortised figure for a request that is built once "
+                                          "and solved repeatedly; value_other_form is one pre-built 12-item request per step"}
         if per_rank is not None:
             out["per_rank"] = per_rank
         if extra:
@@ -634,6 +824,11 @@ def main():
         if rank == 0:
             out["cpu_baseline"] = cpu_baseline(200_000, 4321)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0 and parity is not None:
+        # the metric's second half (cpu_baseline leg: the only place that may call oracle/ -- as the checker)
+        out["parity"] = parity.check()
+        if not out["parity"]["ok"]:
+            print("bench.py: PARITY FAILED: " + json.dumps(out["parity"]), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

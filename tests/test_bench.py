@@ -56,6 +56,9 @@ def test_two_rank_bench_on_one_gpu():
     assert out["ranks_seen"] == 2 and out["rank_devices"] == [0, 0]
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["device_us_per_step"] > 0 for r in out["per_rank"])
     assert out["roofline"]["device_us_per_step"] == max(r["device_us_per_step"] for r in out["per_rank"])
+    assert all(0 < r["roofline_frac"] < 1 and r["units_per_s"] > 0 for r in out["per_rank"])
+    assert abs(out["roofline"]["frac"] - min(r["roofline_frac"] for r in out["per_rank"])) < 1e-9
+    assert out["parity"]["ok"] and out["parity"]["n"] >= 512       # rank 0's timed launch, checked against the oracles
 
 
 @pytest.mark.gpu
@@ -77,7 +80,12 @@ def test_single_gpu_bench_line_has_the_contract_fields():
         assert k in out
     assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["config"]["buffer_sets"] == 16
     rf = out["roofline"]
-    assert rf["bound"] == "hbm" and rf["traffic"] is None and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # HBM bytes per launch from the committed PMC profile of this very command (null only when none is committed)
+    if rf["traffic"] is not None:
+        assert rf["traffic_from_profile"]["bench_args_of_the_profile"].split()[:4] == ["--steps", "20", "--warmup", "5"]
+        assert abs(rf["traffic"] - rf["traffic_from_profile"]["hbm_bytes_per_step"] * 20) < 1.0
+        assert 0.95 < rf["traffic_over_algorithmic"] < 1.2
     # the 20 timed steps = 20 independent batches in ONE persistent launch (mtg_solve_linear_sequence)
     assert out["config"]["sequence"] == "queue" and rf["launches"] == 1 and rf["batches_per_launch"] == 20
     assert rf["bytes_per_launch"] == 20 * 10_000 * 2392 and rf["bytes_per_step"] == 10_000 * 2392
@@ -88,6 +96,16 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     w = out["timed_region_wall_us"]
     assert abs(w["enqueue_call"] + w["until_stop_event"] + w["barrier_and_synchronize"] - w["wall"]) < 1e-6 * w["wall"]
     assert out["settle_ms"] == 50.0 and out["cold_start"]["kernel_us_per_step"] > 0 and 0 < out["cold_start"]["frac"] < 1
+    assert 0 < out["value_cold"] and abs(out["value_cold"] - out["cold_start"]["units_per_s_this_rank"]) < 1e-6 * out["value_cold"]
+    # the metric's second half: coefficient rel-err of the TIMED launch's outputs vs the oracles, >= 512 trajectories over
+    # >= 3 buffer sets, every sampled row NaN-prefilled and rewritten by the timed launch
+    par = out["parity"]
+    assert par["n"] >= 512 and len(set(par["buffer_sets_sampled"])) >= 3 and par["rows_not_written_by_the_timed_launch"] == 0
+    assert par["tol"] == 1e-9 and par["ok"] and par["max_rel_err_vs_port"] <= 1e-9
+    assert par["max_rel_err_vs_reference_build"] is None or par["max_rel_err_vs_reference_build"] <= 1e-9
+    # the per-step hand-over form under the same protocol, as a peer of `value`
+    peer = out["value_other_form"]
+    assert peer["sequence"] == "launches" and peer["steps"] == 20 and 0 < peer["value"] < out["value"] * 1.05
     assert "cold_start" in out["config"]["workload"]
     assert "resident_buffers" in out["extra"]
     one = out["extra"]["one_launch_per_batch"]          # the latency form: reported beside, never as `value`
@@ -113,3 +131,10 @@ def test_latency_form_and_config4_lines():
     assert out["roofline"]["launches"] == 1 and out["roofline"]["batches_per_launch"] == 10     # 10 requests, one launch
     assert out["extra"]["one_launch_per_request"]["us_per_step"] > 0
     assert "cpu_baseline" not in out
+    # parity of the timed launch per polynomial order; the request is pre-built outside the timed region and says so
+    par = out["parity"]
+    assert par["ok"] and set(par["per_n"]) == {"8", "10", "12"} and all(v["n"] >= 512 for v in par["per_n"].values())
+    assert par["per_n"]["8"]["max_rel_err_vs_port"] <= 1e-9 and par["per_n"]["10"]["max_rel_err_vs_port"] <= 1e-9
+    assert out["request_build"]["outside_timed_region"] and out["request_build"]["host_us"] > 0
+    assert 0 < out["request_build"]["value_including_request_build"] < out["value"]
+    assert out["value_other_form"]["sequence"] == "launches" and out["value_other_form"]["value"] > 0
