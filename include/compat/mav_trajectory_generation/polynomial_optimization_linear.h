@@ -13,6 +13,7 @@
 // object owns only host data plus a shared, immutable plan handle; device scratch lives in a per-thread context.
 #ifndef MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
 #define MAV_TRAJECTORY_GENERATION_POLYNOMIAL_OPTIMIZATION_LINEAR_H_
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -98,8 +99,8 @@ inline void check_sync() { check_sync(nullptr); }
 //   * mav_trajectory_generation::setSingleCallsOnDevice(true / false),
 //   * compile-time default `device` with -DMTG_COMPAT_SINGLE_CALLS_ON_DEVICE.
 // Batched entries (PolynomialOptimizationBatch, solveLinearMixed) always run on the GPU.
-inline int& single_calls_on_device_state() {
-  static int state = [] {
+inline std::atomic<int>& single_calls_on_device_state() {   // (atomic: optimiser threads read it while another may toggle it)
+  static std::atomic<int> state{[] {
 #if defined(MTG_COMPAT_SINGLE_CALLS_ON_DEVICE)
     int v = 1;
 #else
@@ -110,13 +111,13 @@ inline int& single_calls_on_device_state() {
       else if (std::string(e) == "host") v = 0;
     }
     return v;
-  }();
+  }()};
   return state;
 }
 }  // namespace mtg_compat_detail
 
-inline void setSingleCallsOnDevice(bool on_device) { mtg_compat_detail::single_calls_on_device_state() = on_device ? 1 : 0; }
-inline bool singleCallsOnDevice() { return mtg_compat_detail::single_calls_on_device_state() != 0; }
+inline void setSingleCallsOnDevice(bool on_device) { mtg_compat_detail::single_calls_on_device_state().store(on_device ? 1 : 0, std::memory_order_relaxed); }
+inline bool singleCallsOnDevice() { return mtg_compat_detail::single_calls_on_device_state().load(std::memory_order_relaxed) != 0; }
 
 template <int _N = 10>
 class PolynomialOptimization {
@@ -197,75 +198,24 @@ class PolynomialOptimization {
     return solveLinearBasic();
   }
 
-  // d_P = basic solution of R_PP d_P = -R_PF d_F (LIN:360-375 with a rank-revealing factorisation), then the
-  // setFreeConstraints path (LIN:263-283) for the coefficients.  Rank threshold as in Eigen's SparseQR::factorize:
-  // 20 * (rows + cols) * (largest column norm) * epsilon.
+  // d_P = basic solution of R_PP d_P = -R_PF d_F (LIN:360-375 with a rank-revealing factorisation; the library's host code,
+  // mtg_basic_solution_host: column-pivoted Householder QR of the dense R_PP, Eigen's SparseQR rank threshold), then the
+  // setFreeConstraints path (LIN:263-283) for the coefficients.
   bool solveLinearBasic() {
     const size_t nf = n_fixed_constraints_, np = n_free_constraints_;
     if (np == 0) return run(/*solve=*/false) == MTG_OK;
-    Eigen::MatrixXd R;
-    getR(&R);
-    std::vector<double> A(np * np);                       // R_PP, column-major
-    for (size_t c = 0; c < np; ++c) for (size_t r = 0; r < np; ++r) A[c * np + r] = R(nf + r, nf + c);
-    std::vector<std::vector<double>> rhs(dimension_, std::vector<double>(np, 0.0));
-    for (size_t d = 0; d < dimension_; ++d)
-      for (size_t r = 0; r < np; ++r) {
-        double acc = 0.0;
-        for (size_t c = 0; c < nf; ++c) acc += R(nf + r, c) * fixed_constraints_compact_[d][c];
-        rhs[d][r] = -acc;
-      }
-    // Householder QR with column pivoting (Businger-Golub), reflectors applied to the right-hand sides on the fly
-    std::vector<size_t> perm(np);
-    std::iota(perm.begin(), perm.end(), (size_t)0);
-    std::vector<double> cn(np);
-    double max_norm = 0.0;
-    for (size_t c = 0; c < np; ++c) {
-      double s2 = 0.0;
-      for (size_t r = 0; r < np; ++r) s2 += A[c * np + r] * A[c * np + r];
-      cn[c] = s2;
-      max_norm = std::max(max_norm, std::sqrt(s2));
-    }
-    const double threshold = 20.0 * double(2 * np) * max_norm * std::numeric_limits<double>::epsilon();
-    size_t rank = 0;
-    std::vector<double> v(np);
-    for (size_t k = 0; k < np; ++k) {
-      size_t piv = k;
-      for (size_t c = k; c < np; ++c) {                   // remaining column norms, recomputed (tiny matrices)
-        double s2 = 0.0;
-        for (size_t r = k; r < np; ++r) s2 += A[c * np + r] * A[c * np + r];
-        cn[c] = s2;
-        if (s2 > cn[piv]) piv = c;
-      }
-      if (std::sqrt(cn[piv]) <= threshold) break;         // every remaining column is numerically dependent
-      if (piv != k) {
-        for (size_t r = 0; r < np; ++r) std::swap(A[k * np + r], A[piv * np + r]);
-        std::swap(perm[k], perm[piv]);
-      }
-      const double alpha = A[k * np + k] > 0.0 ? -std::sqrt(cn[piv]) : std::sqrt(cn[piv]);
-      double vnorm2 = 0.0;
-      for (size_t r = k; r < np; ++r) { v[r] = A[k * np + r]; if (r == k) v[r] -= alpha; vnorm2 += v[r] * v[r]; }
-      if (vnorm2 > 0.0) {
-        auto reflect = [&](double* x) {
-          double dot = 0.0;
-          for (size_t r = k; r < np; ++r) dot += v[r] * x[r];
-          const double f = 2.0 * dot / vnorm2;
-          for (size_t r = k; r < np; ++r) x[r] -= f * v[r];
-        };
-        for (size_t c = k; c < np; ++c) reflect(&A[c * np]);
-        for (size_t d = 0; d < dimension_; ++d) reflect(rhs[d].data());
-      }
-      ++rank;
-    }
-    for (size_t d = 0; d < dimension_; ++d) {
-      std::vector<double> y(np, 0.0);                      // basic solution: variables beyond the rank stay zero
-      for (size_t i = rank; i-- > 0;) {
-        double acc = rhs[d][i];
-        for (size_t c = i + 1; c < rank; ++c) acc -= A[c * np + i] * y[c];
-        y[i] = acc / A[i * np + i];
-      }
-      for (size_t i = 0; i < np; ++i) free_constraints_compact_[d][perm[i]] = y[i];
-    }
-    last_solve_rank_ = rank;
+    std::vector<double> d_fixed(dimension_ * nf), d_free(dimension_ * np);
+    for (size_t d = 0; d < dimension_; ++d) for (size_t c = 0; c < nf; ++c) d_fixed[d * nf + c] = fixed_constraints_compact_[d][c];
+    int32_t rank = 0;
+    const int rc = mtg_basic_solution_host(plan_.get(), segment_times_.data(), d_fixed.data(), d_free.data(), &rank);
+    CHECK(rc == MTG_OK) << mtg_status_string(rc);
+    for (size_t d = 0; d < dimension_; ++d) for (size_t c = 0; c < np; ++c) free_constraints_compact_[d][c] = d_free[d * np + c];
+    last_solve_rank_ = (size_t)rank;
+    static std::atomic<bool> logged{false};
+    if (!logged.exchange(true))
+      LOG(WARNING) << "solveLinear(): rank-deficient free-constraint system (rank " << rank << " of " << np
+                   << "): basic solution from a pivoted QR, like the reference's SparseQR but not in its column order "
+                      "(getLastSolveRank() < getNumberFreeConstraints() tells; logged once)";
     return run(/*solve=*/false) == MTG_OK;
   }
   // numerical rank found by the last solveLinearBasic() (n_free when the last solveLinear() went through the device path)
@@ -575,11 +525,12 @@ class PolynomialOptimizationBatch {
   size_t getNumberFreeConstraints() const { return info_.n_free; }
 
   // Host pointers: synchronous; returns true like the reference -- trajectories whose free-constraint system is rank
-  // deficient (per-trajectory status bit 1 from the library) get the reference's behaviour, a BASIC solution from a
-  // rank-revealing factorisation (LIN:365-378), through PolynomialOptimization<N>::solveLinear() on the host, one by one
-  // (under-constrained problems are rare and tiny); every other trajectory of the batch keeps its device result.
+  // deficient get the reference's behaviour, a BASIC solution from a rank-revealing factorisation (LIN:365-378), inside the
+  // library (MTG_FLAG_BASIC_SOLUTION; under-constrained problems are rare and tiny); every other trajectory of the batch
+  // keeps its device result.
   // Device pointers: asynchronous, no fallback (sync() reports MTG_ERR_SINGULAR; mtg_solve_linear_status names the
-  // trajectories) -- returns true when the launch was enqueued.
+  // trajectories; callers who want the reference's behaviour pass MTG_FLAG_BASIC_SOLUTION to mtg_solve_linear themselves --
+  // that call is synchronous) -- returns true when the launch was enqueued.
   bool solveLinear(size_t batch, const double* times, const double* d_fixed, double* coeffs, double* d_free = nullptr,
                    double* cost = nullptr, bool device_pointers = false) {
     mtg_layout lay;
@@ -589,46 +540,9 @@ class PolynomialOptimizationBatch {
       CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_plan_context(plan_.get()));
       return true;
     }
-    std::vector<int32_t> status(batch, 0);
-    const int rc = mtg_solve_linear_status(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
-                                           status.data(), (uint32_t)MTG_FLAG_HOST_POINTERS);
-    if (rc == MTG_ERR_SINGULAR) {
-      const size_t K = n_segments_, D = dimension_, nf = info_.n_fixed, np = info_.n_free;
-      for (size_t b = 0; b < batch; ++b) {
-        if (!(status[b] & 2)) continue;
-        CHECK(!(status[b] & 1)) << "Segment times need to be greater than zero";   // LIN:297
-        Vertex::Vector vertices;
-        size_t col = 0;
-        for (size_t v = 0; v <= K; ++v) {
-          Vertex vx(D);
-          for (int p = 0; p < N / 2; ++p) {
-            if (!((mask_[v] >> p) & 1u)) continue;
-            Eigen::VectorXd value(D);
-            for (size_t d = 0; d < D; ++d) value[d] = d_fixed[(b * D + d) * nf + col];
-            vx.addConstraint(p, value);
-            ++col;
-          }
-          vertices.push_back(vx);
-        }
-        PolynomialOptimization<N> one(D);
-        one.setupFromVertices(vertices, std::vector<double>(times + b * K, times + (b + 1) * K), derivative_);
-        one.solveLinear();
-        Segment::Vector segs;
-        one.getSegments(&segs);
-        for (size_t k = 0; k < K; ++k)
-          for (size_t d = 0; d < D; ++d) {
-            const Eigen::VectorXd c = segs[k][d].getCoefficients(0);
-            for (int j = 0; j < N; ++j) coeffs[((b * K + k) * D + d) * N + j] = c[j];
-          }
-        if (d_free) {
-          std::vector<Eigen::VectorXd> fr;
-          one.getFreeConstraints(&fr);
-          for (size_t d = 0; d < D; ++d) for (size_t c = 0; c < np; ++c) d_free[(b * D + d) * np + c] = fr[d][c];
-        }
-        if (cost) cost[b] = one.computeCost();
-      }
-      return true;
-    }
+    // (MTG_FLAG_BASIC_SOLUTION: the library replaces the outputs of rank-deficient trajectories by the basic solution)
+    const int rc = mtg_solve_linear(plan_.get(), (int64_t)batch, &lay, times, d_fixed, coeffs, d_free, cost,
+                                    (uint32_t)MTG_FLAG_HOST_POINTERS | (uint32_t)MTG_FLAG_BASIC_SOLUTION);
     CHECK(rc == MTG_OK) << mtg_status_string(rc) << " " << mtg_last_error_string(mtg_plan_context(plan_.get()));
     return true;
   }

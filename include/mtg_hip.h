@@ -103,9 +103,21 @@ enum {
                                      /* joined back onto the context's stream                 */
   MTG_FLAG_QUERY_EXTRA_OUTPUTS = 1u << 9, /* mtg_plan_launch_form only: the form of a call that */
                                      /* also asks for the cost and / or d_free                */
-  MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 1u << 8 /* mtg_solve_linear_sequence: never merge   */
+  MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 1u << 8, /* mtg_solve_linear_sequence: never merge  */
                                      /* the queue into one persistent launch (latency of the  */
                                      /* single launches; A/B measurements)                    */
+  MTG_FLAG_BASIC_SOLUTION = 1u << 10 /* mtg_solve_linear / _status: reference behaviour on     */
+                                     /* RANK-DEFICIENT free systems (LIN:365-378: the rank-   */
+                                     /* revealing SparseQR returns a basic solution and       */
+                                     /* solveLinear() returns true).  Trajectories the sweep  */
+                                     /* flags singular are solved on the host (column-pivoted */
+                                     /* QR of the dense R_PP, Eigen's rank threshold, free    */
+                                     /* variables beyond the rank zero) and their outputs     */
+                                     /* replaced; the call then reports MTG_OK for them (bit 2 */
+                                     /* stays set in trajectory_status: WHICH ones were basic).*/
+                                     /* The call is SYNCHRONOUS and, for device pointers,     */
+                                     /* consumes the context's status word like               */
+                                     /* mtg_context_sync.  Not with MTG_FLAG_COST_ONLY.       */
 };
 #define MTG_HOST_BACKEND_MAX_BATCH 64
 
@@ -170,6 +182,12 @@ int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
 int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* layout,
                             const double* times, const double* d_fixed, double* coeffs,
                             double* d_free, double* cost, int32_t* trajectory_status, uint32_t flags);
+
+/* The basic solution of ONE trajectory's free system on the host (what MTG_FLAG_BASIC_SOLUTION applies to the flagged
+ * trajectories of a batch; LIN:360-375 with a rank-revealing factorisation): times [K], d_fixed [D][n_fixed] ->
+ * d_free [D][n_free] (host pointers); *rank (optional) receives the numerical rank of R_PP (n_free: regular system).
+ * Coefficients follow from mtg_update_segments_from_free (LIN:263-283).                                          */
+int mtg_basic_solution_host(const mtg_plan* plan, const double* times, const double* d_fixed, double* d_free, int32_t* rank);
 
 /* A queue of n INDEPENDENT batches of the same plan (same batch size, layout and flags): solve i reads times[i] /
  * d_fixed[i] and writes coeffs[i] (host arrays of n DEVICE pointers; no batch may read what another one writes), enqueued

@@ -51,6 +51,7 @@ EXPORTS = {
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),
     "mtg_solve_linear_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
                                                c_double_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "mtg_basic_solution_host": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int32)]),
     "mtg_solve_linear_sequence": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "mtg_solve_linear_sequence_events": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(Layout),
@@ -107,6 +108,7 @@ FLAG_HOST_BACKEND = 64
 FLAG_CONCURRENT_ITEMS = 128
 FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 256
 FLAG_QUERY_EXTRA_OUTPUTS = 512
+FLAG_BASIC_SOLUTION = 1024
 
 _lib = None
 

@@ -230,13 +230,15 @@ class Plan:
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
               coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True,
-              traj_status=None):
+              traj_status=None, basic_solution: bool = False):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
         dims: launch form -- 'auto', 'fused', 'split' (one dimension group per workgroup) or 'dimlane' (all dimensions of
         a trajectory in one wavefront; canonical SoA or AoS inputs, coefficient output only -- falls back to 'auto' where
         not eligible).
         traj_status: optional int32 CUDA tensor [B] that receives the per-trajectory status bits (1 bad time, 2 singular).
+        basic_solution: the reference's behaviour on rank-deficient free systems (MTG_FLAG_BASIC_SOLUTION: flagged trajectories
+        get the basic solution of a pivoted QR on the host; the call is then synchronous).
         ordered=False skips the automatic ordering against torch's current stream (the caller forks / joins the
         context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors
         must then be passed in, allocated by the caller before the fork."""
@@ -255,6 +257,8 @@ class Plan:
         lay = self.layout(batch, layout)
         flags = L.FLAG_GENERIC_KERNEL if generic else 0
         flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        if basic_solution:
+            flags |= L.FLAG_BASIC_SOLUTION
         if traj_status is not None:
             assert traj_status.dtype == torch.int32 and traj_status.is_cuda and traj_status.numel() >= batch
         cur = self.ctx._enter() if ordered else None
@@ -327,7 +331,7 @@ class Plan:
         return coeffs, cost
 
     def solve_host(self, times: np.ndarray, d_fixed: np.ndarray, want_free=True, want_cost=True, generic=False,
-                   coeffs: Optional[np.ndarray] = None, host_backend: bool = False):
+                   coeffs: Optional[np.ndarray] = None, host_backend: bool = False, basic_solution: bool = False):
         """Host-buffer convenience (AoS numpy in/out, staged through the device by the library).  Pass page-locked
         arrays (e.g. pinned torch tensors viewed as numpy, also for `coeffs`) to have them DMA'd directly."""
         times = np.ascontiguousarray(times, dtype=np.float64)
@@ -343,6 +347,8 @@ class Plan:
         flags = L.FLAG_HOST_POINTERS | (L.FLAG_GENERIC_KERNEL if generic else 0)
         if host_backend:   # batch <= 64: the lane code's host build on this thread (latency path), no GPU involved
             flags |= L.FLAG_HOST_BACKEND
+        if basic_solution:  # rank-deficient trajectories get the reference's basic solution (LIN:365-378)
+            flags |= L.FLAG_BASIC_SOLUTION
         rc = self.lib.mtg_solve_linear(self.handle, batch, ctypes.byref(lay), p(times), p(d_fixed), p(coeffs),
                                        p(d_free), p(cost), flags)
         _check(self.lib, rc, self.ctx.handle)

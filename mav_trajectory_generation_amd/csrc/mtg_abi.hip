@@ -28,6 +28,8 @@
 #include "mtg_dimlane_rt.h"
 
 int mtg_host_run(const MtgParams& P, int H, bool update);   // mtg_host.cpp: host build of the lane code
+extern "C" int mtg_basic_solution_one(int H, int K, int D, int deriv, const int* mask, const int* offF, const int* offP,
+                                      const double* times, const double* dfix, double* dfree);   // mtg_basic.cpp (internal; exported for the CPU tests)
 
 namespace {
 
@@ -897,14 +899,106 @@ int mtg_plan_set_workspace(mtg_plan* p, void* device_ptr, size_t bytes) {
   return MTG_OK;
 }
 
+int mtg_basic_solution_host(const mtg_plan* p, const double* times, const double* d_fixed, double* d_free, int32_t* rank) {
+  if (!p || !times || (p->n_fixed > 0 && !d_fixed) || (p->n_free > 0 && !d_free)) return MTG_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < p->K; ++k)
+    if (!(times[k] > 0.0)) return MTG_ERR_BAD_SEGMENT_TIME;
+  const int r = mtg_basic_solution_one(p->H, p->K, p->D, p->deriv, p->mask.data(), p->offF.data(), p->offP.data(), times, d_fixed, d_free);
+  if (r < 0) return MTG_ERR_UNSUPPORTED;
+  if (rank) *rank = r;
+  return MTG_OK;
+}
+
+// MTG_FLAG_BASIC_SOLUTION: the ordinary solve, then -- synchronously -- the trajectories the LDL^T sweep flagged singular are
+// solved again on the host (mtg_basic.cpp: column-pivoted QR of the dense R_PP, LIN:365-378), their coefficients recovered
+// with the host build of the update path (LIN:263-283), and their rows of the outputs replaced.
+static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                                     double* coeffs, double* d_free, double* cost, int32_t* traj_status, uint32_t flags) {
+  if (!p || !L) return MTG_ERR_INVALID_ARGUMENT;
+  if (flags & MTG_FLAG_COST_ONLY) return set_err(p->ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_BASIC_SOLUTION needs coefficient output");
+  mtg_context* ctx = p->ctx;
+  const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
+  const uint32_t inner = flags & ~(uint32_t)MTG_FLAG_BASIC_SOLUTION;
+  if (batch <= 0) return solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, traj_status);
+  std::vector<int32_t> ts((size_t)batch, 0);
+  int32_t* dev_ts = nullptr;           // device-pointer calls: the per-trajectory status the kernels write
+  bool own_dev_ts = false;
+  int rc;
+  if (host) {
+    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, ts.data());
+    if (traj_status) std::memcpy(traj_status, ts.data(), (size_t)batch * sizeof(int32_t));
+    if (rc != MTG_ERR_SINGULAR && rc != MTG_ERR_BAD_SEGMENT_TIME) return rc;
+  } else {
+    dev_ts = traj_status;
+    if (!dev_ts) {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+      MTG_HIP_TRY(ctx, hipMalloc((void**)&dev_ts, (size_t)batch * sizeof(int32_t)));
+      own_dev_ts = true;
+    }
+    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, dev_ts);
+    if (rc == MTG_OK) rc = mtg_context_sync(ctx);      // (consumes the context's status word: documented with the flag)
+    if (rc == MTG_ERR_SINGULAR || rc == MTG_ERR_BAD_SEGMENT_TIME) {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      if (hipMemcpy(ts.data(), dev_ts, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = MTG_ERR_DEVICE;
+    }
+    if (own_dev_ts) { std::lock_guard<std::mutex> lock(ctx->mu); hipFree(dev_ts); }
+    if (rc != MTG_ERR_SINGULAR && rc != MTG_ERR_BAD_SEGMENT_TIME) return rc;
+  }
+  // one flagged trajectory after the other: gather its inputs (any strides), solve, recover, scatter
+  const int K = p->K, D = p->D, nf = p->n_fixed, np = p->n_free, N = p->N;
+  std::vector<double> t(K), fx((size_t)D * std::max(nf, 1)), fr((size_t)D * std::max(np, 1)), co((size_t)K * D * N);
+  double cost1 = 0.0;
+  bool any_bad_time = false;
+  auto pull = [&](double* dst, const double* src, int64_t stride, int count) -> bool {   // dst[i] = src[i * stride]
+    if (host) { for (int i = 0; i < count; ++i) dst[i] = src[(int64_t)i * stride]; return true; }
+    return hipMemcpy2D(dst, sizeof(double), src, (size_t)stride * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost) == hipSuccess;
+  };
+  auto push = [&](double* dst, int64_t stride, const double* src, int count) -> bool {   // dst[i * stride] = src[i]
+    if (host) { for (int i = 0; i < count; ++i) dst[(int64_t)i * stride] = src[i]; return true; }
+    return hipMemcpy2D(dst, (size_t)stride * sizeof(double), src, sizeof(double), sizeof(double), (size_t)count, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  std::unique_lock<std::mutex> lock(ctx->mu, std::defer_lock);
+  if (!host) { lock.lock(); MTG_HIP_TRY(ctx, hipSetDevice(ctx->device)); }
+  for (int64_t b = 0; b < batch; ++b) {
+    if (ts[b] & MTG_FLAG_BAD_TIME) { any_bad_time = true; continue; }
+    if (!(ts[b] & MTG_FLAG_SINGULAR)) continue;
+    bool ok = pull(t.data(), times + b * L->times_stride_b, std::max<int64_t>(L->times_stride_k, 1), K);
+    for (int d = 0; d < D && ok && nf > 0; ++d)
+      ok = pull(fx.data() + (size_t)d * nf, d_fixed + b * L->fixed_stride_b + d * L->fixed_stride_d, std::max<int64_t>(L->fixed_stride_c, 1), nf);
+    if (!ok) return set_err(ctx, MTG_ERR_DEVICE, "basic solution: gathering a flagged trajectory failed");
+    if (mtg_basic_solution_one(p->H, K, D, p->deriv, p->mask.data(), p->offF.data(), p->offP.data(), t.data(), fx.data(), fr.data()) < 0)
+      return set_err(ctx, MTG_ERR_UNSUPPORTED, "basic solution: unsupported shape");
+    // coefficients (and the cost) of this one trajectory: host build of the update path, contiguous AoS scratch
+    MtgParams P;
+    mtg_layout one;
+    mtg_layout_aos(p, 1, &one);
+    fill_common(p, P, 1, &one);
+    int st_word = 0;
+    P.times = t.data(); P.dfix = fx.data(); P.coeffs = co.data(); P.dfree = fr.data(); P.cost = cost ? &cost1 : nullptr;
+    P.status = &st_word; P.tstatus = nullptr;
+    P.vmask = p->mask.data(); P.offF = p->offF.data(); P.offP = p->offP.data();
+    if (mtg_host_run(P, p->H, /*update=*/true) != 0) return set_err(ctx, MTG_ERR_UNSUPPORTED, "basic solution: no host update path");
+    ok = push(coeffs + b * (int64_t)K * D * N, 1, co.data(), K * D * N);
+    for (int d = 0; d < D && ok && d_free && np > 0; ++d)
+      ok = push(d_free + b * L->free_stride_b + d * L->free_stride_d, std::max<int64_t>(L->free_stride_c, 1), fr.data() + (size_t)d * np, np);
+    if (ok && cost) ok = push(cost + b, 1, &cost1, 1);
+    if (!ok) return set_err(ctx, MTG_ERR_DEVICE, "basic solution: writing a trajectory back failed");
+  }
+  return any_bad_time ? set_err(ctx, MTG_ERR_BAD_SEGMENT_TIME, mtg_status_string(MTG_ERR_BAD_SEGMENT_TIME)) : MTG_OK;
+}
+
 int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                      const double* d_fixed, double* coeffs, double* d_free, double* cost, uint32_t flags) {
+  if (flags & MTG_FLAG_BASIC_SOLUTION) return solve_with_basic_solution(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, nullptr, flags);
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false);
 }
 
 int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                             const double* d_fixed, double* coeffs, double* d_free, double* cost,
                             int32_t* trajectory_status, uint32_t flags) {
+  if (flags & MTG_FLAG_BASIC_SOLUTION)
+    return solve_with_basic_solution(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, trajectory_status, flags);
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false, trajectory_status);
 }
 

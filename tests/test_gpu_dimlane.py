@@ -361,6 +361,54 @@ def test_runtime_k_body_other_interior_masks(ctx, k, dim, interior):
     plan.close()
 
 
+RT_MANY_TILES = [  # (N, K, D, interior mask, layout, B): B > 2 * CUs * tile width and not a multiple of it
+    (10, 6, 3, 1, "soa", 12001), (10, 9, 3, 1, "aos", 12001), (10, 35, 3, 1, "soa", 25000), (10, 40, 3, 1, "soa", 12001),
+    (12, 7, 3, 1, "soa", 12001), (12, 19, 3, 1, "aos", 25000), (12, 37, 3, 1, "soa", 12001),
+    (8, 5, 3, 1, "soa", 25000), (8, 70, 3, 1, "aos", 12001),
+    (10, 9, 4, 1, "soa", 12001), (10, 24, 4, 7, "aos", 9001), (10, 57, 4, 7, "soa", 9001),
+]
+
+
+@pytest.mark.parametrize("case", RT_MANY_TILES)
+def test_runtime_k_body_many_tiles_per_workgroup(ctx, ctx_rt, case):
+    """the persistent workgroups of the run-time-K body (grid = 2 x CUs) must walk SEVERAL tiles each -- reuse of
+    the LDS slab / exchange area, the step area and the workspace column across tiles, the per-tile phase reset of pieces that
+    are not a multiple of 64 bytes (N = 10: K mod 4 != 0, N = 12: odd K) for tiles with b0 > 0, and a ragged last tile after a
+    full round.  Against another launch form of the same plan (static variant / fused), NaN-prefilled outputs, a sentinel row
+    behind the last trajectory, and the oracle on rows of the first, a middle and the last tile."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, mi, layout, bsz = case
+    d = n // 2 - 1
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tpw = 64 // dim
+    assert bsz > 2 * cus * tpw and bsz % tpw != 0
+    masks = m.ends_full_masks(n, k, mi)
+    t, f = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=7 * n + k + dim, device="cuda", layout=layout, yaw_dim=(dim == 4))
+    plan_rt = m.Plan(ctx_rt, n, dim, k, d, masks)
+    assert plan_rt.launch_form(bsz, layout) == "dimlane_rt"
+    co = torch.full((bsz + 1, k, dim, n), float("nan"), dtype=torch.float64, device="cuda")
+    co[bsz] = 7.0
+    plan_rt.solve(t, f, layout=layout, coeffs=co[:bsz])
+    ctx_rt.sync()
+    assert torch.isfinite(co[:bsz]).all()
+    assert float(co[bsz].min()) == 7.0 and float(co[bsz].max()) == 7.0      # nothing written past the end
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    other = "fused" if plan.launch_form(bsz, layout) == "dimlane_rt" else "auto"
+    ref, _, _ = plan.solve(t, f, layout=layout, dims=other)
+    ctx.sync()
+    assert plan.launch_form(bsz, layout, other) != "dimlane_rt"
+    rel, _ = ctx.compare_coefficients(co[:bsz].contiguous(), ref)
+    assert rel < (1e-11 if n <= 10 else 1e-9), (plan.launch_form(bsz, layout, other), rel)
+    rows = torch.tensor([0, 1, tpw, bsz // 2, bsz // 2 + 1, 2 * cus * tpw + 3, bsz - 2, bsz - 1], device="cuda")
+    th = (t[:, rows].t() if layout == "soa" else t[rows]).contiguous().cpu().numpy()
+    fh = (f[:, :, rows].permute(2, 0, 1) if layout == "soa" else f[rows]).contiguous().cpu().numpy()
+    c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
+    assert helpers.poly_relerr(co[rows].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    plan_rt.close()
+    plan.close()
+
+
 def test_runtime_k_body_is_the_default_beyond_the_static_variants(ctx):
     import mav_trajectory_generation_amd as m
     for (n, k, want) in ((12, 50, "dimlane_rt"), (10, 100, "dimlane_rt"), (8, 33, "dimlane_rt"), (10, 32, "dimlane"), (10, 50, "dimlane")):
