@@ -6,8 +6,11 @@ reference's own PolynomialOptimization<N> code is compiled from /root/reference 
 lies into oracle/_ref/libmtg_ref.so (oracle/Makefile `ref`; Eigen and glog -- un-vendored,
 un-pinned dependencies fetched by install/mav_trajectory_generation_https.rosinstall:1-6,
 absent offline -- are replaced by the container stand-ins in oracle/ref_shim/, whose
-header says exactly what is not Eigen's: Gauss-Jordan inverse, natural-order Householder
-QR for SparseQR+COLAMD).  tests/test_reference_build.py checks this restatement against
+header says exactly what is not Eigen's: eager dense containers; inverse() and SparseQR
+follow Eigen's algorithm CLASSES -- cofactor formulas up to 4x4, partial-pivoting LU above,
+left-looking column Householder QR in a minimum-degree column order with Eigen's pivot
+threshold -- not its exact operation order; `make -C oracle ref_eigen EIGEN_DIR=...` builds
+the same sources against a real Eigen on a box that has one).  tests/test_reference_build.py checks this restatement against
 that library step by step (A, Q bit/ulp-equal; M identical; A^-1, R, d_P, coefficients,
 cost to round-off x cond: <= 7e-11 norm-wise for N = 10 snap) and against its committed
 outputs (tests/golden/reference_solve_linear.npz).  It is additionally pinned on the
@@ -15,8 +18,9 @@ reference's golden vector (test_polynomial_optimization.cpp:777-780, n_free == 0
 property tests (AMatrixInversion :731-741, ConstraintPacking :505-564, checkPath
 :113-174); oracle/oracle_mp.py (mpmath, 50 digits) arbitrates below the float64
 evaluation error of the reference's own formulas (1e-11 for N = 10 .. 1e-8 for N = 12).
-What stays unpinned: real Eigen's last-bits behaviour (its LU / SparseQR pivot order),
-which no reference test constrains either.
+What stays unpinned in THIS image: real Eigen's last-bits behaviour (its LU / SparseQR
+operation order), which no reference test constrains either; tests/test_reference_build.py::
+test_real_eigen_build_vs_stand_in pins it wherever _ref/libmtg_ref_eigen.so exists.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 

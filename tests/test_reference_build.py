@@ -257,3 +257,26 @@ def test_scale_segment_times_restatement_vs_reference():
         cs = np.abs(c_ref).max(axis=-1, keepdims=True)
         assert np.max(np.abs(segs - c_ref) / cs) <= 1e-10
     assert n_scaled > 0
+
+
+# ------------------------------------------------------------------------------------------------ real-Eigen layer
+@pytest.mark.skipif(not ref_linear.eigen_build_available(),
+                    reason="oracle/_ref/libmtg_ref_eigen.so absent: this image has no Eigen (make -C oracle ref_eigen EIGEN_DIR=...)")
+@pytest.mark.parametrize("name", NAMES)
+def test_real_eigen_build_vs_stand_in(name):
+    """the anchor's last bits are Eigen's (inverse(), sparse products, SparseQR + COLAMD), which the container
+    stand-ins only follow by algorithm class.  On a box that has Eigen, `make -C oracle ref_eigen EIGEN_DIR=...` builds the SAME
+    reference sources against it; this test then pins the committed stand-in outputs to the real-Eigen outputs within the
+    reference's own distance to the 50-digit truth (the tolerance every comparison against the reference uses), and checks
+    the known-answer vector through real Eigen."""
+    n, d, masks, times, d_fixed = inputs(name)
+    ref_linear.use_eigen_build(True)
+    try:
+        co, fr, cost, _ = ref_linear.solve_batch(n, d, masks, times, d_fixed)
+    finally:
+        ref_linear.use_eigen_build(False)
+    tol = tol_for(n, d)
+    assert helpers.poly_relerr(co, REF[f"{name}/coeffs_ref"]) < tol
+    assert np.allclose(cost, REF[f"{name}/cost_ref"], rtol=1e-8)
+    if name == "two_vertices":
+        assert np.abs(co[0, 0, 0] - GOLD["two_vertices/matlab_coeffs"]).max() < 1e-12

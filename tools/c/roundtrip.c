@@ -83,9 +83,40 @@ int main(int argc, char** argv) {
     }
     printf("queue of %d x %lld trajectories in one call vs one call each: max norm-wise rel diff %.3e\n", NQ, (long long)bq, rel_q);
   }
+  /* an UNDER-CONSTRAINED problem (one segment, only the two end positions fixed): the reference's rank-revealing SparseQR
+   * returns a basic solution and solveLinear() returns true (LIN:365-378).  Without the flag the call reports
+   * MTG_ERR_SINGULAR; with MTG_FLAG_BASIC_SOLUTION it returns MTG_OK, the straight line between the points costs nothing */
+  int basic_ok = 0;
+  {
+    uint32_t m2[2] = {1u, 1u};
+    mtg_plan_desc d2 = {N, D, 1, DERIV, m2};
+    mtg_plan* p2 = NULL;
+    CHECK(mtg_plan_create(ctx, &d2, &p2));
+    mtg_layout l2;
+    mtg_layout_aos(p2, 3, &l2);
+    const double t2[3] = {1.0, 1.5, 2.5};
+    const double f2[3 * D * 2] = {0, 1, 0, 2, 0, 3, 1, -1, 2, -2, 3, -3, 0.5, 0.25, 0.5, 0.75, -1, 4};
+    double c2[3 * D * N], j2[3];
+    const int rc_plain = mtg_solve_linear(p2, 3, &l2, t2, f2, c2, NULL, j2, MTG_FLAG_HOST_POINTERS);
+    CHECK(mtg_solve_linear(p2, 3, &l2, t2, f2, c2, NULL, j2, MTG_FLAG_HOST_POINTERS | MTG_FLAG_BASIC_SOLUTION));
+    double worst = 0.0;
+    for (int b = 0; b < 3; ++b)
+      for (int d = 0; d < D; ++d) {
+        const double* c = c2 + (b * D + d) * N;
+        double end = 0.0, tp_ = 1.0;
+        for (int j = 0; j < N; ++j) { end += c[j] * tp_; tp_ *= t2[b]; }
+        const double e0 = c[0] - f2[(b * D + d) * 2], e1 = end - f2[(b * D + d) * 2 + 1];
+        if ((e0 < 0 ? -e0 : e0) > worst) worst = e0 < 0 ? -e0 : e0;
+        if ((e1 < 0 ? -e1 : e1) > worst) worst = e1 < 0 ? -e1 : e1;
+      }
+    basic_ok = rc_plain == MTG_ERR_SINGULAR && worst < 1e-9 && j2[0] < 1e-9 && j2[1] < 1e-9 && j2[2] < 1e-9;
+    printf("under-constrained batch: plain call -> %d (%s); with MTG_FLAG_BASIC_SOLUTION -> ok, end-point error %.2e, cost %.2e\n",
+           rc_plain, mtg_status_string(rc_plain), worst, j2[0] + j2[1] + j2[2]);
+    mtg_plan_destroy(p2);
+  }
   mtg_device_free(ctx, times); mtg_device_free(ctx, dfix); mtg_device_free(ctx, ca); mtg_device_free(ctx, cb);
   mtg_plan_destroy(plan);
   mtg_context_destroy(ctx);
   free(mask);
-  return (rel < 1e-10 && rel_q < 1e-10) ? 0 : 3;
+  return (rel < 1e-10 && rel_q < 1e-10 && basic_ok) ? 0 : 3;
 }
