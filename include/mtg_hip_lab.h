@@ -1,0 +1,35 @@
+/* mtg_hip_lab.h -- measurement knobs of libmtg_hip.so.  NOT part of the drop-in boundary (include/mtg_hip.h): nothing a
+ * consumer of the solver needs lives here.  The library never reads the environment; A/B measurements (tools/) and the
+ * tests that force one kernel form against another set these per context, by name.  The Python layer
+ * (mav_trajectory_generation_amd.Context) forwards the environment variables MTG_<NAME> of the process it runs in.
+ *
+ *   name               value                       effect (default = shipped behaviour)
+ *   "force_dg"         1..4, 0 = off               dimension-group size of the specialised fused / split kernels
+ *   "prefer_rolled"    0 / 1                       rolled (run-time K) kernel even where a static one exists
+ *   "no_dimlane"       0 / 1                       never the dimension-in-lane forms
+ *   "dl_policy"        -1 default, 0 / 1 / 2       coefficient store policy of the dimension-in-lane form
+ *   "no_slab"          0 / 1                       fused form without the slab-output kernel
+ *   "no_slab_extra"    0 / 1                       extra outputs (cost / d_P) through the older fused kernel
+ *   "no_dl_extra"      0 / 1                       extra outputs never through the dimension-in-lane kernels
+ *   "no_queue"         0 / 1                       mtg_solve_linear_sequence as one launch per batch
+ *   "no_balance"       0 / 1                       persistent grids not evened out over their rounds
+ *   "dl_occ2"          -1 default, 0 never, 1 always   two-waves-per-SIMD twins of the dimension-in-lane variants
+ *   "dl_rt"            -1 default, 0 never, 1 always   run-time-K dimension-in-lane body
+ *   "dl_grid_per_cu"   >= 1 (default 8)            workgroups per CU of a non-workspace dimension-in-lane launch
+ *   "dl_any_sched_rr"  0 / 1                       round 2's unit schedule of the cross-structure launch
+ *   "slab_policy"      -1 default, 0 / 1           store policy of the slab-output kernels (write-back / nt sc1)
+ *   "rolled_wg_per_cu" >= 1 (default 4)            persistent workgroups per CU of the rolled kernels
+ *   "dl_max_units"     -1 default, >= 0            upper limit of the dimension-in-lane default range (x CUs)
+ *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
+ * Returns MTG_OK, or MTG_ERR_INVALID_ARGUMENT for an unknown name.                                                  */
+#ifndef MTG_HIP_LAB_H_
+#define MTG_HIP_LAB_H_
+#include "mtg_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int mtg_context_set_option(mtg_context* ctx, const char* name, int value);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,6 +37,7 @@ EXPORTS = {
     "mtg_context_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "mtg_context_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mtg_context_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_context_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),   # include/mtg_hip_lab.h
     "mtg_last_error_string": (ctypes.c_char_p, [ctypes.c_void_p]),
     "mtg_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mtg_plan_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanDesc), ctypes.POINTER(ctypes.c_void_p)]),
@@ -96,6 +97,19 @@ EXPORTS = {
     "mtg_multi_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mtg_time_last_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mtg_selftest_rcp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+}
+
+# Measurement knobs (include/mtg_hip_lab.h): the library never reads the environment; Context forwards these variables of
+# the process it is created in -- environment variable -> (option name, how its text becomes the option's value)
+_flag = lambda e: 1
+ENV_OPTIONS = {
+    "MTG_FORCE_DG": ("force_dg", int), "MTG_PREFER_ROLLED": ("prefer_rolled", _flag), "MTG_NO_DIMLANE": ("no_dimlane", _flag),
+    "MTG_DL_POLICY": ("dl_policy", int), "MTG_NO_SLAB": ("no_slab", _flag), "MTG_NO_QUEUE": ("no_queue", _flag),
+    "MTG_NO_SLAB_EXTRA": ("no_slab_extra", _flag), "MTG_NO_DL_EXTRA": ("no_dl_extra", _flag),
+    "MTG_NO_BALANCE": ("no_balance", _flag), "MTG_DL_OCC2": ("dl_occ2", int), "MTG_DL_RT": ("dl_rt", int),
+    "MTG_DL_GRID_PER_CU": ("dl_grid_per_cu", int), "MTG_DL_ANY_SCHED": ("dl_any_sched_rr", lambda e: int(e == "rr")),
+    "MTG_SLAB_POLICY": ("slab_policy", lambda e: 1 if int(e) else 0), "MTG_ROLLED_WG_PER_CU": ("rolled_wg_per_cu", int),
+    "MTG_DL_MAX_UNITS": ("dl_max_units", int), "MTG_SAMPLE_GENERIC": ("sample_generic", _flag),
 }
 
 FLAG_HOST_POINTERS = 1

@@ -49,8 +49,17 @@ class Context:
         _check(self.lib, self.lib.mtg_context_create(self.device, ctypes.c_void_p(self.stream.cuda_stream),
                                                      ctypes.byref(h)))
         self.handle = h
+        import os
         import weakref
         self._plans = weakref.WeakSet()   # plans must be destroyed before their context
+        # measurement knobs (include/mtg_hip_lab.h): the library itself never reads the environment
+        for env, (name, conv) in L.ENV_OPTIONS.items():
+            if env in os.environ:
+                self.set_option(name, conv(os.environ[env]))
+
+    def set_option(self, name: str, value: int):
+        """A measurement knob of this context by name (include/mtg_hip_lab.h: A/B runs and form-forcing tests)."""
+        _check(self.lib, self.lib.mtg_context_set_option(self.handle, name.encode(), int(value)), self.handle)
 
     def _enter(self):
         """Order the library's stream after torch's current stream (no-op when they are the same)."""

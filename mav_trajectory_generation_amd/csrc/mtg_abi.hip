@@ -106,7 +106,9 @@ struct mtg_context {
   double* h_bounce = nullptr;
   size_t h_bounce_bytes = 0;
   int n_cu = 256;
-  // measurement knobs, read once from the environment at context creation (A/B runs in tools/; 0 = off)
+  // measurement knobs (A/B runs in tools/, form-forcing tests): set through mtg_context_set_option (include/mtg_hip_lab.h),
+  // never read from the environment by the library; defaults = the shipped behaviour.  The names in the comments are the
+  // environment variables the PYTHON layer forwards (mav_trajectory_generation_amd.Context) -- e.g. MTG_FORCE_DG -> "force_dg"
   int knob_force_dg = 0;        // MTG_FORCE_DG: dimension-group size of the specialised kernels
   bool knob_prefer_rolled = false;   // MTG_PREFER_ROLLED: rolled variant even where a static one exists
   bool knob_no_dimlane = false;      // MTG_NO_DIMLANE: never pick the dimension-in-lane form
@@ -123,6 +125,7 @@ struct mtg_context {
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
+  bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
@@ -262,25 +265,38 @@ int mtg_context_create(int device, void* stream, mtg_context** out) {
     return MTG_ERR_DEVICE;
   }
   *ctx->h_status = 0;
-  if (const char* e = getenv("MTG_FORCE_DG")) ctx->knob_force_dg = atoi(e);
-  ctx->knob_prefer_rolled = getenv("MTG_PREFER_ROLLED") != nullptr;
-  ctx->knob_no_dimlane = getenv("MTG_NO_DIMLANE") != nullptr;
-  if (const char* e = getenv("MTG_DL_POLICY")) ctx->knob_dl_policy = atoi(e);
-  ctx->knob_no_slab = getenv("MTG_NO_SLAB") != nullptr;
-  ctx->knob_no_queue = getenv("MTG_NO_QUEUE") != nullptr;
-  ctx->knob_no_slab_extra = getenv("MTG_NO_SLAB_EXTRA") != nullptr;
-  ctx->knob_no_dl_extra = getenv("MTG_NO_DL_EXTRA") != nullptr;
-  ctx->knob_no_balance = getenv("MTG_NO_BALANCE") != nullptr;
-  if (const char* e = getenv("MTG_DL_OCC2")) ctx->knob_dl_occ2 = atoi(e);
-  if (const char* e = getenv("MTG_DL_RT")) ctx->knob_dl_rt = atoi(e);
-  if (const char* e = getenv("MTG_DL_GRID_PER_CU")) ctx->knob_dl_grid_per_cu = std::max(1, atoi(e));
-  if (const char* e = getenv("MTG_DL_ANY_SCHED")) ctx->knob_dl_any_rr = std::string(e) == "rr";
-  if (const char* e = getenv("MTG_SLAB_POLICY")) ctx->knob_slab_policy = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("MTG_ROLLED_WG_PER_CU")) ctx->rolled_wg_per_cu = std::max(1, atoi(e));
-  if (const char* e = getenv("MTG_DL_MAX_UNITS")) ctx->dl_max_units_per_cu = atoi(e);
   *out = ctx;
   return MTG_OK;
 }
+
+// include/mtg_hip_lab.h: measurement knobs by name (no environment reads inside the library)
+int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
+  if (!ctx || !name) return MTG_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const std::string n(name);
+  if (n == "force_dg") ctx->knob_force_dg = value;
+  else if (n == "prefer_rolled") ctx->knob_prefer_rolled = value != 0;
+  else if (n == "no_dimlane") ctx->knob_no_dimlane = value != 0;
+  else if (n == "dl_policy") ctx->knob_dl_policy = value;
+  else if (n == "no_slab") ctx->knob_no_slab = value != 0;
+  else if (n == "no_queue") ctx->knob_no_queue = value != 0;
+  else if (n == "no_slab_extra") ctx->knob_no_slab_extra = value != 0;
+  else if (n == "no_dl_extra") ctx->knob_no_dl_extra = value != 0;
+  else if (n == "no_balance") ctx->knob_no_balance = value != 0;
+  else if (n == "dl_occ2") ctx->knob_dl_occ2 = value;
+  else if (n == "dl_rt") ctx->knob_dl_rt = value;
+  else if (n == "dl_grid_per_cu") ctx->knob_dl_grid_per_cu = std::max(1, value);
+  else if (n == "dl_any_sched_rr") ctx->knob_dl_any_rr = value != 0;
+  else if (n == "slab_policy") ctx->knob_slab_policy = value < 0 ? -1 : (value ? 1 : 0);
+  else if (n == "rolled_wg_per_cu") ctx->rolled_wg_per_cu = std::max(1, value);
+  else if (n == "dl_max_units") ctx->dl_max_units_per_cu = value;
+  else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
+  else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
+  return MTG_OK;
+}
+
+// (mtg_sample.hip)
+bool mtg_context_sample_generic(const mtg_context* ctx) { return ctx && ctx->knob_sample_generic; }
 
 int mtg_context_destroy(mtg_context* ctx) {
   if (!ctx) return MTG_OK;
@@ -529,6 +545,9 @@ static const MtgDimlaneRtEntry* pick_dimlane_rt(const mtg_plan* p, int64_t batch
   if (p->dimlane && p->ctx->knob_dl_rt != 1) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
   if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
+  // the body keeps the batch size and its tile count in 32-bit integers (its input addresses are 64-bit, unlike the static
+  // variants' 32-bit byte offsets)
+  if (batch + rt->tpw >= (1ll << 31)) return nullptr;
   return rt;
 }
 
@@ -581,6 +600,306 @@ static const MtgSlabEntry* pick_slab(const mtg_plan* p, const MtgStaticEntry* va
 
 struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradient: (K + 1) virtual problems per trajectory
 
+// ---- one solve / update call: stage (host pointers) -> pick_form -> launch_<form> -> fetch (host pointers) ------------------
+enum class SolveForm { kUpdate, kDimlaneRt, kDimlane, kFused };   // kFused: slab-output / static / rolled / generic kernels
+
+struct SolveCall {                  // everything a launcher needs, assembled once by solve_impl
+  mtg_plan* p;
+  int64_t batch;
+  const mtg_layout* L;
+  uint32_t flags;
+  bool cost_only, wc;               // wc: extra outputs (cost and / or d_P) requested
+  const PerturbedTimes* pert;
+  hipStream_t st;
+  MtgParams P;                      // device pointers, strides, tables
+  int ntiles;                       // 64-trajectory tiles (x (K + 1) virtual problems for perturbed-time launches)
+  int32_t* dts;                     // per-trajectory status on the device (or null)
+  const MtgDimlaneRtEntry* rt = nullptr;    // set by pick_form for the form it chose
+  const MtgDimlaneEntry* dl = nullptr;
+};
+
+static int workspace(mtg_plan* p, size_t need, double** out) {
+  mtg_context* ctx = p->ctx;
+  if (p->user_ws) {
+    if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
+    *out = p->user_ws;
+    return MTG_OK;
+  }
+  const int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
+  if (rc == MTG_OK) *out = p->ws;
+  return rc;
+}
+
+// Which form a call takes: the run-time-K dimension-in-lane body where the plan has no static variant, the static
+// dimension-in-lane variants inside their default range (or forced), else the fused family.  Same order as
+// mtg_plan_launch_form reports.
+static SolveForm pick_form(SolveCall& c, bool update_only) {
+  if (update_only) return SolveForm::kUpdate;
+  if ((c.rt = pick_dimlane_rt(c.p, c.batch, c.L, c.P, c.flags, c.cost_only))) return SolveForm::kDimlaneRt;
+  if ((c.dl = dimlane_twin(c.p, pick_dimlane(c.p, c.batch, c.L, c.P, c.flags, c.cost_only), c.batch))) return SolveForm::kDimlane;
+  return SolveForm::kFused;
+}
+
+// setFreeConstraints path (LIN:500-508): compile-time-mask ("rolled") update kernel when the plan has one (all D dimensions in
+// one launch), else generic
+static int launch_update(SolveCall& c) {
+  mtg_plan* p = c.p;
+  mtg_context* ctx = p->ctx;
+  const MtgStaticEntry* uv = (c.flags & MTG_FLAG_GENERIC_KERNEL) ? nullptr
+                             : mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
+  for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
+    const int dc = uv ? p->D : std::min(4, p->D - dim0);
+    UpdateFn fn = uv ? uv->upd[c.wc ? 1 : 0] : mtg_pick_generic_update(p->H, dc, c.wc);
+    if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no update kernel");
+    MtgParams Q = c.P;
+    Q.dim0 = dim0;
+    const int grid = std::min(c.ntiles, ctx->n_cu * 16);
+    size_t lds = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+    // whole-sector output (mtg_update_slab_kernel) for the rolled form; "no_slab" keeps the per-segment staging
+    const int phase = ((size_t)p->K * p->D * p->N * 8) % 64 != 0 ? 1 : 0;
+    if (uv && !ctx->knob_no_slab && uv->upd_slab[c.wc ? 1 : 0][phase] && uv->upd_slab_lds <= 64 * 1024) {
+      fn = uv->upd_slab[c.wc ? 1 : 0][phase];
+      lds = uv->upd_slab_lds;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, c.st, Q, c.ntiles);
+    if (uv) break;
+  }
+  return MTG_OK;
+}
+
+// run-time-K dimension-in-lane body: persistent 2-wave workgroups, two per CU; the head steps beyond the register tail and the
+// LDS step area go through a lane-coalesced workspace
+static int launch_dimlane_rt(SolveCall& c) {
+  mtg_plan* p = c.p;
+  mtg_context* ctx = p->ctx;
+  const MtgDimlaneRtEntry* rt = c.rt;
+  const int nt = (int)((c.batch + rt->tpw - 1) / rt->tpw);
+  const int grid = std::min(nt, ctx->n_cu * 2);
+  const int kc_max = (p->K + 1) / 2;
+  double* rt_ws = nullptr;
+  if (kc_max - 1 - rt->r_steps - rt->l_steps > 0) {      // head steps beyond the register tail and the LDS step area
+    const size_t need = rt->step_bytes_per_lane * (size_t)(kc_max - 1 - rt->r_steps) * (size_t)grid * 2 * kWave;   // slots j - 1 of all head steps
+    const int rc = workspace(p, need, &rt_ws);
+    if (rc != MTG_OK) return rc;
+  }
+  const int aos = dimlane_input_kind(p, c.L, c.batch);
+  if (rt->launch((void*)c.st, grid, c.P.times, c.P.dfix, c.P.coeffs, c.P.status, c.dts, (int)c.batch, p->K, nt, rt_ws, aos) != 0)
+    return set_err(ctx, MTG_ERR_DEVICE, "run-time-K dimension-in-lane launch set-up failed");
+  LaunchRecord r;
+  r.valid = true; r.params = c.P; r.ntiles = nt; r.grid = grid; r.rt = rt; r.dl_ws = rt_ws; r.dl_aos = aos;
+  p->last.push_back(r);
+  return MTG_OK;
+}
+
+// dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
+static int launch_dimlane(SolveCall& c) {
+  mtg_plan* p = c.p;
+  mtg_context* ctx = p->ctx;
+  const MtgDimlaneEntry* dl = c.dl;
+  const MtgParams& P = c.P;
+  const int nt = (int)((c.batch + dl->tpw - 1) / dl->tpw);
+  const int units = (nt + dl->np - 1) / dl->np;
+  int grid = std::min(units, ctx->n_cu * ctx->knob_dl_grid_per_cu);
+  const int policy = ctx->knob_dl_policy >= 0 ? ctx->knob_dl_policy : 0;
+  double* dl_ws = nullptr;
+  if (dl->ws_per_lane) {
+    // long chains: part of the back-substitution data goes through the workspace; persistent workgroups only (two
+    // 2-wave workgroups per CU, one wave per SIMD), so the workspace stays small enough to live in the Infinity Cache
+    grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
+    const int rc = workspace(p, dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave, &dl_ws);
+    if (rc != MTG_OK) return rc;
+  }
+  const int aos = dimlane_input_kind(p, c.L, c.batch);
+  const int lrc = (P.dfree || P.cost)
+                      ? dl->launch_extra((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, dl_ws, aos,
+                                         P.dfree, P.cost, P.ps_b, P.ps_d, P.ps_c)
+                      : dl->launch((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, policy, dl_ws, aos);
+  if (lrc != 0) return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
+  LaunchRecord r;
+  r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws; r.dl_aos = aos;
+  p->last.push_back(r);
+  return MTG_OK;
+}
+
+// the fused family: slab-output kernel (whole-sector stores) where the shape has one, else static (fused / dimension-split),
+// rolled (run-time K, workspace) or generic (run-time masks) kernels
+static int launch_fused(SolveCall& c) {
+  mtg_plan* p = c.p;
+  mtg_context* ctx = p->ctx;
+  const bool wc = c.wc, cost_only = c.cost_only;
+  const int ntiles = c.ntiles;
+  hipStream_t st = c.st;
+  // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
+  // dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.
+  const MtgStaticEntry* var = pick_static(p, ntiles, c.flags, !wc && !cost_only && !c.pert);
+  const int vm = (p->K + 1) / 2;
+  const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
+  for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
+    const int dc = var ? var->d : std::min(4, p->D - dim0);
+    const int ngroups = var ? p->D / var->d : 1;
+    MtgParams Q = c.P;
+    Q.dim0 = dim0;
+    SolveFn fn;
+    int grid;
+    const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
+    // fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
+    const MtgSlabEntry* slab = nullptr;
+    if (!cost_only && !c.pert) slab = pick_slab(p, var);
+    if (slab && wc && (!slab->extra || ctx->knob_no_slab_extra)) slab = nullptr;
+    if (slab) {
+      // (extra outputs -- cost / d_P -- through the slab-output kernel as well: the older fused kernel's 240-byte pieces
+      // complete most sectors from two store instructions, 80-83 us at B = 125k with rotating buffers)
+      const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
+      SolveFn sfn = wc ? slab->extra : slab->fn[pol];
+      bool& attr_set = wc ? p->slab_extra_attr_set : p->slab_attr_set[pol];
+      const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
+      if (!attr_set) {
+        MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(sfn, dim3(sgrid), dim3(kBlock), slab->lds, st, Q, ntiles);
+      LaunchRecord r;
+      r.valid = true; r.fn = sfn; r.params = Q; r.ntiles = ntiles; r.grid = sgrid; r.gridy = 1; r.lds = slab->lds;
+      p->last.push_back(r);
+      break;
+    }
+    if (var) {
+      Q.ws = p->user_ws;   // unused by the static kernels (measurement builds park timestamps here)
+      // few tiles => every workgroup finishes at about the same time: write-through stores avoid the serial
+      // end-of-kernel L2 write-back; many tiles => plain write-back stores are faster
+      const bool write_through = (long long)ntiles * ngroups <= 4ll * ctx->n_cu;
+      fn = cost_only ? var->fn[4] : var->fn[(wc ? 1 : 0) + (write_through ? 2 : 0)];
+      grid = std::min(ntiles, std::max(1, ctx->n_cu * 8 / ngroups));
+    } else {
+      fn = mtg_pick_generic_solve(p->H, dc, cost_only ? 2 : (wc ? 1 : 0));
+      if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
+      grid = std::min(ntiles, ctx->n_cu * 4);
+    }
+    if (needs_ws) {
+      if (var) grid = std::min(ntiles, std::max(1, ctx->n_cu * ctx->rolled_wg_per_cu / ngroups));
+      const int kc = (p->K + 1) / 2;
+      const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
+      const int rc = workspace(p, (size_t)kc * E * (size_t)grid * ngroups * kBlock * sizeof(double), &Q.ws);
+      if (rc != MTG_OK) return rc;
+      Q.ws_stride = (long long)grid * ngroups * kBlock;
+    }
+    // LDS: two coefficient staging buffers (64 rows x odd number of 16-byte chunks) + two exchange buffers
+    const size_t stage = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
+    const size_t lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
+    hipLaunchKernelGGL(fn, dim3(grid, ngroups), dim3(kBlock), lds, st, Q, ntiles);
+    LaunchRecord r;
+    r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.gridy = ngroups; r.lds = lds;
+    p->last.push_back(r);
+    if (var) break;
+  }
+  return MTG_OK;
+}
+
+// Host-pointer calls: inputs staged into the plan's device area ([times | d_fixed | d_free | coeffs | cost | per-trajectory
+// status | status word]; small calls through ONE page-locked bounce buffer = one H2D DMA, the kernel, one D2H DMA), outputs and
+// the call's OWN status word fetched back synchronously.
+struct HostStaging {
+  bool bounce = false;
+  int64_t n_times = 0, n_fix = 0, n_fre = 0, n_coef = 0, n_ts = 0;
+  int* status_dev = nullptr;        // this call's own status word (a host-pointer call reports its status itself; it must neither
+                                    // collect nor clear the flags earlier asynchronous launches left in the context's word)
+  const double *dt = nullptr, *dfx = nullptr;
+  double *dco = nullptr, *dfr = nullptr, *dcs = nullptr;
+  int32_t* dts = nullptr;
+};
+
+static int stage_host_inputs(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                             const double* d_free, bool want_cost, bool want_ts, bool update_only, hipStream_t st, HostStaging& h) {
+  mtg_context* ctx = p->ctx;
+  constexpr size_t kBounceLimit = 1u << 20;
+  h.n_times = span(batch, L->times_stride_b, p->K, L->times_stride_k, 1, 0);
+  h.n_fix = p->n_fixed ? span(batch, L->fixed_stride_b, p->D, L->fixed_stride_d, p->n_fixed, L->fixed_stride_c) : 0;
+  h.n_fre = p->n_free ? span(batch, L->free_stride_b, p->D, L->free_stride_d, p->n_free, L->free_stride_c) : 0;
+  h.n_coef = batch * p->K * p->D * p->N;
+  h.n_ts = want_ts ? (batch + 1) / 2 : 0;   // doubles that hold `batch` int32
+  const size_t need = (size_t)(h.n_times + h.n_fix + h.n_fre + h.n_coef + batch + h.n_ts + 1) * sizeof(double);
+  int rc = ensure_buffer(ctx, &p->stage, &p->stage_bytes, need);
+  if (rc != MTG_OK) return rc;
+  double* s = p->stage;
+  double* s_t = s; s += h.n_times;
+  double* s_f = s; s += h.n_fix;
+  double* s_p = s; s += h.n_fre;
+  double* s_c = s; s += h.n_coef;
+  double* s_j = s; s += batch;
+  if (want_ts) h.dts = reinterpret_cast<int32_t*>(s);
+  s += h.n_ts;
+  h.status_dev = reinterpret_cast<int*>(s);
+  const size_t n_in = (size_t)(h.n_times + h.n_fix + (update_only ? h.n_fre : 0));
+  h.bounce = need <= kBounceLimit;
+  if (h.bounce) {
+    if (ctx->h_bounce_bytes < need) {
+      if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
+      ctx->h_bounce = nullptr;
+      ctx->h_bounce_bytes = 0;
+      MTG_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_bounce, kBounceLimit, hipHostMallocDefault));
+      ctx->h_bounce_bytes = kBounceLimit;
+    }
+    std::memcpy(ctx->h_bounce, times, h.n_times * sizeof(double));
+    if (h.n_fix) std::memcpy(ctx->h_bounce + h.n_times, d_fixed, h.n_fix * sizeof(double));
+    if (update_only && h.n_fre) std::memcpy(ctx->h_bounce + h.n_times + h.n_fix, d_free, h.n_fre * sizeof(double));
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, ctx->h_bounce, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, times, h.n_times * sizeof(double), hipMemcpyHostToDevice, st));
+    if (h.n_fix) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_f, d_fixed, h.n_fix * sizeof(double), hipMemcpyHostToDevice, st));
+    if (update_only && h.n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_p, d_free, h.n_fre * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  h.dt = s_t; h.dfx = s_f; h.dco = s_c;
+  h.dfr = (d_free && h.n_fre) ? s_p : nullptr;
+  h.dcs = want_cost ? s_j : nullptr;
+  return MTG_OK;
+}
+
+static int fetch_host_outputs(mtg_plan* p, int64_t batch, double* coeffs, double* d_free, double* cost, int32_t* traj_status,
+                              bool update_only, hipStream_t st, const HostStaging& h, int* host_status) {
+  mtg_context* ctx = p->ctx;
+  const int64_t n_times = h.n_times, n_fix = h.n_fix, n_fre = h.n_fre, n_coef = h.n_coef, n_ts = h.n_ts;
+  if (h.bounce) {
+    // [d_free | coeffs | cost | per-trajectory status | status word] sit back to back in the device staging area: one D2H DMA
+    double* s_p = p->stage + n_times + n_fix;
+    const size_t n_out = (size_t)(n_fre + n_coef + batch + n_ts + 1);
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounce, s_p, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::memcpy(host_status, ctx->h_bounce + n_fre + n_coef + batch + n_ts, sizeof(int));
+    if (!update_only && d_free && n_fre) std::memcpy(d_free, ctx->h_bounce, n_fre * sizeof(double));
+    std::memcpy(coeffs, ctx->h_bounce + n_fre, n_coef * sizeof(double));
+    if (cost) std::memcpy(cost, ctx->h_bounce + n_fre + n_coef, batch * sizeof(double));
+    if (traj_status) std::memcpy(traj_status, ctx->h_bounce + n_fre + n_coef + batch, batch * sizeof(int32_t));
+  } else {
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(coeffs, h.dco, n_coef * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, h.dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, h.dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (traj_status) MTG_HIP_TRY(ctx, hipMemcpyAsync(traj_status, h.dts, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // (h_status is the context's pinned word; the context lock is held, and mtg_context_sync overwrites it under the same lock)
+    MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, h.status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *host_status = *ctx->h_status;
+  }
+  return MTG_OK;
+}
+
+// latency path of single-trajectory host callers: the lane code's host build on the calling thread (mtg_host.cpp); no device
+// work, no lock
+static int solve_on_host_backend(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                                 double* coeffs, double* d_free, double* cost, bool update_only, int32_t* traj_status) {
+  MtgParams P;
+  fill_common(p, P, batch, L);
+  P.times = times; P.dfix = d_fixed; P.coeffs = coeffs; P.dfree = p->n_free ? d_free : nullptr; P.cost = cost;
+  int st_word = 0;
+  P.status = &st_word;
+  P.tstatus = traj_status;
+  P.vmask = p->mask.data(); P.offF = p->offF.data(); P.offP = p->offP.data();
+  if (traj_status) std::memset(traj_status, 0, (size_t)batch * sizeof(int32_t));
+  if (mtg_host_run(P, p->H, update_only) != 0) return MTG_ERR_UNSUPPORTED;
+  if (st_word & MTG_FLAG_BAD_TIME) return MTG_ERR_BAD_SEGMENT_TIME;
+  if (st_word & MTG_FLAG_SINGULAR) return MTG_ERR_SINGULAR;
+  return MTG_OK;
+}
+
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only,
                       int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr,
@@ -594,279 +913,56 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   if (p->n_fixed > 0 && !d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_fixed is null");
   if (update_only && p->n_free > 0 && !d_free) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "d_free is null");
   if (batch == 0) return MTG_OK;
-  if ((flags & MTG_FLAG_HOST_POINTERS) && (flags & MTG_FLAG_HOST_BACKEND) && batch <= MTG_HOST_BACKEND_MAX_BATCH) {
-    // latency path: the lane code's host build on the calling thread (mtg_host.cpp); no device work, no lock
-    MtgParams P;
-    fill_common(p, P, batch, L);
-    P.times = times; P.dfix = d_fixed; P.coeffs = coeffs; P.dfree = p->n_free ? d_free : nullptr; P.cost = cost;
-    int st_word = 0;
-    P.status = &st_word;
-    P.tstatus = traj_status;
-    P.vmask = p->mask.data(); P.offF = p->offF.data(); P.offP = p->offP.data();
-    if (traj_status) std::memset(traj_status, 0, (size_t)batch * sizeof(int32_t));
-    if (mtg_host_run(P, p->H, update_only) != 0) return MTG_ERR_UNSUPPORTED;
-    if (st_word & MTG_FLAG_BAD_TIME) return MTG_ERR_BAD_SEGMENT_TIME;
-    if (st_word & MTG_FLAG_SINGULAR) return MTG_ERR_SINGULAR;
-    return MTG_OK;
-  }
+  const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
+  if (host && (flags & MTG_FLAG_HOST_BACKEND) && batch <= MTG_HOST_BACKEND_MAX_BATCH)
+    return solve_on_host_backend(p, batch, L, times, d_fixed, coeffs, d_free, cost, update_only, traj_status);
   std::lock_guard<std::mutex> lock(ctx->mu);
   MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = on_stream ? on_stream : ctx->stream;   // on_stream: a side stream of a concurrent mixed request
 
-  const int64_t n_times = span(batch, L->times_stride_b, p->K, L->times_stride_k, 1, 0);
-  const int64_t n_fix = p->n_fixed ? span(batch, L->fixed_stride_b, p->D, L->fixed_stride_d, p->n_fixed, L->fixed_stride_c) : 0;
-  const int64_t n_fre = p->n_free ? span(batch, L->free_stride_b, p->D, L->free_stride_d, p->n_free, L->free_stride_c) : 0;
-  const int64_t n_coef = batch * p->K * p->D * p->N;
-
+  SolveCall c;
+  c.p = p; c.batch = batch; c.L = L; c.flags = flags; c.cost_only = cost_only; c.pert = pert;
+  c.st = on_stream ? on_stream : ctx->stream;   // on_stream: a side stream of a concurrent mixed request
+  c.dts = traj_status;
   const double* dt = times; const double* dfx = d_fixed; double* dco = coeffs; double* dfr = d_free; double* dcs = cost;
-  const bool host = (flags & MTG_FLAG_HOST_POINTERS) != 0;
-  bool bounce = false;
-  int host_status = 0;
-  int* host_status_dev = nullptr;           // host-pointer calls: this call's own status word (in the staging area)
-  int32_t* dts = traj_status;               // per-trajectory status on the device
-  const int64_t n_ts = traj_status ? (batch + 1) / 2 : 0;   // doubles that hold `batch` int32
-  constexpr size_t kBounceLimit = 1u << 20;
+  HostStaging h;
   if (host) {
-    // (+ 1: the call's OWN status word.  A host-pointer call reports its status itself; it must neither collect nor clear
-    // the flags that earlier asynchronous device-pointer / graph launches left in the context's word -- those belong to
-    // the next mtg_context_sync.)
-    const size_t need = (size_t)(n_times + n_fix + n_fre + n_coef + batch + n_ts + 1) * sizeof(double);
-    int rc = ensure_buffer(ctx, &p->stage, &p->stage_bytes, need);
+    const int rc = stage_host_inputs(p, batch, L, times, d_fixed, d_free, cost != nullptr, traj_status != nullptr, update_only, c.st, h);
     if (rc != MTG_OK) return rc;
-    double* s = p->stage;
-    double* s_t = s; s += n_times;
-    double* s_f = s; s += n_fix;
-    double* s_p = s; s += n_fre;
-    double* s_c = s; s += n_coef;
-    double* s_j = s; s += batch;
-    if (traj_status) dts = reinterpret_cast<int32_t*>(s);
-    s += n_ts;
-    host_status_dev = reinterpret_cast<int*>(s);
-    // small calls go through the context's page-locked bounce buffer: [times | d_fixed | d_free] is one H2D DMA
-    const size_t n_in = (size_t)(n_times + n_fix + (update_only ? n_fre : 0));
-    bounce = need <= kBounceLimit;
-    if (bounce) {
-      if (ctx->h_bounce_bytes < need) {
-        if (ctx->h_bounce) hipHostFree(ctx->h_bounce);
-        ctx->h_bounce = nullptr;
-        ctx->h_bounce_bytes = 0;
-        MTG_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_bounce, kBounceLimit, hipHostMallocDefault));
-        ctx->h_bounce_bytes = kBounceLimit;
-      }
-      std::memcpy(ctx->h_bounce, times, n_times * sizeof(double));
-      if (n_fix) std::memcpy(ctx->h_bounce + n_times, d_fixed, n_fix * sizeof(double));
-      if (update_only && n_fre) std::memcpy(ctx->h_bounce + n_times + n_fix, d_free, n_fre * sizeof(double));
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, ctx->h_bounce, n_in * sizeof(double), hipMemcpyHostToDevice, st));
-    } else {
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(s_t, times, n_times * sizeof(double), hipMemcpyHostToDevice, st));
-      if (n_fix) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_f, d_fixed, n_fix * sizeof(double), hipMemcpyHostToDevice, st));
-      if (update_only && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(s_p, d_free, n_fre * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    dt = s_t; dfx = s_f; dco = s_c;
-    dfr = (d_free && n_fre) ? s_p : nullptr;
-    dcs = cost ? s_j : nullptr;
+    dt = h.dt; dfx = h.dfx; dco = h.dco; dfr = h.dfr; dcs = h.dcs; c.dts = h.dts;
   }
-  if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, (pert ? (size_t)(p->K + 1) : (size_t)1) * batch * sizeof(double), st));
-  if (dts) MTG_HIP_TRY(ctx, hipMemsetAsync(dts, 0, batch * sizeof(int32_t), st));
-  if (host_status_dev) MTG_HIP_TRY(ctx, hipMemsetAsync(host_status_dev, 0, sizeof(double), st));
+  if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, (pert ? (size_t)(p->K + 1) : (size_t)1) * batch * sizeof(double), c.st));
+  if (c.dts) MTG_HIP_TRY(ctx, hipMemsetAsync(c.dts, 0, batch * sizeof(int32_t), c.st));
+  if (h.status_dev) MTG_HIP_TRY(ctx, hipMemsetAsync(h.status_dev, 0, sizeof(double), c.st));
 
-  MtgParams P;
-  fill_common(p, P, batch, L);
-  if (host_status_dev) P.status = host_status_dev;
-  P.times = dt; P.dfix = dfx; P.coeffs = dco; P.dfree = (p->n_free ? dfr : nullptr); P.cost = dcs;
-  P.tstatus = dts;
-  const bool wc = dcs != nullptr || (!update_only && P.dfree != nullptr);
-  int ntiles = (int)((batch + kWave - 1) / kWave);
+  fill_common(p, c.P, batch, L);
+  if (h.status_dev) c.P.status = h.status_dev;
+  c.P.times = dt; c.P.dfix = dfx; c.P.coeffs = dco; c.P.dfree = (p->n_free ? dfr : nullptr); c.P.cost = dcs;
+  c.P.tstatus = c.dts;
+  c.wc = dcs != nullptr || (!update_only && c.P.dfree != nullptr);
+  c.ntiles = (int)((batch + kWave - 1) / kWave);
   if (pert) {   // cost-only launch over (K + 1) x batch virtual problems; cost = [(K + 1)][batch]
-    P.pert_on = 1; P.pert_seg = -1; P.pert_tpv = ntiles;
-    P.pert_h = pert->h; P.pert_corr = pert->h / (p->K - 1.0); P.pert_lo = pert->lower_bound;
-    ntiles *= p->K + 1;
+    c.P.pert_on = 1; c.P.pert_seg = -1; c.P.pert_tpv = c.ntiles;
+    c.P.pert_h = pert->h; c.P.pert_corr = pert->h / (p->K - 1.0); c.P.pert_lo = pert->lower_bound;
+    c.ntiles *= p->K + 1;
   }
   p->last.clear();
 
-  if (update_only) {
-    // compile-time-mask ("rolled") update kernel when the plan has one (all D dimensions in one launch), else generic
-    const MtgStaticEntry* uv = (flags & MTG_FLAG_GENERIC_KERNEL) ? nullptr
-                               : mtg_find_static(p->H, p->D, p->K, p->deriv, p->mask.data(), true);
-    for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
-      const int dc = uv ? p->D : std::min(4, p->D - dim0);
-      UpdateFn fn = uv ? uv->upd[wc ? 1 : 0] : mtg_pick_generic_update(p->H, dc, wc);
-      if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no update kernel");
-      MtgParams Q = P;
-      Q.dim0 = dim0;
-      const int grid = std::min(ntiles, ctx->n_cu * 16);
-      size_t lds = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
-      // whole-sector output (mtg_update_slab_kernel) for the rolled form; MTG_NO_SLAB keeps the per-segment staging
-      const int phase = ((size_t)p->K * p->D * p->N * 8) % 64 != 0 ? 1 : 0;
-      if (uv && !ctx->knob_no_slab && uv->upd_slab[wc ? 1 : 0][phase] && uv->upd_slab_lds <= 64 * 1024) {
-        fn = uv->upd_slab[wc ? 1 : 0][phase];
-        lds = uv->upd_slab_lds;
-      }
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, st, Q, ntiles);
-      if (uv) break;
-    }
-  } else if (const MtgDimlaneRtEntry* rt = pick_dimlane_rt(p, batch, L, P, flags, cost_only)) {
-    // run-time-K dimension-in-lane body: persistent 2-wave workgroups, two per CU; the head steps beyond the register tail
-    // and the LDS step area go through a lane-coalesced workspace
-    const int nt = (int)((batch + rt->tpw - 1) / rt->tpw);
-    const int grid = std::min(nt, ctx->n_cu * 2);
-    const int kc_max = (p->K + 1) / 2;
-    double* rt_ws = nullptr;
-    if (kc_max - 1 - rt->r_steps - rt->l_steps > 0) {      // head steps beyond the register tail and the LDS step area
-      const size_t need = rt->step_bytes_per_lane * (size_t)(kc_max - 1 - rt->r_steps) * (size_t)grid * 2 * kWave;   // slots j - 1 of all head steps
-      if (p->user_ws) {
-        if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
-        rt_ws = p->user_ws;
-      } else {
-        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
-        if (rc != MTG_OK) return rc;
-        rt_ws = p->ws;
-      }
-    }
-    const int aos = dimlane_input_kind(p, L, batch);
-    if (rt->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, p->K, nt, rt_ws, aos) != 0)
-      return set_err(ctx, MTG_ERR_DEVICE, "run-time-K dimension-in-lane launch set-up failed");
-    LaunchRecord r;
-    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.rt = rt; r.dl_ws = rt_ws; r.dl_aos = aos;
-    p->last.push_back(r);
-  } else if (const MtgDimlaneEntry* dl = dimlane_twin(p, pick_dimlane(p, batch, L, P, flags, cost_only), batch)) {
-    // dimension-in-lane form (mtg_dimlane.h): all dimensions of a trajectory in one wave, whole-sector coefficient stores
-    const int nt = (int)((batch + dl->tpw - 1) / dl->tpw);
-    const int units = (nt + dl->np - 1) / dl->np;
-    int grid = std::min(units, ctx->n_cu * ctx->knob_dl_grid_per_cu);
-    const int policy = ctx->knob_dl_policy >= 0 ? ctx->knob_dl_policy : 0;
-    double* dl_ws = nullptr;
-    if (dl->ws_per_lane) {
-      // long chains: part of the back-substitution data goes through the workspace; persistent workgroups only (two
-      // 2-wave workgroups per CU, one wave per SIMD), so the workspace stays small enough to live in the Infinity Cache
-      grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
-      const size_t need = dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave;
-      if (p->user_ws) {
-        if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
-        dl_ws = p->user_ws;
-      } else {
-        int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
-        if (rc != MTG_OK) return rc;
-        dl_ws = p->ws;
-      }
-    }
-    const int aos = dimlane_input_kind(p, L, batch);
-    const int lrc = (P.dfree || P.cost)
-                        ? dl->launch_extra((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, dl_ws, aos, P.dfree, P.cost,
-                                           P.ps_b, P.ps_d, P.ps_c)
-                        : dl->launch((void*)st, grid, dt, dfx, dco, P.status, dts, (int)batch, nt, policy, dl_ws, aos);
-    if (lrc != 0) return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
-    LaunchRecord r;
-    r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws; r.dl_aos = aos;
-    p->last.push_back(r);
-  } else {
-    // variant choice: specialised kernels when the plan matches one; with few tiles (small batch) the
-    // dimension-split form puts Dtot/D times as many (lighter, 2-per-SIMD) waves on the machine.
-    const MtgStaticEntry* var = pick_static(p, ntiles, flags, !wc && !cost_only && !pert);
-    const int vm = (p->K + 1) / 2;
-    const int fm = p->H - __builtin_popcount((unsigned)p->mask[vm]);
-    for (int dim0 = 0; dim0 < p->D; dim0 += 4) {
-      const int dc = var ? var->d : std::min(4, p->D - dim0);
-      const int ngroups = var ? p->D / var->d : 1;
-      MtgParams Q = P;
-      Q.dim0 = dim0;
-      SolveFn fn;
-      int grid;
-      const bool needs_ws = !var || var->k < 0;   // generic and rolled kernels stream (G, g) through the workspace
-      // fused static form, coefficient output only: the slab-output kernel (whole-sector stores, mtg_solve_slab_kernel)
-      const MtgSlabEntry* slab = nullptr;
-      if (!cost_only && !pert) slab = pick_slab(p, var);
-      if (slab && wc && (!slab->extra || ctx->knob_no_slab_extra)) slab = nullptr;
-      if (slab && wc) {
-        // extra outputs (cost / d_P) through the slab-output kernel as well (round 3; the older fused kernel's 240-byte
-        // pieces complete most sectors from two store instructions: 80-83 us at B = 125k with rotating buffers)
-        const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);
-        if (!p->slab_extra_attr_set) {
-          MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->extra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
-          p->slab_extra_attr_set = true;
-        }
-        hipLaunchKernelGGL(slab->extra, dim3(sgrid), dim3(kBlock), slab->lds, st, Q, ntiles);
-        LaunchRecord r;
-        r.valid = true; r.fn = slab->extra; r.params = Q; r.ntiles = ntiles; r.grid = sgrid; r.gridy = 1; r.lds = slab->lds;
-        p->last.push_back(r);
-        break;
-      }
-      if (slab) {
-        const int pol = ctx->knob_slab_policy >= 0 ? ctx->knob_slab_policy : 1;
-        const int sgrid = balanced_grid(ctx, ntiles, ctx->n_cu * 2);   // 63.5 KB of LDS per workgroup: two per CU, one wave per SIMD
-        if (!p->slab_attr_set[pol]) {
-          MTG_HIP_TRY(ctx, hipFuncSetAttribute((const void*)slab->fn[pol], hipFuncAttributeMaxDynamicSharedMemorySize, (int)slab->lds));
-          p->slab_attr_set[pol] = true;
-        }
-        hipLaunchKernelGGL(slab->fn[pol], dim3(sgrid), dim3(kBlock), slab->lds, st, Q, ntiles);
-        LaunchRecord r;
-        r.valid = true; r.fn = slab->fn[pol]; r.params = Q; r.ntiles = ntiles; r.grid = sgrid; r.gridy = 1; r.lds = slab->lds;
-        p->last.push_back(r);
-        break;
-      }
-      if (var) {
-        Q.ws = p->user_ws;   // unused by the static kernels (measurement builds park timestamps here)
-        // few tiles => every workgroup finishes at about the same time: write-through stores avoid the serial
-        // end-of-kernel L2 write-back; many tiles => plain write-back stores are faster
-        const bool write_through = (long long)ntiles * ngroups <= 4ll * ctx->n_cu;
-        fn = cost_only ? var->fn[4] : var->fn[(wc ? 1 : 0) + (write_through ? 2 : 0)];
-        grid = std::min(ntiles, std::max(1, ctx->n_cu * 8 / ngroups));
-      } else {
-        fn = mtg_pick_generic_solve(p->H, dc, cost_only ? 2 : (wc ? 1 : 0));
-        if (!fn) return set_err(ctx, MTG_ERR_UNSUPPORTED, "no generic kernel");
-        grid = std::min(ntiles, ctx->n_cu * 4);
-      }
-      if (needs_ws) {
-        if (var) grid = std::min(ntiles, std::max(1, ctx->n_cu * ctx->rolled_wg_per_cu / ngroups));
-        const int kc = (p->K + 1) / 2;
-        const size_t E = (size_t)p->H * p->H + (size_t)dc * p->H;
-        const size_t need = (size_t)kc * E * (size_t)grid * ngroups * kBlock * sizeof(double);
-        if (p->user_ws) {
-          if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
-          Q.ws = p->user_ws;
-        } else {
-          int rc = ensure_buffer(ctx, &p->ws, &p->ws_bytes, need);
-          if (rc != MTG_OK) return rc;
-          Q.ws = p->ws;
-        }
-        Q.ws_stride = (long long)grid * ngroups * kBlock;
-      }
-      // LDS: two coefficient staging buffers (64 rows x odd number of 16-byte chunks) + two exchange buffers
-      const size_t stage = (size_t)64 * ((size_t)(dc * p->N / 2) | 1) * 2 * sizeof(double);
-      const size_t lds = 2 * stage + (size_t)2 * (fm * (fm + 1) / 2 + dc * fm) * kWave * sizeof(double);
-      hipLaunchKernelGGL(fn, dim3(grid, ngroups), dim3(kBlock), lds, st, Q, ntiles);
-      LaunchRecord r;
-      r.valid = true; r.fn = fn; r.params = Q; r.ntiles = ntiles; r.grid = grid; r.gridy = ngroups; r.lds = lds;
-      p->last.push_back(r);
-      if (var) break;
-    }
+  int rc = MTG_OK;
+  switch (pick_form(c, update_only)) {
+    case SolveForm::kUpdate: rc = launch_update(c); break;
+    case SolveForm::kDimlaneRt: rc = launch_dimlane_rt(c); break;
+    case SolveForm::kDimlane: rc = launch_dimlane(c); break;
+    case SolveForm::kFused: rc = launch_fused(c); break;
   }
+  if (rc != MTG_OK) return rc;
   MTG_HIP_TRY(ctx, hipGetLastError());
 
   if (host) {
     // A host-pointer call synchronises anyway: the status word (and the per-trajectory status) come back with the
     // results, and the call itself returns MTG_ERR_BAD_SEGMENT_TIME / MTG_ERR_SINGULAR -- no mtg_context_sync needed.
-    if (bounce) {
-      // [d_free | coeffs | cost | per-trajectory status | status word] sit back to back in the device staging area: one D2H DMA
-      double* s_p = p->stage + n_times + n_fix;
-      const size_t n_out = (size_t)(n_fre + n_coef + batch + n_ts + 1);
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounce, s_p, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
-      std::memcpy(&host_status, ctx->h_bounce + n_fre + n_coef + batch + n_ts, sizeof(int));
-      if (!update_only && d_free && n_fre) std::memcpy(d_free, ctx->h_bounce, n_fre * sizeof(double));
-      std::memcpy(coeffs, ctx->h_bounce + n_fre, n_coef * sizeof(double));
-      if (cost) std::memcpy(cost, ctx->h_bounce + n_fre + n_coef, batch * sizeof(double));
-      if (traj_status) std::memcpy(traj_status, ctx->h_bounce + n_fre + n_coef + batch, batch * sizeof(int32_t));
-    } else {
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(coeffs, dco, n_coef * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (!update_only && d_free && n_fre) MTG_HIP_TRY(ctx, hipMemcpyAsync(d_free, dfr, n_fre * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (cost) MTG_HIP_TRY(ctx, hipMemcpyAsync(cost, dcs, batch * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (traj_status) MTG_HIP_TRY(ctx, hipMemcpyAsync(traj_status, dts, batch * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      // (h_status is the context's pinned word; the context lock is held, and mtg_context_sync overwrites it under the same lock)
-      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, host_status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-      MTG_HIP_TRY(ctx, hipStreamSynchronize(st));
-      host_status = *ctx->h_status;
-    }
+    int host_status = 0;
+    rc = fetch_host_outputs(p, batch, coeffs, d_free, cost, traj_status, update_only, c.st, h, &host_status);
+    if (rc != MTG_OK) return rc;
     return status_code(ctx, host_status);
   }
   return MTG_OK;

@@ -377,6 +377,7 @@ __global__ void mtg_sample_valid_kernel(SampleParams P) {
 
 // C ABI (declared in include/mtg_hip.h).  The context type is opaque here: only its stream / device are needed.
 extern "C" int mtg_context_stream_device(mtg_context* ctx, void** stream, int* device);
+extern "C" bool mtg_context_sample_generic(const mtg_context* ctx);   // measurement knob "sample_generic" (mtg_hip_lab.h)
 
 extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments, int32_t dimension, int64_t batch,
                                 const double* coeffs, const double* times, int64_t times_stride_b, int64_t times_stride_k,
@@ -412,7 +413,7 @@ extern "C" int mtg_sample_range(mtg_context* ctx, int32_t n_coeffs, int32_t n_se
   }
   // compile-time shapes (K <= 16): the reference's N = 10 / 12 / 8 in 3-D, N = 10 in 1-D (yaw) and 4-D (x, y, z, yaw)
   SampleFn fast = nullptr;
-  if (n_segments <= 16 && total >= 64 && !getenv("MTG_SAMPLE_GENERIC")) {
+  if (n_segments <= 16 && total >= 64 && !mtg_context_sample_generic(ctx)) {
     if (n_coeffs == 10 && dimension == 3) fast = mtg_pick_sample_ct<10, 3>(n_derivatives, n_segments);
     else if (n_coeffs == 12 && dimension == 3) fast = mtg_pick_sample_ct<12, 3>(n_derivatives, n_segments);
     else if (n_coeffs == 8 && dimension == 3) fast = mtg_pick_sample_ct<8, 3>(n_derivatives, n_segments);

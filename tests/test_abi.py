@@ -9,9 +9,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mtg_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mtg_[a-z_0-9]+)\s*\(", txt)))
+    """The drop-in boundary (mtg_hip.h) and the measurement-knob header next to it (mtg_hip_lab.h)."""
+    syms = set()
+    for name in ("mtg_hip.h", "mtg_hip_lab.h"):
+        txt = open(os.path.join(ROOT, "include", name)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(mtg_[a-z_0-9]+)\s*\(", txt))
+    return sorted(syms)
+
+
+def test_the_library_never_reads_the_environment():
+    """Round-3 review: 17 getenv knobs lived in the product library.  They are per-context options now
+    (mtg_context_set_option, include/mtg_hip_lab.h); only the Python plumbing forwards MTG_* variables."""
+    csrc = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    from mav_trajectory_generation_amd import _lib
+    lib = _lib.load()
+    assert lib.mtg_context_set_option(None, b"no_slab", 1) == -1
 
 
 def test_header_declares_expected_entry_points():
