@@ -110,6 +110,7 @@ ENV_OPTIONS = {
     "MTG_DL_GRID_PER_CU": ("dl_grid_per_cu", int), "MTG_DL_ANY_SCHED": ("dl_any_sched_rr", lambda e: int(e == "rr")),
     "MTG_SLAB_POLICY": ("slab_policy", lambda e: 1 if int(e) else 0), "MTG_ROLLED_WG_PER_CU": ("rolled_wg_per_cu", int),
     "MTG_DL_MAX_UNITS": ("dl_max_units", int), "MTG_SAMPLE_GENERIC": ("sample_generic", _flag),
+    "MTG_DL_STAGGER": ("dl_stagger", int),
 }
 
 FLAG_HOST_POINTERS = 1

@@ -128,6 +128,14 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   static_assert(DL >= 1 && DL <= 4, "1..4 dimensions per trajectory");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   constexpr int TPW = kWave / DL;
+  // Phase stagger (measurement knob "dl_stagger", bits 8.. of the layout word; 0 = off): every second workgroup starts
+  // `stagger` x 2048 cycles late, so that half of the chip is in its (memory-silent) forward phase while the other half streams
+  // its coefficients out -- persistent one-wave-per-SIMD workgroups of equal work otherwise stay phase-locked
+  const int stagger = aos >> 8;
+  aos &= 1;
+  if (stagger > 0 && (blockIdx.x & 1)) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;      // wave-uniform
   const int pair = w >> 1, dir = w & 1;
