@@ -21,8 +21,9 @@
  *   "rolled_wg_per_cu" >= 1 (default 4)            persistent workgroups per CU of the rolled kernels
  *   "dl_max_units"     -1 default, >= 0            upper limit of the dimension-in-lane default range (x CUs)
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
- *   "dl_stagger"       >= 0 (default 0)            every second workgroup of a single dimension-in-lane launch starts
- *                                                  value x 2048 shader cycles late (phase-stagger experiment)
+ *   "dl_stagger"       -1 default, >= 0            every second workgroup of a single dimension-in-lane launch starts
+ *                                                  value x 2048 shader cycles late (default: 8 for the workspace hybrids in
+ *                                                  launches of three or more rounds, else 0)
  * Returns MTG_OK, or MTG_ERR_INVALID_ARGUMENT for an unknown name.                                                  */
 #ifndef MTG_HIP_LAB_H_
 #define MTG_HIP_LAB_H_

@@ -126,7 +126,8 @@ struct mtg_context {
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
-  int knob_dl_stagger = 0;           // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
+  int knob_dl_stagger = -1;          // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
+                                     // (-1: the default -- kDlStaggerWorkspace for the workspace hybrids in multi-round launches, else 0)
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
@@ -292,7 +293,7 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   else if (n == "rolled_wg_per_cu") ctx->rolled_wg_per_cu = std::max(1, value);
   else if (n == "dl_max_units") ctx->dl_max_units_per_cu = value;
   else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
-  else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(0, std::min(value, 1 << 20));
+  else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(-1, std::min(value, 1 << 20));
   else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
   return MTG_OK;
 }
@@ -711,7 +712,14 @@ static int launch_dimlane(SolveCall& c) {
     const int rc = workspace(p, dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave, &dl_ws);
     if (rc != MTG_OK) return rc;
   }
-  const int aos = dimlane_input_kind(p, c.L, c.batch) | (ctx->knob_dl_stagger << 8);
+  // Phase stagger (mtg_dimlane.h): the long-chain hybrids whose head steps go through the global workspace run 5-11 % faster
+  // when every second persistent workgroup starts ~7 us late (profiles/r04a_stagger_sweep.jsonl: N = 12 / K = 16 210 -> 186 us,
+  // N = 10 / K = 32 291 -> 267 us, N = 12 / K = 32 520 -> 500 us at 100k; the all-register variants lose 0-15 %) -- where the
+  // launch runs several rounds, so that the delay is small against the whole
+  constexpr int kDlStaggerWorkspace = 8;
+  const int stagger = ctx->knob_dl_stagger >= 0 ? ctx->knob_dl_stagger
+                                                : ((dl->ws_per_lane && units >= 3 * grid) ? kDlStaggerWorkspace : 0);
+  const int aos = dimlane_input_kind(p, c.L, c.batch) | (stagger << 8);
   const int lrc = (P.dfree || P.cost)
                       ? dl->launch_extra((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, dl_ws, aos,
                                          P.dfree, P.cost, P.ps_b, P.ps_d, P.ps_c)

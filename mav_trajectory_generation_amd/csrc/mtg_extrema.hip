@@ -8,9 +8,9 @@
 // The per-lane algorithm (real-root isolation by a compile-time derivative chain instead of the reference's
 // Jenkins-Traub) lives in mtg_extrema_lane.h.  Mapping: one lane per (trajectory, segment); blockIdx.y selects the
 // derivative (velocity / acceleration are searched in one launch for the scaling path).  The kernels are
-// FP64-latency bound, not HBM bound: ~10^4 dependent FMAs per lane against 240 B of coefficients read.  The root
-// list of each lane lives in LDS ([slot][lane] layout: lanes in lock-step hit distinct banks); everything else is
-// in registers with compile-time indices.
+// FP64-issue bound, not HBM bound: ~10^4 FMAs per lane against 240 B of coefficients read (round 4: two independent chains
+// at a time and lane-aligned refinement rounds, mtg_extrema_lane.h).  The two root buffers of each lane live in LDS ([slot][lane]
+// layout: lanes in lock-step hit distinct banks); everything else is in registers with compile-time indices.
 #include <hip/hip_runtime.h>
 
 #include "../../include/mtg_hip.h"
@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 128;   // two root buffers of L - 1 doubles per lane in LDS: 128 x 2 x 21 x 8 B = 43 KB at most
 
 struct ExtremaParams {
   const double* coeffs;   // [B][K][D][N]
@@ -84,16 +84,37 @@ struct ScaleParams {
   double* coeffs;
   double* times;
   long long ts_b, ts_k;
-  const double* traj_out;   // [2][B][4]: slot 0 velocity, slot 1 acceleration
+  double* seg_out;          // [2][B][K][4]
+  double* traj_out;         // [2][B][4]: slot 0 velocity, slot 1 acceleration
   double* scaling;          // [B] or null: product of the applied factors
   int* within;              // [B] or null
   long long B;
   int N, K, D;
   double v_max, a_max;
-  int first;
+  int max_iterations;
 };
 
-// One iteration body of scaleSegmentTimesToMeetConstraints (trajectory.cpp:398-425): lane per (b, segment, dim).
+// The WHOLE loop of scaleSegmentTimesToMeetConstraints (trajectory.cpp:392-426) for one trajectory from ONE extrema search:
+// stretching every segment time by s is a re-parametrisation p(t / s), so the next round's maxima are known exactly --
+// velocity / s, acceleration / s^2, at s times the old instant -- and the reference's re-computation (:397) only reproduces
+// them up to round-off.  total: product of the factors applied; total_chk: the factor in force at the LAST check (what the
+// tables show afterwards: "the maxima seen by the last round's check").  Round 3 ran the root search again in every round.
+struct ScaleLoop { double total, total_chk; bool within; };
+__device__ __forceinline__ ScaleLoop mtg_scale_loop(double v_act, double a_act, double v_max, double a_max, int max_iterations) {
+  ScaleLoop r{1.0, 1.0, false};
+  for (int it = 0; it < max_iterations; ++it) {
+    r.total_chk = r.total;
+    const double s = mtgx::violation_scaling(v_act, a_act, v_max, a_max, r.within);
+    if (r.within) break;   // the reference breaks out before scaling (:405-407)
+    r.total *= s;
+    v_act /= s;
+    a_act /= s * s;
+  }
+  return r;
+}
+
+// lane per (b, segment, dim): Polynomial::scalePolynomialInTime (polynomial.cpp:199-205) + Segment::setTime with the factor
+// of the whole loop.  Reads the UNSCALED trajectory maxima; mtg_scale_finish_kernel (launched after it) updates the tables.
 __global__ void mtg_scale_kernel(ScaleParams P) {
   const long long total = P.B * P.K * P.D;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,30 +123,43 @@ __global__ void mtg_scale_kernel(ScaleParams P) {
   const int d = (int)(idx - bk * P.D);
   const long long b = bk / P.K;
   const int seg = (int)(bk - b * P.K);
-  const double v_act = P.traj_out[b * 4 + 3];
-  const double a_act = P.traj_out[(P.B + b) * 4 + 3];
-  bool within;
-  const double s = mtgx::violation_scaling(v_act, a_act, P.v_max, P.a_max, within);
-  if (seg == 0 && d == 0) {
-    if (P.within) P.within[b] = within ? 1 : 0;
-    if (P.scaling) P.scaling[b] = (P.first ? 1.0 : P.scaling[b]) * (within ? 1.0 : s);
-  }
-  if (within) return;   // the reference breaks out before scaling (:405-407)
-  const double inv = 1.0 / s;
+  const ScaleLoop r = mtg_scale_loop(P.traj_out[b * 4 + 3], P.traj_out[(P.B + b) * 4 + 3], P.v_max, P.a_max, P.max_iterations);
+  if (r.total == 1.0) return;
+  const double inv = 1.0 / r.total;
   double* c = P.coeffs + idx * (long long)P.N;
   double scale = 1.0;
-  for (int n = 0; n < P.N; ++n) {   // Polynomial::scalePolynomialInTime (polynomial.cpp:199-205)
+  for (int n = 0; n < P.N; ++n) {
     c[n] *= scale;
     scale *= inv;
   }
-  if (d == 0) P.times[b * P.ts_b + (long long)seg * P.ts_k] *= s;
+  if (d == 0) P.times[b * P.ts_b + (long long)seg * P.ts_k] *= r.total;
+}
+
+// lane per trajectory, after mtg_scale_kernel: per-trajectory outputs, and the extrema tables as the last round's check saw
+// them (instants x factor, velocity / factor, acceleration / factor^2)
+__global__ void mtg_scale_finish_kernel(ScaleParams P) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  const ScaleLoop r = mtg_scale_loop(P.traj_out[b * 4 + 3], P.traj_out[(P.B + b) * 4 + 3], P.v_max, P.a_max, P.max_iterations);
+  if (P.within) P.within[b] = r.within ? 1 : 0;
+  if (P.scaling) P.scaling[b] = r.total;
+  const double f = r.total_chk;
+  if (f == 1.0) return;
+  const double inv = 1.0 / f;
+  for (int slot = 0; slot < 2; ++slot) {
+    const double vs = slot == 0 ? inv : inv * inv;
+    double* t = P.traj_out + ((long long)slot * P.B + b) * 4;
+    t[0] *= f; t[1] *= vs; t[2] *= f; t[3] *= vs;
+    double* s = P.seg_out + ((long long)slot * P.B + b) * P.K * 4;
+    for (int k = 0; k < P.K; ++k) { s[4 * k] *= f; s[4 * k + 1] *= vs; s[4 * k + 2] *= f; s[4 * k + 3] *= vs; }
+  }
 }
 
 template <int NMAX>
 void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   constexpr int L = 2 * NMAX - 2;
   const long long total = P.B * P.K;
-  const size_t lds = (size_t)kThreads * (L - 1) * sizeof(double);
+  const size_t lds = (size_t)kThreads * 2 * (L - 1) * sizeof(double);   // two root buffers per lane (mtg_extrema_lane.h)
   hipLaunchKernelGGL(mtg_minmax_seg_kernel<NMAX>, dim3((unsigned)((total + kThreads - 1) / kThreads), n_slots),
                      dim3(kThreads), lds, stream, P);
 }
@@ -208,15 +242,14 @@ extern "C" int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int
   P.der[0] = 1;   // derivative_order::VELOCITY
   P.der[1] = 2;   // derivative_order::ACCELERATION
   ScaleParams S;
-  S.coeffs = coeffs; S.times = times; S.ts_b = times_stride_b; S.ts_k = times_stride_k; S.traj_out = P.traj_out;
+  S.coeffs = coeffs; S.times = times; S.ts_b = times_stride_b; S.ts_k = times_stride_k; S.seg_out = P.seg_out; S.traj_out = P.traj_out;
   S.scaling = scaling; S.within = within_range; S.B = batch; S.N = n_coeffs; S.K = n_segments; S.D = dimension;
-  S.v_max = v_max; S.a_max = a_max;
+  S.v_max = v_max; S.a_max = a_max; S.max_iterations = max_iterations;
+  // ONE root search (velocity and acceleration in one launch), then the whole check / stretch loop analytically (mtg_scale_loop)
+  rc = launch_minmax(P, 2, (hipStream_t)stream);
+  if (rc != MTG_OK) return rc;
   const long long total = (long long)batch * n_segments * dimension;
-  for (int it = 0; it < max_iterations; ++it) {
-    rc = launch_minmax(P, 2, (hipStream_t)stream);
-    if (rc != MTG_OK) return rc;
-    S.first = it == 0;
-    hipLaunchKernelGGL(mtg_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S);
-  }
+  hipLaunchKernelGGL(mtg_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S);
+  hipLaunchKernelGGL(mtg_scale_finish_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S);
   return hipGetLastError() == hipSuccess ? MTG_OK : MTG_ERR_DEVICE;
 }

@@ -13,10 +13,14 @@
 //   * map the segment to tau = t/T in [0, 1] (coefficient j scaled by T^j) -- same roots, better scaling;
 //   * derivative chain: g_k = (m-k)-th divided derivative of g (degree k).  Between two consecutive roots of
 //     g_{k-1} the polynomial g_k is monotone, so every sign change of g_k over that partition brackets exactly one
-//     root, found by bisection-safeguarded Newton.  Level k's roots partition [0, 1] for level k+1; the root list
-//     is updated in place (at most one new root per interval).  Identically-zero leading levels (zero-padded
-//     coefficients, trailing zeros -- the reference strips them, rpoly_ak1.cpp:57-68) produce no sign changes and
-//     fall through.
+//     root, found by bisection-safeguarded Newton.  Level k's roots partition [0, 1] for level k+1 (two root buffers,
+//     the levels alternate).  Identically-zero leading levels (zero-padded coefficients, trailing zeros -- the reference
+//     strips them, rpoly_ak1.cpp:57-68) produce no sign changes and fall through.
+//     Round 4: every level runs in two phases -- (A) the level's values at all partition points, TWO Horner chains at a
+//     time, sign changes noted in a bit mask; (B) the brackets refined TWO at a time, a lane's j-th pair together with every
+//     other lane's j-th pair.  Round 3 refined each bracket where the scan met it: one dependent chain at a time (8 cycles
+//     per dependent FP64 operation for a lone wave) and, across the wave, one refinement per interval with a sign change in
+//     ANY lane.
 //   * evaluate the magnitude at tau = 0, 1 and at every root in that order, keeping strict </> like
 //     std::min/std::max over Extremum::operator< (extremum.h:37-38; segment.cpp:175-181).
 // Same code runs on the host for the emulation tests (tests/extrema_emu.cpp).
@@ -62,55 +66,126 @@ MTGX_HD void horner2(const double* a, double x, double& f, double& df) {   // va
 }
 
 constexpr double kRootTol = 4e-15;        // absolute, in tau in [0, 1]: roots of g itself (the candidates)
-constexpr double kPartitionTol = 1e-7;    // roots of the derivative levels only partition [0, 1] for the next level
+constexpr double kPartitionTol = 1e-5;    // roots of the derivative levels only partition [0, 1] for the next level (the last
+                                          // Newton step that is smaller than this leaves ~1e-10; a root pair closer than that
+                                          // changes no extremum value beyond round-off)
 constexpr int kRootMaxIter = 100;         // pure bisection needs ~48
 
-// One root of the degree-K polynomial a in [lo, hi], given f(lo), f(hi) of opposite sign and a monotone there.
+// Two chains at once: a lane alone on its SIMD pays ~8 cycles per DEPENDENT FP64 operation and 4 per independent one, and the
+// extrema kernels run at about one wave per SIMD at the sizes that matter (10k trajectories x 8 segments = 1250 waves) -- the
+// round-3 form (one Horner chain after the other) was bound by exactly that latency.
 template <int K>
-MTGX_HD double bracketed_root(const double* a, double lo, double hi, double flo, double fhi, double tol) {
-  double xl = flo < 0.0 ? lo : hi;   // f(xl) < 0 <= f(xh)
-  double xh = flo < 0.0 ? hi : lo;
-  // start from the chord's zero (inside the bracket by construction), nudged off the end points
-  double x = lo - flo * (hi - lo) / (fhi - flo);
-  if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
-  double dxold = fabs(hi - lo), dx = dxold;
-  double f, df;
-  horner2<K>(a, x, f, df);
-  for (int it = 0; it < kRootMaxIter; ++it) {
-    const bool newton_leaves = ((x - xh) * df - f) * ((x - xl) * df - f) > 0.0;
-    const bool newton_slow = fabs(2.0 * f) > fabs(dxold * df);
-    dxold = dx;
-    if (newton_leaves || newton_slow || !(df != 0.0)) {
-      dx = 0.5 * (xh - xl);
-      x = xl + dx;
-    } else {
-      dx = f / df;
-      x -= dx;
-    }
-    if (fabs(dx) < tol) break;
-    horner2<K>(a, x, f, df);
-    if (f < 0.0) xl = x; else xh = x;
+MTGX_HD void horner_pair(const double* a, double x0, double x1, double& f0, double& f1) {
+  f0 = a[K];
+  f1 = a[K];
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    f0 = fma(f0, x0, a[j]);
+    f1 = fma(f1, x1, a[j]);
   }
-  return x;
+}
+template <int K>
+MTGX_HD void horner2_pair(const double* a, double x0, double x1, double& f0, double& d0, double& f1, double& d1) {
+  f0 = a[K]; f1 = a[K];
+  d0 = 0.0; d1 = 0.0;
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    d0 = fma(d0, x0, f0);
+    d1 = fma(d1, x1, f1);
+    f0 = fma(f0, x0, a[j]);
+    f1 = fma(f1, x1, a[j]);
+  }
 }
 
-// Derivative-chain level K (compile time): a[0..K] holds the (M-K)-th divided derivative of g on entry.
+// Bisection-safeguarded Newton on TWO brackets at once (each: f of opposite sign at its ends, monotone inside); a bracket that
+// has converged keeps its x while the other one finishes.  Same step rule as the one-bracket form of round 3.
+struct Bracket {
+  double xl, xh, x, dx, dxold;
+  bool done;
+};
+MTGX_HD void bracket_init(Bracket& b, double lo, double hi, double flo, double fhi) {
+  b.xl = flo < 0.0 ? lo : hi;   // f(xl) < 0 <= f(xh)
+  b.xh = flo < 0.0 ? hi : lo;
+  // start from the chord's zero (inside the bracket by construction), nudged off the end points
+  b.x = lo - flo * (hi - lo) / (fhi - flo);
+  if (!(b.x > lo && b.x < hi)) b.x = 0.5 * (lo + hi);
+  b.dxold = fabs(hi - lo);
+  b.dx = b.dxold;
+  b.done = false;
+}
+MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol) {
+  if (b.done) return;
+  if (f < 0.0) b.xl = b.x; else b.xh = b.x;
+  const bool newton_leaves = ((b.x - b.xh) * df - f) * ((b.x - b.xl) * df - f) > 0.0;
+  const bool newton_slow = fabs(2.0 * f) > fabs(b.dxold * df);
+  b.dxold = b.dx;
+  if (newton_leaves || newton_slow || !(df != 0.0)) {
+    b.dx = 0.5 * (b.xh - b.xl);
+    b.x = b.xl + b.dx;
+  } else {
+    b.dx = f / df;
+    b.x -= b.dx;
+  }
+  if (fabs(b.dx) < tol) b.done = true;
+}
+template <int K>
+MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, double tol) {
+  for (int it = 0; it < kRootMaxIter; ++it) {
+    double f0, d0, f1, d1;
+    horner2_pair<K>(a, b0.x, b1.x, f0, d0, f1, d1);
+    bracket_step(b0, f0, d0, tol);
+    bracket_step(b1, f1, d1, tol);
+    if (b0.done && b1.done) break;
+  }
+}
+
+// Derivative-chain level K (compile time): a[0..K] holds the (M-K)-th divided derivative of g on entry.  The partition points
+// left by level K-1 are in buffer (K-1) & 1 of `roots`, this level's roots go to buffer K & 1 (element i of buffer b:
+// roots[b * M + i]).  Two phases, so that the lanes of a wave refine their brackets TOGETHER (a lane's j-th bracket with every
+// other lane's j-th bracket -- the wave runs max-over-lanes(brackets) / 2 refinements per level, not one per interval that has
+// a sign change in ANY lane): (A) evaluate this level at every partition point, two points at a time, and note the
+// intervals with a sign change in a bit mask; (B) refine them two at a time.
 template <int M, int K, class Roots>
 struct Level {
   static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt) {
-    // roots of this level between the partition points left by level K-1
+    constexpr int SRC = ((K - 1) & 1) * M, DST = (K & 1) * M;
+    const double tol = K < M ? kPartitionTol : kRootTol;
+    // partition points P_0 = 0, P_i = roots[SRC + i - 1] (i = 1 .. cnt), P_(cnt+1) = 1; interval i = [P_i, P_(i+1)]
+    unsigned mask = 0;
+    {
+      double flo = a[0];   // value at 0
+      for (int i = 0; i <= cnt; i += 2) {
+        const double h0 = i < cnt ? roots[SRC + i] : 1.0;
+        const double h1 = i + 1 < cnt ? roots[SRC + i + 1] : 1.0;
+        double f0, f1;
+        horner_pair<K>(a, h0, h1, f0, f1);
+        if ((flo < 0.0) != (f0 < 0.0)) mask |= 1u << i;
+        if (i + 1 <= cnt && (f0 < 0.0) != (f1 < 0.0)) mask |= 1u << (i + 1);
+        flo = f1;
+      }
+    }
     int cnt_new = 0;
-    double lo = 0.0, flo = a[0];
-    for (int i = 0; i <= cnt; ++i) {
-      const double hi = i < cnt ? roots[i] : 1.0;
-      const double fhi = horner<K>(a, hi);
-      if ((flo < 0.0) != (fhi < 0.0)) {
-        const double r = bracketed_root<K>(a, lo, hi, flo, fhi, K < M ? kPartitionTol : kRootTol);
-        roots[cnt_new] = r;   // cnt_new <= i and roots[i] was already read: in-place is safe
+    while (mask != 0u) {
+      const int i0 = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const bool two = mask != 0u;
+      const int i1 = two ? __builtin_ctz(mask) : i0;
+      mask &= mask - 1u;       // (0 & anything = 0: harmless when there was only one)
+      const double lo0 = i0 > 0 ? roots[SRC + i0 - 1] : 0.0, hi0 = i0 < cnt ? roots[SRC + i0] : 1.0;
+      const double lo1 = i1 > 0 ? roots[SRC + i1 - 1] : 0.0, hi1 = i1 < cnt ? roots[SRC + i1] : 1.0;
+      double fl0, fh0, fl1, fh1;
+      horner_pair<K>(a, lo0, hi0, fl0, fh0);
+      horner_pair<K>(a, lo1, hi1, fl1, fh1);
+      Bracket b0, b1;
+      bracket_init(b0, lo0, hi0, fl0, fh0);
+      bracket_init(b1, lo1, hi1, fl1, fh1);
+      bracketed_root_pair<K>(a, b0, b1, tol);
+      roots[DST + cnt_new] = b0.x;
+      ++cnt_new;
+      if (two) {
+        roots[DST + cnt_new] = b1.x;
         ++cnt_new;
       }
-      lo = hi;
-      flo = fhi;
     }
     cnt = cnt_new;
     if constexpr (K < M) {
@@ -125,10 +200,12 @@ struct Level {
   }
 };
 
-// Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending in roots[0..return).  L >= 2.
+// Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 2 * (L - 1) elements (two
+// buffers the levels alternate between); returns the count and, in `base`, the offset of the buffer that holds the result.
 template <int L, class Roots>
-MTGX_HD int real_roots_unit(const double* g, Roots& roots) {
+MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base) {
   constexpr int M = L - 1;   // degree
+  static_assert(M <= 31, "interval bit mask");
   double a[L];
 #pragma unroll
   for (int j = 0; j < L; ++j) a[j] = 0.0;
@@ -136,6 +213,7 @@ MTGX_HD int real_roots_unit(const double* g, Roots& roots) {
   a[1] = g[M] * (double)M;   // level 1 = (M-1)-th divided derivative: g[M-1] + M g[M] tau
   int cnt = 0;
   Level<M, 1, Roots>::run(g, a, roots, cnt);
+  base = (M & 1) * M;
   return cnt;
 }
 
@@ -192,7 +270,8 @@ MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, 
       for (int j = 0; j + 1 < NMAX; ++j) g[j] = (double)(j + 1) * u[j + 1];
     }
   }
-  const int cnt = real_roots_unit<L>(g, roots);
+  int base = 0;
+  const int cnt = real_roots_unit<L>(g, roots, base);
 
   MinMax mm;
   mm.v_min = DBL_MAX;     // segment.cpp:172-173
@@ -200,7 +279,7 @@ MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, 
   mm.t_min = 0.0;
   mm.t_max = 0.0;
   for (int i = -2; i < cnt; ++i) {   // candidate order of polynomial.cpp:43-45: t_start, t_end, then the roots
-    const double t = i == -2 ? 0.0 : (i == -1 ? T : roots[i] * T);
+    const double t = i == -2 ? 0.0 : (i == -1 ? T : roots[base + i] * T);
     const double v = magnitude_at(c, N, D, dim_mask, der, t);
     if (v > mm.v_max) { mm.v_max = v; mm.t_max = t; }
     if (v < mm.v_min) { mm.v_min = v; mm.t_min = t; }

@@ -5,7 +5,7 @@
 
 namespace {
 struct LocalRoots {
-  double v[24];
+  double v[48];   // two buffers of L - 1 elements (the derivative-chain levels alternate between them)
   double& operator[](int i) { return v[i]; }
 };
 
@@ -39,7 +39,8 @@ extern "C" int extrema_emu_segments(int N, int K, int D, long long B, const doub
 // all real roots in [0, 1] of sum g[j] tau^j (j < 22), for direct root-finder tests
 extern "C" int extrema_emu_roots22(const double* g, double* roots_out) {
   LocalRoots roots;
-  const int cnt = mtgx::real_roots_unit<22>(g, roots);
-  for (int i = 0; i < cnt; ++i) roots_out[i] = roots[i];
+  int base = 0;
+  const int cnt = mtgx::real_roots_unit<22>(g, roots, base);
+  for (int i = 0; i < cnt; ++i) roots_out[i] = roots[base + i];
   return cnt;
 }

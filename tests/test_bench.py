@@ -101,7 +101,7 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     # >= 3 buffer sets, every sampled row NaN-prefilled and rewritten by the timed launch
     par = out["parity"]
     assert par["n"] >= 512 and len(set(par["buffer_sets_sampled"])) >= 3 and par["rows_not_written_by_the_timed_launch"] == 0
-    assert par["tol"] == 1e-9 and par["ok"] and par["max_rel_err_vs_port"] <= 1e-9
+    assert par["tol"] == 1e-9 and par["ok"] and par["max_rel_err_vs_port"] <= 1e-9, par
     assert par["max_rel_err_vs_reference_build"] is None or par["max_rel_err_vs_reference_build"] <= 1e-9
     # the per-step hand-over form under the same protocol, as a peer of `value`
     peer = out["value_other_form"]
@@ -133,7 +133,7 @@ def test_latency_form_and_config4_lines():
     assert "cpu_baseline" not in out
     # parity of the timed launch per polynomial order; the request is pre-built outside the timed region and says so
     par = out["parity"]
-    assert par["ok"] and set(par["per_n"]) == {"8", "10", "12"} and all(v["n"] >= 512 for v in par["per_n"].values())
+    assert par["ok"] and set(par["per_n"]) == {"8", "10", "12"} and all(v["n"] >= 512 for v in par["per_n"].values()), par
     assert par["per_n"]["8"]["max_rel_err_vs_port"] <= 1e-9 and par["per_n"]["10"]["max_rel_err_vs_port"] <= 1e-9
     assert out["request_build"]["outside_timed_region"] and out["request_build"]["host_us"] > 0
     assert 0 < out["request_build"]["value_including_request_build"] < out["value"]

@@ -34,28 +34,44 @@ __global__ __launch_bounds__(64) void k(double* out, long long* ticks, int iters
   if (s == 123.456) out[0] = s;
 }
 
+// NOP: wait states between the VALU write of the DPP source and the DPP read (the hazard recogniser does not see inside
+// inline asm: "VALU writes VGPR -> DPP reads that VGPR" needs 2 wait states on gfx9)
+template <int NOP>
 __global__ void check(double* out) {
   double x = 100.0 + threadIdx.x, y = 2.0, acc = 0.5;
-  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+  if (NOP) asm volatile("s_nop 1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
   double m = 7.0;
-  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(x));
+  if (NOP) asm volatile("s_nop 1\n v_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(x));
+  else asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(x));
+  // bank-masked form: lanes 0-7 of each row take lane 2, lanes 8-15 take lane 11 (two 8-lane groups per row)
+  double acc2 = 0.25;
+  asm volatile("s_nop 1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0x3\n"
+               "v_fmac_f64_dpp %0, %1, %2 row_newbcast:11 row_mask:0xf bank_mask:0xc" : "+v"(acc2) : "v"(x), "v"(y));
   out[threadIdx.x] = acc;
   out[64 + threadIdx.x] = m;
+  out[128 + threadIdx.x] = acc2;
 }
 
 int main() {
   double* out; long long* ticks;
-  hipMalloc(&out, 128 * 8); hipMalloc(&ticks, 8192 * 8);
-  check<<<1, 64>>>(out);
-  double h[128];
-  hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+  hipMalloc(&out, 192 * 8); hipMalloc(&ticks, 8192 * 8);
   int bad = 0;
-  for (int l = 0; l < 64; ++l) {
-    const double want = 0.5 + (100.0 + (l & ~15) + 3) * 2.0, wm = 100.0 + (l & ~15) + 5;
-    if (h[l] != want || h[64 + l] != wm) ++bad;
+  for (int nop = 0; nop < 2; ++nop) {
+    if (nop) check<1><<<1, 64>>>(out); else check<0><<<1, 64>>>(out);
+    double h[192];
+    hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    int b0 = 0, b1 = 0, b2 = 0;
+    for (int l = 0; l < 64; ++l) {
+      const double want = 0.5 + (100.0 + (l & ~15) + 3) * 2.0, wm = 100.0 + (l & ~15) + 5;
+      const double w2 = 0.25 + (100.0 + (l & ~15) + ((l & 8) ? 11 : 2)) * 2.0;
+      b0 += h[l] != want; b1 += h[64 + l] != wm; b2 += h[128 + l] != w2;
+    }
+    std::printf("%s wait states: v_fmac_f64_dpp row_newbcast:3 %s (%d lanes off), v_mov_b64_dpp row_newbcast:5 %s (%d), bank-masked 8-lane pair %s (%d); lanes 0 / 20 / 45: fmac %.1f %.1f %.1f mov %.1f %.1f %.1f pair %.2f %.2f %.2f\n",
+                nop ? "with 2" : "without", b0 ? "MISMATCH" : "ok", b0, b1 ? "MISMATCH" : "ok", b1, b2 ? "MISMATCH" : "ok", b2,
+                h[0], h[20], h[45], h[64], h[84], h[109], h[128], h[148], h[173]);
+    if (nop) bad = b0 + b1 + b2;
   }
-  std::printf("v_fmac_f64_dpp row_newbcast:3 / v_mov_b64_dpp row_newbcast:5 semantics: %s (lane 20: %.1f, want %.1f)\n",
-              bad ? "MISMATCH" : "ok", h[20], 0.5 + (100.0 + 16 + 3) * 2.0);
   const int iters = 2000;
   const char* names[3] = {"v_fma_f64 (VOP3), 8 independent accumulators", "v_fmac_f64_dpp row_newbcast, 8 independent accumulators",
                           "v_fmac_f64 (VOP2), 8 independent accumulators"};

@@ -27,5 +27,5 @@ for (N, K, D, d, mi, B, dims) in CASES:
             base = base or us
             print(json.dumps(dict(N=N, K=K, D=D, B=B, form=plan.launch_form(B, "soa", dims), stagger_x2048_cycles=stag, kernel_us=round(us, 2),
                                   vs_no_stagger=round(us / base, 3), frac=round(B * plan.bytes_per_trajectory / us * 1e-3 / 8000, 3))), flush=True)
-    ctx.set_option("dl_stagger", 0)
+    ctx.set_option("dl_stagger", -1)
     plan.close()
