@@ -106,6 +106,11 @@ enum {
   MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 1u << 8, /* mtg_solve_linear_sequence: never merge  */
                                      /* the queue into one persistent launch (latency of the  */
                                      /* single launches; A/B measurements)                    */
+  MTG_FLAG_COOPERATIVE = 1u << 11,   /* force the row-cooperative launch form (16 lanes per   */
+                                     /* trajectory-half: the LATENCY form for small launches  */
+                                     /* of long chains) where the plan and the call are       */
+                                     /* eligible (standard shapes, D = 3, coefficients only); */
+                                     /* default: chosen from the batch size and chain length  */
   MTG_FLAG_BASIC_SOLUTION = 1u << 10 /* mtg_solve_linear / _status: reference behaviour on     */
                                      /* RANK-DEFICIENT free systems (LIN:365-378: the rank-   */
                                      /* revealing SparseQR returns a basic solution and       */
@@ -143,7 +148,8 @@ mtg_context* mtg_plan_context(const mtg_plan* plan);
 /* Which kernel form a device-pointer mtg_solve_linear(plan, batch, layout, ..., flags) call with coefficient output only
  * (with MTG_FLAG_QUERY_EXTRA_OUTPUTS: a call that also returns the cost / d_free) takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
  * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane (one unrolled body per chain length), 6 dimension-in-lane
- * with a run-time chain length (one body per polynomial order).  Negative: mtg_status.                                 */
+ * with a run-time chain length (one body per polynomial order), 7 row-cooperative (16 lanes per trajectory-half; small
+ * launches of long chains).  Negative: mtg_status.                                                                     */
 int mtg_plan_launch_form(const mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint32_t flags);
 void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);

@@ -110,7 +110,7 @@ ENV_OPTIONS = {
     "MTG_DL_GRID_PER_CU": ("dl_grid_per_cu", int), "MTG_DL_ANY_SCHED": ("dl_any_sched_rr", lambda e: int(e == "rr")),
     "MTG_SLAB_POLICY": ("slab_policy", lambda e: 1 if int(e) else 0), "MTG_ROLLED_WG_PER_CU": ("rolled_wg_per_cu", int),
     "MTG_DL_MAX_UNITS": ("dl_max_units", int), "MTG_SAMPLE_GENERIC": ("sample_generic", _flag),
-    "MTG_DL_STAGGER": ("dl_stagger", int),
+    "MTG_DL_STAGGER": ("dl_stagger", int), "MTG_COOP": ("coop", int),
 }
 
 FLAG_HOST_POINTERS = 1
@@ -124,6 +124,7 @@ FLAG_CONCURRENT_ITEMS = 128
 FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 256
 FLAG_QUERY_EXTRA_OUTPUTS = 512
 FLAG_BASIC_SOLUTION = 1024
+FLAG_COOPERATIVE = 2048
 
 _lib = None
 

@@ -265,7 +265,7 @@ class Plan:
             cost = torch.empty((batch,), dtype=torch.float64, device=dev)
         lay = self.layout(batch, layout)
         flags = L.FLAG_GENERIC_KERNEL if generic else 0
-        flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE, "coop": L.FLAG_COOPERATIVE}[dims]
         if basic_solution:
             flags |= L.FLAG_BASIC_SOLUTION
         if traj_status is not None:
@@ -297,7 +297,7 @@ class Plan:
             assert co.dtype == torch.float64 and co.is_cuda and co.is_contiguous() and co.shape[0] == batch
         arr = [(ctypes.c_void_p * n)(*[x[j].data_ptr() for x in sets]) for j in range(3)]
         lay = self.layout(batch, layout)
-        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE, "coop": L.FLAG_COOPERATIVE}[dims]
         if one_launch_per_batch:
             flags |= L.FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH
         ev = [ctypes.c_void_p(e.cuda_event) if e is not None else None for e in (start_event, stop_event)]
@@ -363,13 +363,13 @@ class Plan:
         _check(self.lib, rc, self.ctx.handle)
         return coeffs, d_free, cost
 
-    LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane", 6: "dimlane_rt"}
+    LAUNCH_FORMS = {0: "generic", 1: "fused", 2: "split", 3: "rolled", 4: "slab", 5: "dimlane", 6: "dimlane_rt", 7: "coop"}
 
     def launch_form(self, batch: int, layout: str = "soa", dims: str = "auto", extra_outputs: bool = False) -> str:
         """Kernel form a coefficient-only device-pointer solve of `batch` trajectories takes (mtg_plan_launch_form);
         extra_outputs: of a solve that also returns the cost / d_free."""
         lay = self.layout(batch, layout)
-        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE}[dims]
+        flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE, "coop": L.FLAG_COOPERATIVE}[dims]
         if extra_outputs:
             flags |= L.FLAG_QUERY_EXTRA_OUTPUTS
         rc = self.lib.mtg_plan_launch_form(self.handle, batch, ctypes.byref(lay), flags)

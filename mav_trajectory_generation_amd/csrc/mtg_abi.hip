@@ -28,6 +28,10 @@
 #include "mtg_dimlane_rt.h"
 
 int mtg_host_run(const MtgParams& P, int H, bool update);   // mtg_host.cpp: host build of the lane code
+// mtg_coop.hip: the row-cooperative kernel (0 launched, 1 shape / size not covered, 2 runtime error) and its LDS need
+int mtg_coop_launch(void* stream, int H, int D, int K, int deriv, long long B, const double* times, long long ts_b, long long ts_k,
+                    const double* dfix, long long fs_b, long long fs_d, long long fs_c, double* coeffs, int* status, int* tstatus);
+size_t mtg_coop_lds_bytes(int H, int D, int K);
 extern "C" int mtg_basic_solution_one(int H, int K, int D, int deriv, const int* mask, const int* offF, const int* offP,
                                       const double* times, const double* dfix, double* dfree);   // mtg_basic.cpp (internal; exported for the CPU tests)
 
@@ -126,6 +130,7 @@ struct mtg_context {
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
+  int knob_coop = -1;                // MTG_COOP: 1 always / 0 never take the row-cooperative form where eligible (default: by size)
   int knob_dl_stagger = -1;          // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
                                      // (-1: the default -- kDlStaggerWorkspace for the workspace hybrids in multi-round launches, else 0)
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
@@ -146,6 +151,7 @@ struct LaunchRecord {
   const MtgDimlaneRtEntry* rt = nullptr; // run-time-K dimension-in-lane launch (mtg_dimlane_rt.h)
   int dl_policy = 0;
   int dl_aos = 0;                        // input layout kind of a dimension-in-lane launch (dimlane_input_kind)
+  bool coop = false;                     // row-cooperative launch (mtg_coop.hip)
   double* dl_ws = nullptr;
 };
 
@@ -293,6 +299,7 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   else if (n == "rolled_wg_per_cu") ctx->rolled_wg_per_cu = std::max(1, value);
   else if (n == "dl_max_units") ctx->dl_max_units_per_cu = value;
   else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
+  else if (n == "coop") ctx->knob_coop = value;
   else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(-1, std::min(value, 1 << 20));
   else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
   return MTG_OK;
@@ -604,7 +611,7 @@ static const MtgSlabEntry* pick_slab(const mtg_plan* p, const MtgStaticEntry* va
 struct PerturbedTimes { double h, lower_bound; };   // mtg_mellinger_cost_gradient: (K + 1) virtual problems per trajectory
 
 // ---- one solve / update call: stage (host pointers) -> pick_form -> launch_<form> -> fetch (host pointers) ------------------
-enum class SolveForm { kUpdate, kDimlaneRt, kDimlane, kFused };   // kFused: slab-output / static / rolled / generic kernels
+enum class SolveForm { kUpdate, kCoop, kDimlaneRt, kDimlane, kFused };   // kFused: slab-output / static / rolled / generic kernels
 
 struct SolveCall {                  // everything a launcher needs, assembled once by solve_impl
   mtg_plan* p;
@@ -633,11 +640,41 @@ static int workspace(mtg_plan* p, size_t need, double** out) {
   return rc;
 }
 
+// The row-cooperative form (mtg_coop.hip): standard shapes (end vertices fully fixed, position-only interior vertices), D = 3,
+// coefficient output only, non-negative strides, 32-bit input offsets, the step storage of the chain within one CU's LDS.
+// Default range: LAUNCHES THAT DO NOT FILL THE CHIP in the lane-per-half forms -- a chain step costs ~2.4x the lane-instructions
+// here, but four trajectory-halves share a wavefront instead of 21-64: kCoopMaxUnitsPerSimd x SIMDs wavefronts at most, chains of
+// at least kCoopMinSegments segments (shorter chains are launch-latency-bound in every form).
+constexpr bool kCoopDefault = false;    // (opt-in -- MTG_FLAG_COOPERATIVE / option "coop" -- until its cross-over is measured)
+constexpr int kCoopMinSegments = 16;
+constexpr int kCoopMaxWavesPerSimd = 2;
+static bool coop_eligible(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P, bool cost_only) {
+  if (p->D != 3 || p->H < 4 || p->H > 6 || p->K < 2 || cost_only || P.dfree || P.cost || P.pert_on) return false;
+  const int full = (1 << p->H) - 1;
+  if (p->mask[0] != full || p->mask[p->K] != full) return false;
+  for (int v = 1; v < p->K; ++v) if (p->mask[v] != 1) return false;
+  const size_t lds = mtg_coop_lds_bytes(p->H, p->D, p->K);
+  if (lds == 0 || lds > 160 * 1024) return false;
+  if (L->times_stride_b < 0 || L->times_stride_k < 0 || L->fixed_stride_b < 0 || L->fixed_stride_d < 0 || L->fixed_stride_c < 0) return false;
+  const int64_t tmax = (batch - 1) * L->times_stride_b + (int64_t)(p->K - 1) * L->times_stride_k;
+  const int64_t fmax = (batch - 1) * L->fixed_stride_b + (int64_t)(p->D - 1) * L->fixed_stride_d + (int64_t)(p->n_fixed - 1) * L->fixed_stride_c;
+  return tmax * 8 < (1ll << 32) && fmax * 8 < (1ll << 32);
+}
+static bool pick_coop(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P, uint32_t flags, bool cost_only) {
+  if (p->ctx->knob_coop == 0 || !coop_eligible(p, batch, L, P, cost_only)) return false;
+  if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_DIMLANE)) return false;
+  if ((flags & MTG_FLAG_COOPERATIVE) || p->ctx->knob_coop == 1) return true;
+  if (!kCoopDefault) return false;
+  const int64_t waves = 2 * ((batch + 3) / 4);
+  return p->K >= kCoopMinSegments && waves <= (int64_t)kCoopMaxWavesPerSimd * 4 * p->ctx->n_cu;
+}
+
 // Which form a call takes: the run-time-K dimension-in-lane body where the plan has no static variant, the static
 // dimension-in-lane variants inside their default range (or forced), else the fused family.  Same order as
 // mtg_plan_launch_form reports.
 static SolveForm pick_form(SolveCall& c, bool update_only) {
   if (update_only) return SolveForm::kUpdate;
+  if (pick_coop(c.p, c.batch, c.L, c.P, c.flags, c.cost_only)) return SolveForm::kCoop;
   if ((c.rt = pick_dimlane_rt(c.p, c.batch, c.L, c.P, c.flags, c.cost_only))) return SolveForm::kDimlaneRt;
   if ((c.dl = dimlane_twin(c.p, pick_dimlane(c.p, c.batch, c.L, c.P, c.flags, c.cost_only), c.batch))) return SolveForm::kDimlane;
   return SolveForm::kFused;
@@ -667,6 +704,19 @@ static int launch_update(SolveCall& c) {
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWave), lds, c.st, Q, c.ntiles);
     if (uv) break;
   }
+  return MTG_OK;
+}
+
+// row-cooperative form (mtg_coop.hip): one 2-wave workgroup per four trajectories, step storage in LDS
+static int launch_coop(SolveCall& c) {
+  mtg_plan* p = c.p;
+  const MtgParams& P = c.P;
+  const int rc = mtg_coop_launch((void*)c.st, p->H, p->D, p->K, p->deriv, c.batch, P.times, P.ts_b, P.ts_k, P.dfix, P.fs_b, P.fs_d, P.fs_c,
+                                 P.coeffs, P.status, c.dts);
+  if (rc != 0) return set_err(p->ctx, rc == 1 ? MTG_ERR_UNSUPPORTED : MTG_ERR_DEVICE, "row-cooperative launch failed");
+  LaunchRecord r;
+  r.valid = true; r.params = P; r.coop = true;
+  p->last.push_back(r);
   return MTG_OK;
 }
 
@@ -960,6 +1010,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   int rc = MTG_OK;
   switch (pick_form(c, update_only)) {
     case SolveForm::kUpdate: rc = launch_update(c); break;
+    case SolveForm::kCoop: rc = launch_coop(c); break;
     case SolveForm::kDimlaneRt: rc = launch_dimlane_rt(c); break;
     case SolveForm::kDimlane: rc = launch_dimlane(c); break;
     case SolveForm::kFused: rc = launch_fused(c); break;
@@ -986,6 +1037,7 @@ int mtg_plan_launch_form(const mtg_plan* p, int64_t batch, const mtg_layout* L, 
   static double cost_stands_for_any_extra_output = 0.0;
   if (extra) P.cost = &cost_stands_for_any_extra_output;   // ... unless asked for the form of a call with extra outputs; never dereferenced)
   flags &= ~(uint32_t)MTG_FLAG_QUERY_EXTRA_OUTPUTS;
+  if (pick_coop(p, batch, L, P, flags, false)) return 7;
   if (pick_dimlane_rt(p, batch, L, P, flags, false)) return 6;
   if (pick_dimlane(p, batch, L, P, flags, false)) return 5;
   const MtgStaticEntry* var = pick_static(p, (int)((batch + kWave - 1) / kWave), flags, !extra);
@@ -1654,6 +1706,11 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
   MTG_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
   for (int i = 0; i < iters; ++i) {
     for (const LaunchRecord& r : p->last) {
+      if (r.coop) {
+        mtg_coop_launch((void*)ctx->stream, p->H, p->D, p->K, p->deriv, r.params.B, r.params.times, r.params.ts_b, r.params.ts_k,
+                        r.params.dfix, r.params.fs_b, r.params.fs_d, r.params.fs_c, r.params.coeffs, r.params.status, r.params.tstatus);
+        continue;
+      }
       if (r.rt) {
         r.rt->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status, r.params.tstatus,
                      (int)r.params.B, r.params.K, r.ntiles, r.dl_ws, r.dl_aos);

@@ -65,11 +65,32 @@ MTGX_HD void horner2(const double* a, double x, double& f, double& df) {   // va
   }
 }
 
-constexpr double kRootTol = 4e-15;        // absolute, in tau in [0, 1]: roots of g itself (the candidates)
-constexpr double kPartitionTol = 1e-5;    // roots of the derivative levels only partition [0, 1] for the next level (the last
-                                          // Newton step that is smaller than this leaves ~1e-10; a root pair closer than that
+// (an extremum's VALUE is second order in the root's error: 1e-12 in tau moves it by ~1e-24 relative; its instant by 1e-12 T)
+constexpr double kRootTol = 1e-12;        // absolute, in tau in [0, 1]: roots of g itself (the candidates)
+constexpr double kPartitionTol = 1e-4;    // roots of the derivative levels only partition [0, 1] for the next level (the last
+                                          // Newton step that is smaller than this leaves ~1e-8; a root pair closer than that
                                           // changes no extremum value beyond round-off)
 constexpr int kRootMaxIter = 100;         // pure bisection needs ~48
+#ifndef MTGX_NOISE_ULPS
+#define MTGX_NOISE_ULPS 4.0
+#endif
+constexpr double kNoiseUlps = MTGX_NOISE_ULPS;        // |f| below this many ulps of sum |a_k|: converged (evaluation noise)
+#if defined(MTGX_COUNT_ITERATIONS)
+static long long mtgx_iteration_count = 0;   // host diagnostics (tests/extrema_emu.cpp): refinement rounds executed
+static int mtgx_trace[32][16];               // [level][pair slot of the level]: rounds of the last root search (one lane)
+static int mtgx_trace_slot = 0;
+#endif
+
+// 1 / x for a Newton STEP (24 bits are plenty: the step's error is second order in the iteration, and convergence is judged by
+// |dx| and |f|, not by the step's last bits).  v_rcp_f64 is one instruction; the IEEE division sequence is ~12 dependent ones,
+// and there were two per refinement round.
+MTGX_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(x);
+#else
+  return 1.0 / x;
+#endif
+}
 
 // Two chains at once: a lane alone on its SIMD pays ~8 cycles per DEPENDENT FP64 operation and 4 per independent one, and the
 // extrema kernels run at about one wave per SIMD at the sizes that matter (10k trajectories x 8 segments = 1250 waves) -- the
@@ -107,34 +128,50 @@ MTGX_HD void bracket_init(Bracket& b, double lo, double hi, double flo, double f
   b.xl = flo < 0.0 ? lo : hi;   // f(xl) < 0 <= f(xh)
   b.xh = flo < 0.0 ? hi : lo;
   // start from the chord's zero (inside the bracket by construction), nudged off the end points
-  b.x = lo - flo * (hi - lo) / (fhi - flo);
+  b.x = lo - flo * (hi - lo) * fast_rcp(fhi - flo);
   if (!(b.x > lo && b.x < hi)) b.x = 0.5 * (lo + hi);
   b.dxold = fabs(hi - lo);
   b.dx = b.dxold;
   b.done = false;
 }
-MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol) {
-  if (b.done) return;
-  if (f < 0.0) b.xl = b.x; else b.xh = b.x;
-  const bool newton_leaves = ((b.x - b.xh) * df - f) * ((b.x - b.xl) * df - f) > 0.0;
+// fnoise: evaluation noise of the level's polynomial on [0, 1] (a few ulps of sum |a_k|).  Below it the sign of f carries no
+// information: the iteration has reached what float64 can resolve (a root of multiplicity m -- the rest-to-rest end segments have
+// a 7-fold root of g at the trajectory end -- is resolvable only to ~eps^(1/m); bisecting such a cluster down to `tol` cost ~45
+// rounds per bracket and level, and it was the slowest lane of every wave: 250 us per 10k x 8 segments in round 3).
+MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fnoise) {
+  // branch-free (selects only): the two brackets of a pair interleave, and a finished bracket costs no exec-mask detour
+  const bool live = !b.done && !(fabs(f) <= fnoise);
+  const bool neg = f < 0.0;
+  const double xl = (live && neg) ? b.x : b.xl;
+  const double xh = (live && !neg) ? b.x : b.xh;
+  const bool newton_leaves = ((b.x - xh) * df - f) * ((b.x - xl) * df - f) > 0.0;
   const bool newton_slow = fabs(2.0 * f) > fabs(b.dxold * df);
-  b.dxold = b.dx;
-  if (newton_leaves || newton_slow || !(df != 0.0)) {
-    b.dx = 0.5 * (b.xh - b.xl);
-    b.x = b.xl + b.dx;
-  } else {
-    b.dx = f / df;
-    b.x -= b.dx;
-  }
-  if (fabs(b.dx) < tol) b.done = true;
+  const bool bisect = newton_leaves || newton_slow || !(df != 0.0);
+  const double dx_b = 0.5 * (xh - xl);
+  const double dx_n = f * fast_rcp(df);
+  const double dx = bisect ? dx_b : dx_n;
+  const double x = bisect ? xl + dx_b : b.x - dx_n;
+  b.xl = xl;
+  b.xh = xh;
+  b.dxold = live ? b.dx : b.dxold;
+  b.dx = live ? dx : b.dx;
+  b.x = live ? x : b.x;
+  b.done = !live || fabs(dx) < tol;
 }
 template <int K>
-MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, double tol) {
+MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, double tol, double fnoise) {
+#if defined(MTGX_COUNT_ITERATIONS)
+  const long long before = mtgx_iteration_count;
+  struct Rec { long long b; ~Rec() { if (mtgx_trace_slot < 16) mtgx_trace[K][mtgx_trace_slot++] = (int)(mtgx_iteration_count - b); } } rec{before};
+#endif
   for (int it = 0; it < kRootMaxIter; ++it) {
     double f0, d0, f1, d1;
     horner2_pair<K>(a, b0.x, b1.x, f0, d0, f1, d1);
-    bracket_step(b0, f0, d0, tol);
-    bracket_step(b1, f1, d1, tol);
+#if defined(MTGX_COUNT_ITERATIONS)
+    ++mtgx_iteration_count;
+#endif
+    bracket_step(b0, f0, d0, tol, fnoise);
+    bracket_step(b1, f1, d1, tol, fnoise);
     if (b0.done && b1.done) break;
   }
 }
@@ -150,6 +187,10 @@ struct Level {
   static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt) {
     constexpr int SRC = ((K - 1) & 1) * M, DST = (K & 1) * M;
     const double tol = K < M ? kPartitionTol : kRootTol;
+    double anorm = 0.0;
+#pragma unroll
+    for (int j = 0; j <= K; ++j) anorm += fabs(a[j]);
+    const double fnoise = kNoiseUlps * DBL_EPSILON * anorm;
     // partition points P_0 = 0, P_i = roots[SRC + i - 1] (i = 1 .. cnt), P_(cnt+1) = 1; interval i = [P_i, P_(i+1)]
     unsigned mask = 0;
     {
@@ -165,6 +206,9 @@ struct Level {
       }
     }
     int cnt_new = 0;
+#if defined(MTGX_COUNT_ITERATIONS)
+    mtgx_trace_slot = 0;
+#endif
     while (mask != 0u) {
       const int i0 = __builtin_ctz(mask);
       mask &= mask - 1u;
@@ -179,7 +223,7 @@ struct Level {
       Bracket b0, b1;
       bracket_init(b0, lo0, hi0, fl0, fh0);
       bracket_init(b1, lo1, hi1, fl1, fh1);
-      bracketed_root_pair<K>(a, b0, b1, tol);
+      bracketed_root_pair<K>(a, b0, b1, tol, fnoise);
       roots[DST + cnt_new] = b0.x;
       ++cnt_new;
       if (two) {

@@ -1,0 +1,103 @@
+// Host emulation of the ROW-COOPERATIVE solve (csrc/mtg_coop.h): the SAME header the HIP kernel compiles, with the 16 lanes of
+// one DPP row executed in lock step on the CPU (a "value" is 16 doubles, a DPP row_newbcast read is v[L]), so that the lane
+// mapping, the parity schedule, the Gauss-Jordan sweeps and the recovery are checked against the oracle without a GPU.
+// Test infrastructure only.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../mav_trajectory_generation_amd/csrc/mtg_coop.h"
+
+namespace {
+struct V16 { double v[16]; };
+struct P16 { bool m[16]; };
+
+struct EmuOps {
+  using V = V16;
+  using P = P16;
+  static V splat(double x) { V r; for (double& e : r.v) e = x; return r; }
+  static V add(V a, V b) { V r; for (int l = 0; l < 16; ++l) r.v[l] = a.v[l] + b.v[l]; return r; }
+  static V mul(V a, V b) { V r; for (int l = 0; l < 16; ++l) r.v[l] = a.v[l] * b.v[l]; return r; }
+  static V fma(V a, V b, V c) { V r; for (int l = 0; l < 16; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+  static V neg(V a) { V r; for (int l = 0; l < 16; ++l) r.v[l] = -a.v[l]; return r; }
+  static V rcp(V a) { V r; for (int l = 0; l < 16; ++l) r.v[l] = 1.0 / a.v[l]; return r; }
+  static V sel(P c, V a, V b) { V r; for (int l = 0; l < 16; ++l) r.v[l] = c.m[l] ? a.v[l] : b.v[l]; return r; }
+  static V powi(V x, int e) { V r = splat(1.0); for (int i = 0; i < e; ++i) r = mul(r, x); return r; }
+  template <int E> static V powc(V x) { return powi(x, E); }
+  static P pand(P a, P b) { P r; for (int l = 0; l < 16; ++l) r.m[l] = a.m[l] && b.m[l]; return r; }
+  static P por(P a, P b) { P r; for (int l = 0; l < 16; ++l) r.m[l] = a.m[l] || b.m[l]; return r; }
+  static P pfalse() { P r; for (bool& e : r.m) e = false; return r; }
+  static P not_gt0(V a) { P r; for (int l = 0; l < 16; ++l) r.m[l] = !(a.v[l] > 0.0); return r; }
+  static void settle(V&) {}
+  template <class A, class B, class C> static void settle_rows(A&, B&, C&) {}
+  template <class A> static void settle_vec(A&) {}
+  template <int L> static void fmac_bcast(V& acc, V src, V m) {
+    const double s = src.v[L];
+    for (int l = 0; l < 16; ++l) acc.v[l] = std::fma(s, m.v[l], acc.v[l]);
+  }
+};
+
+struct EmuLanes {
+  template <class F> V16 make(F f) const { V16 r; for (int l = 0; l < 16; ++l) r.v[l] = f(l); return r; }
+  template <class F> P16 pred(F f) const { P16 r; for (int l = 0; l < 16; ++l) r.m[l] = f(l); return r; }
+};
+
+template <int H, int D>
+struct EmuIO {
+  static constexpr int N = 2 * H, F = H - 1;
+  const double* times;   // [K]
+  const double* dfix;    // [D][n_fixed]
+  int n_fixed, K;
+  double* coeffs;        // [K][D][N]
+  std::vector<V16> steps;
+  V16 time(int seg) { return EmuOps::splat(times[seg]); }
+  V16 fixed(int dm, int col) { return EmuOps::splat(dfix[dm * n_fixed + col]); }
+  void save(int j, int k, V16 v) { steps[(size_t)j * (F + D) + k] = v; }
+  V16 load(int j, int k) { return steps[(size_t)j * (F + D) + k]; }
+  void store(int seg, int dm, V16 v) { for (int l = 0; l < N; ++l) coeffs[((size_t)seg * D + dm) * N + l] = v.v[l]; }
+};
+
+template <int H, int D>
+int run(int K, int deriv, long long B, const double* times, const double* dfix, double* coeffs) {
+  constexpr int N = 2 * H, F = H - 1;
+  const int n_fixed = 2 * H + (K - 1);
+  const double* h1 = kH1 + mtg_h1_offset(N, deriv);
+  const int KA = (K + 1) / 2, KB = K / 2;
+  int flags = 0;
+  for (long long b = 0; b < B; ++b) {
+    mtgc::Coop<EmuOps, H, D> ca, cb;
+    EmuLanes li;
+    ca.init(h1, li);
+    cb.init(h1, li);
+    EmuIO<H, D> ioa{times + b * K, dfix + b * D * n_fixed, n_fixed, K, coeffs + b * K * D * N, std::vector<V16>((size_t)KA * (F + D))};
+    EmuIO<H, D> iob = ioa;
+    V16 pma[D], pmb[D];
+    mtgc::coop_forward<EmuOps, H, D, 1>(ca, ioa, K, KA, deriv, pma);
+    mtgc::coop_forward<EmuOps, H, D, -1>(cb, iob, K, KB, deriv, pmb);
+    V16 fa[F + D], fb[F + D];
+    for (int q = 0; q < F; ++q) { fa[q] = ca.B1[q]; fb[q] = cb.B1[q]; }
+    for (int dm = 0; dm < D; ++dm) { fa[F + dm] = ca.R[dm]; fb[F + dm] = cb.R[dm]; }
+    ca.solve_middle(fb);
+    cb.solve_middle(fa);
+    mtgc::coop_backward<EmuOps, H, D, 1>(ca, ioa, K, KA, deriv, pma);
+    mtgc::coop_backward<EmuOps, H, D, -1>(cb, iob, K, KB, deriv, pmb);
+    for (int l = 0; l < 16; ++l) {
+      if (ca.flag_time.m[l] || cb.flag_time.m[l]) flags |= 1;
+      if (ca.flag_singular.m[l] || cb.flag_singular.m[l]) flags |= 2;
+    }
+  }
+  return flags;
+}
+}  // namespace
+
+// Standard shapes (end vertices fix all h derivatives, interior vertices the position).  times [B][K], dfix [B][D][n_fixed],
+// coeffs [B][K][D][N].  Returns the OR of the status flags, or -1 for an unsupported shape.
+extern "C" int coop_emu_solve(int N, int K, int D, int deriv, long long B, const double* times, const double* dfix, double* coeffs) {
+  if (K < 2 || D != 3) return -1;
+  switch (N) {
+    case 8: return run<4, 3>(K, deriv, B, times, dfix, coeffs);
+    case 10: return run<5, 3>(K, deriv, B, times, dfix, coeffs);
+    case 12: return run<6, 3>(K, deriv, B, times, dfix, coeffs);
+  }
+  return -1;
+}

@@ -1,6 +1,7 @@
 // Host emulation of the device lane code of the extrema search (mtg_extrema_lane.h): the SAME header the HIP
 // kernel compiles, run lane-by-lane on the CPU so the algorithm can be checked against the oracle without a GPU.
 // Test infrastructure only.
+#define MTGX_COUNT_ITERATIONS 1
 #include "../mav_trajectory_generation_amd/csrc/mtg_extrema_lane.h"
 
 namespace {
@@ -43,4 +44,12 @@ extern "C" int extrema_emu_roots22(const double* g, double* roots_out) {
   const int cnt = mtgx::real_roots_unit<22>(g, roots, base);
   for (int i = 0; i < cnt; ++i) roots_out[i] = roots[base + i];
   return cnt;
+}
+
+// diagnostics: refinement rounds (pairs of Newton / bisection steps) executed since the last call
+extern "C" long long extrema_emu_iterations() { const long long n = mtgx::mtgx_iteration_count; mtgx::mtgx_iteration_count = 0; return n; }
+
+// diagnostics: [32][16] rounds per (level, pair slot) of the LAST segment searched; cleared on read
+extern "C" void extrema_emu_trace(int* out) {
+  for (int k = 0; k < 32; ++k) for (int j = 0; j < 16; ++j) { out[k * 16 + j] = mtgx::mtgx_trace[k][j]; mtgx::mtgx_trace[k][j] = 0; }
 }

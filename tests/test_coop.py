@@ -1,0 +1,141 @@
+"""The row-cooperative form (csrc/mtg_coop.h / mtg_coop.hip): 16 lanes per trajectory-half, DPP row broadcasts inside the FMAs.
+CPU: the SAME header run on a 16-lane lock-step host emulation (tests/coop_emu.cpp) against the oracles and against the host
+build of the lane-per-half code (the product's other forms).  GPU: the kernel through the C ABI against the other launch forms,
+the oracle, ragged batch sizes, both input layouts, status flags."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import cpu_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so, src = os.path.join(ROOT, "tests", "libmtg_coop_emu.so"), os.path.join(ROOT, "tests", "coop_emu.cpp")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("mtg_coop.h", "mtg_lane.h", "mtg_tables.inc")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.coop_emu_solve.argtypes = [ctypes.c_int] * 4 + [ctypes.c_longlong, dp, dp, dp]
+    return lib
+
+
+def emu_solve(lib, n, k, deriv, times, d_fixed):
+    dp = ctypes.POINTER(ctypes.c_double)
+    t, f = np.ascontiguousarray(times), np.ascontiguousarray(d_fixed)
+    co = np.full((t.shape[0], k, 3, n), np.nan)
+    rc = lib.coop_emu_solve(n, k, 3, deriv, t.shape[0], t.ctypes.data_as(dp), f.ctypes.data_as(dp), co.ctypes.data_as(dp))
+    return rc, co
+
+
+@pytest.mark.parametrize("n", [8, 10, 12])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 8, 9, 16, 17, 33, 64])
+def test_emulated_rows_vs_oracle_and_lane_code(emu, n, k):
+    """Every parity combination of the two half-chains (K even / odd, half-chain lengths even / odd), the first-step special case
+    (K = 2: nothing but end steps), long chains: against the C++ restatement of the reference (float64 evaluation error of the
+    reference's formulas: 1e-10 for N = 10, 1e-8 for N = 12) and, tightly, against the host build of the product's lane code."""
+    d = n // 2 - 1
+    masks, times, d_fixed = helpers.reference_batch(5, k, n, 3, 1000 + 10 * n + k)
+    rc, co = emu_solve(emu, n, k, d, times, d_fixed)
+    assert rc == 0 and np.isfinite(co).all()
+    ref = cpu_ref.solve_batch(n, d, masks, times, d_fixed)[0]
+    assert helpers.poly_relerr(co, ref) < {8: 1e-10, 10: 2e-9, 12: 5e-6}[n]   # (N = 12: the float64 restatement is the side that is off)
+    lane = ctypes.CDLL(os.path.join(ROOT, "tests", "libmtg_host_emu.so"))
+    _, co_lane, _, _, st = helpers.emu_run(lane, n, 3, k, d, masks, times, d_fixed, want_cost=False)
+    assert st == 0 and helpers.poly_relerr(co, co_lane) < (1e-11 if n <= 10 else 1e-9)   # (another elimination order: round-off x cond)
+
+
+def test_emulated_rows_other_derivatives_and_flags(emu):
+    """derivative_to_optimize below h - 1 (run-time exponent path), a non-positive segment time (flag 1)."""
+    masks, times, d_fixed = helpers.reference_batch(4, 6, 10, 3, 77)
+    for d in (2, 3):
+        rc, co = emu_solve(emu, 10, 6, d, times, d_fixed)
+        ref = cpu_ref.solve_batch(10, d, masks, times, d_fixed)[0]
+        assert rc == 0 and helpers.poly_relerr(co, ref) < 1e-6
+    bad = times.copy()
+    bad[2, 4] = -1.0
+    rc, _ = emu_solve(emu, 10, 6, 4, bad, d_fixed)
+    assert rc & 1
+
+
+def test_no_dpp_hazard_in_the_compiled_kernel(tmp_path):
+    """The kernel's v_fmac_f64_dpp are inline asm, which the compiler's hazard recogniser does not see: the gfx9 rule "VALU writes
+    a VGPR -> DPP reads it: 2 wait states" is checked on the emitted code (tools/check_dpp_hazards.py)."""
+    out = str(tmp_path / "coop.s")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result",
+                           "--cuda-device-only", "-S", os.path.join(CSRC, "mtg_coop.hip"), "-o", out])
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "check_dpp_hazards.py"), out, "coop"], capture_output=True, text=True)
+    assert r.returncode == 0 and "DPP hazard check: ok" in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("DPP") >= 3          # three instantiations with DPP instructions were inspected
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import mav_trajectory_generation_amd as m
+    c = m.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 10, 12])
+@pytest.mark.parametrize("k", [2, 3, 5, 8, 16, 17, 32, 50])
+@pytest.mark.parametrize("bsz,layout", [(1, "soa"), (3, "aos"), (4, "soa"), (301, "aos"), (2500, "soa")])
+def test_gpu_cooperative_form_vs_other_forms(ctx, n, k, bsz, layout):
+    import torch
+    import mav_trajectory_generation_amd as m
+    d = n // 2 - 1
+    masks = m.ends_full_masks(n, k, 1)
+    plan = m.Plan(ctx, n, 3, k, d, masks)
+    assert plan.launch_form(bsz, layout, "coop") == "coop"
+    t, f = m.random_waypoint_batch(bsz, k, 3, n, masks, seed=17 * n + k, device="cuda", layout=layout)
+    co = torch.full((bsz + 1, k, 3, n), float("nan"), dtype=torch.float64, device="cuda")
+    co[bsz] = 7.0
+    plan.solve(t, f, layout=layout, coeffs=co[:bsz], dims="coop")
+    ref, _, _ = plan.solve(t, f, layout=layout)
+    ctx.sync()
+    assert plan.launch_form(bsz, layout) != "coop"
+    assert torch.isfinite(co[:bsz]).all() and float(co[bsz].min()) == 7.0 and float(co[bsz].max()) == 7.0
+    rel, _ = ctx.compare_coefficients(co[:bsz].contiguous(), ref)
+    assert rel < (1e-11 if n <= 10 else 1e-9), rel
+    nb = min(bsz, 4)
+    th = (t[:, :nb].t() if layout == "soa" else t[:nb]).contiguous().cpu().numpy()
+    fh = (f[:, :, :nb].permute(2, 0, 1) if layout == "soa" else f[:nb]).contiguous().cpu().numpy()
+    from oracle import oracle_np as onp
+    c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
+    assert helpers.poly_relerr(co[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cooperative_form_status_and_eligibility(ctx):
+    import torch
+    import mav_trajectory_generation_amd as m
+    masks = m.ends_full_masks(10, 20)
+    plan = m.Plan(ctx, 10, 3, 20, 4, masks)
+    t, f = m.random_waypoint_batch(50, 20, 3, 10, masks, seed=3, device="cuda", layout="soa")
+    bad = {4: 0, 17: 9, 33: 10, 49: 19}
+    for b, seg in bad.items():
+        t[seg, b] = 0.0
+    st = torch.full((50,), 77, dtype=torch.int32, device="cuda")
+    plan.solve(t, f, layout="soa", traj_status=st, dims="coop")
+    with pytest.raises(m.MtgError) as e:
+        ctx.sync()
+    assert e.value.code == -2
+    assert sorted(np.nonzero(st.cpu().numpy() & 1)[0].tolist()) == sorted(bad)
+    plan.close()
+    # not eligible: other constraint patterns, four dimensions, extra outputs -> the flag falls back to the ordinary choice
+    p5 = m.Plan(ctx, 10, 4, 16, 4, m.ends_full_masks(10, 16, 7))
+    assert p5.launch_form(100, "soa", "coop") != "coop"
+    p5.close()
+    p = m.Plan(ctx, 10, 3, 16, 4, m.ends_full_masks(10, 16, 1))
+    assert p.launch_form(100, "soa", "coop", extra_outputs=True) != "coop"
+    p.close()
