@@ -134,7 +134,12 @@ def test_latency_form_and_config4_lines():
     # parity of the timed launch per polynomial order; the request is pre-built outside the timed region and says so
     par = out["parity"]
     assert par["ok"] and set(par["per_n"]) == {"8", "10", "12"} and all(v["n"] >= 512 for v in par["per_n"].values()), par
-    assert par["per_n"]["8"]["max_rel_err_vs_port"] <= 1e-9 and par["per_n"]["10"]["max_rel_err_vs_port"] <= 1e-9
+    # N <= 10 within 1e-9 of both oracles -- or, for the rare long ill-conditioned N = 10 chain on which the float64 oracles are
+    # themselves ~1e-8 off, within 1e-9 of the 50-digit solution (the bench arbitrates every sample above the tolerance)
+    assert par["per_n"]["8"]["max_rel_err_vs_port"] <= 1e-9 and par["per_n"]["10"]["ok"]
+    if par["per_n"]["10"]["max_rel_err_vs_port"] > 1e-9:
+        arb = par["above_tol_arbitrated_by_the_50_digit_solution"]
+        assert arb and all(a["gpu_vs_50_digit_solution"] <= 1e-9 for a in arb), arb
     assert out["request_build"]["outside_timed_region"] and out["request_build"]["host_us"] > 0
     assert 0 < out["request_build"]["value_including_request_build"] < out["value"]
     assert out["value_other_form"]["sequence"] == "launches" and out["value_other_form"]["value"] > 0
