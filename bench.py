@@ -417,6 +417,31 @@ class MixedLoop:
         return [b["coeffs"] for s in self.sets for b in s]
 
 
+FP64_VALU_PEAK = {"simds": 1024, "clock_hz": 2.4e9, "cycles_per_wave_instruction": 4.0, "tflops": 78.6}
+
+
+def fp64_issue_roofline(row, us, B):
+    """The compute-bound (f) rows against the FP64 VECTOR peak: one VALU instruction per 4 cycles and SIMD (for FMAs: 78.6 TFLOP/s,
+    /opt/skills/guides/MI355X_MICROARCH.md).  VALU instructions per call from the committed rocprofv3 PMC pass of the same row at
+    this size (profiles/r04_next_rows_pmc.json, tools/gpu_profile_rows.sh: its own profiling run); the duration is this run's."""
+    path = os.path.join(ROOT, "profiles", "r04_next_rows_pmc.json")
+    if B != 10_000 or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path)).get(row)
+    except Exception:
+        return None
+    if not d or not d.get("valu_insts_per_call"):
+        return None
+    pk = FP64_VALU_PEAK
+    issue_s = d["valu_insts_per_call"] * pk["cycles_per_wave_instruction"] / (pk["simds"] * pk["clock_hz"])
+    frac = issue_s / (us * 1e-6)
+    return {"bound": "fp64", "peak": pk["tflops"], "unit": "TFLOP/s", "valu_instructions_per_call": d["valu_insts_per_call"],
+            "valu_issue_us_at_peak": issue_s * 1e6, "frac": frac, "achieved": frac * pk["tflops"],
+            "achieved_is": "upper bound: as if every VALU instruction were an FP64 FMA (64 lanes x 2 flops)",
+            "counters_from": os.path.relpath(path, ROOT)}
+
+
 def next_rows(m, ctx, plan, sets, B, K, D, N):
     """SURVEY 8(f) rows on the config's batch (coefficients of buffer set 0): device durations from events on the library's
     stream, each with the roofline that bounds it."""
@@ -447,18 +472,19 @@ def next_rows(m, ctx, plan, sets, B, K, D, N):
     us_v = timed(lambda: m.minmax_magnitude(ctx, co, tt, 1), 5)
     out["extrema"] = {"what": f"{B} x {K} segments, velocity magnitude extrema (Trajectory::computeMinMaxMagnitude)", "us": us_v,
                       "segment_derivatives_per_s": B * K / us_v * 1e6,
-                      "roofline": {"bound": "fp64 issue (DESIGN.md 4b: ~4e4 VALU instructions per wave, 272 B per lane)",
-                                   "hbm_frac": B * K * (D * N * 8 + 32) / us_v * 1e-3 / HBM_PEAK_GBS}}
+                      "roofline": fp64_issue_roofline("extrema", us_v, B) or {"bound": "fp64", "frac": None},
+                      "hbm_frac": B * K * (D * N * 8 + 32) / us_v * 1e-3 / HBM_PEAK_GBS}
     us_s = timed(lambda: m.scale_segment_times_to_meet_constraints(ctx, co.clone(), tt.clone(), 2.0, 3.0), 3)
     out["time_scaling"] = {"what": f"{B} trajectories, scaleSegmentTimesToMeetConstraints(v_max 2, a_max 3), incl. the copies "
-                                   f"of its inputs", "us": us_s, "traj_per_s": B / us_s * 1e6}
+                                   f"of its inputs", "us": us_s, "traj_per_s": B / us_s * 1e6,
+                           "roofline": fp64_issue_roofline("time_scaling", us_s, B) or {"bound": "fp64", "frac": None}}
     # N2: Mellinger cost + gradient = (K + 1) x B perturbed-time cost-only solves in one launch
     lay = "soa" if t.shape[0] == K else "aos"
     us_m = timed(lambda: m.mellinger_cost_and_gradient(plan, t, f, layout=lay), 10)
     out["mellinger"] = {"what": f"{B} trajectories x {K + 1} perturbed-time cost-only solves (getCostAndGradientMellinger)",
                         "us": us_m, "solves_per_s": B * (K + 1) / us_m * 1e6,
-                        "roofline": {"bound": "fp64 issue (no coefficient output)",
-                                     "hbm_frac": B * (K + 1) * (K + D * plan.n_fixed + 1) * 8 / us_m * 1e-3 / HBM_PEAK_GBS}}
+                        "roofline": fp64_issue_roofline("mellinger", us_m, B) or {"bound": "fp64", "frac": None},
+                        "hbm_frac": B * (K + 1) * (K + D * plan.n_fixed + 1) * 8 / us_m * 1e-3 / HBM_PEAK_GBS}
     return out
 
 

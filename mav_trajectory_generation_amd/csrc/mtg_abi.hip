@@ -658,7 +658,7 @@ static bool coop_eligible(const mtg_plan* p, int64_t batch, const mtg_layout* L,
   if (L->times_stride_b < 0 || L->times_stride_k < 0 || L->fixed_stride_b < 0 || L->fixed_stride_d < 0 || L->fixed_stride_c < 0) return false;
   const int64_t tmax = (batch - 1) * L->times_stride_b + (int64_t)(p->K - 1) * L->times_stride_k;
   const int64_t fmax = (batch - 1) * L->fixed_stride_b + (int64_t)(p->D - 1) * L->fixed_stride_d + (int64_t)(p->n_fixed - 1) * L->fixed_stride_c;
-  return tmax * 8 < (1ll << 32) && fmax * 8 < (1ll << 32);
+  return tmax * 8 < (1ll << 32) && fmax * 8 < (1ll << 32) && batch * p->K * p->D * p->N * 8 < (1ll << 32);
 }
 static bool pick_coop(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P, uint32_t flags, bool cost_only) {
   if (p->ctx->knob_coop == 0 || !coop_eligible(p, batch, L, P, cost_only)) return false;

@@ -215,7 +215,7 @@ struct Coop {
 
   // ---- one backward step (parity PI as in the forward step): back-substitution of the LEFT vertex, then the coefficients of the
   // step's segment.  load(k): value k of the step's saved data (LEFT lanes).  DIR > 0: the LEFT vertex is the segment's start.
-  // store(dm, value): coefficient `lane` of dimension dm (lanes < N).
+  // store(values[D]): coefficient `lane` of every dimension (lanes < N).
   template <int PI, bool FIRST, int DIR, class Load, class Store>
   MTG_HD void backward_step(V T, int deriv, const V (&fixl)[D][H], const V (&posr)[D], Load&& load, Store&& store) {
     constexpr int GL = PI, GR = 1 - PI;
@@ -244,6 +244,17 @@ struct Coop {
     for (int dm = 0; dm < D; ++dm) sx[dm] = O::mul(so, x[dm]);
     O::settle_vec(sx);
     constexpr int KL = DIR > 0 ? 0 : H, KR = DIR > 0 ? H : 0;   // table columns of the LEFT / RIGHT vertex's derivatives
+    // T^-lane (the coefficient's power), once for all dimensions
+    V tp = O::sel(bit[0], tinv, O::splat(1.0));
+    const V t2 = O::mul(tinv, tinv);
+    tp = O::mul(tp, O::sel(bit[1], t2, O::splat(1.0)));
+    const V t4 = O::mul(t2, t2);
+    tp = O::mul(tp, O::sel(bit[2], t4, O::splat(1.0)));
+    if constexpr (N > 8) {
+      const V t8 = O::mul(t4, t4);
+      tp = O::mul(tp, O::sel(bit[3], t8, O::splat(1.0)));
+    }
+    V cf[D];
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
       V acc = O::mul(ai[KR], posr[dm]);
@@ -257,16 +268,9 @@ struct Coop {
       }
 #pragma unroll
       for (int q = 0; q < F; ++q) fmac_from<GR>(q, acc, sx[dm], ai[KR + q + 1]);
-      // T^-lane
-      V tp = O::sel(bit[0], tinv, O::splat(1.0));
-      V t2 = O::mul(tinv, tinv);
-      tp = O::mul(tp, O::sel(bit[1], t2, O::splat(1.0)));
-      V t4 = O::mul(t2, t2);
-      tp = O::mul(tp, O::sel(bit[2], t4, O::splat(1.0)));
-      V t8 = O::mul(t4, t4);
-      tp = O::mul(tp, O::sel(bit[3], t8, O::splat(1.0)));
-      store(dm, O::mul(acc, tp));
+      cf[dm] = O::mul(acc, tp);
     }
+    store(cf);
   }
 
  private:
@@ -292,7 +296,7 @@ struct Coop {
 // IO (one 16-lane row = one trajectory-half):
 //   V time(int seg); V fixed(int dm, int col);                  inputs (the same value in every lane of the row)
 //   void save(int j, int k, V); V load(int j, int k);           step storage
-//   void store(int seg, int dm, V);                             coefficient `lane` of (seg, dm)
+//   void store(int seg, const V (&)[D]);                        coefficient `lane` of every dimension of segment seg
 // Standard shapes: end vertices fix all h derivatives (columns 0 .. h-1 and the last h), interior vertices the position.
 template <int H>
 MTG_HD int coop_col_of_vertex(int K, int v) { return v == 0 ? 0 : (v == K ? H + (K - 1) : H + (v - 1)); }
@@ -318,13 +322,28 @@ MTG_HD void coop_forward(Coop<O, H, D>& cp, IO& io, int K, int kc, int deriv, ty
     if (p0 == 0) cp.template forward_step<0, true>(T, (double)DIR, deriv, fixl, posr, save);
     else cp.template forward_step<1, true>(T, (double)DIR, deriv, fixl, posr, save);
   }
+  // the inputs of step j + 1 (segment time, right vertex position) are requested while step j is eliminated: a step is ~1000
+  // cycles of dependent arithmetic, a load from L2 / HBM 500-900 -- and the form exists for launches too small to hide it
+  V Tn = O::splat(1.0), posn[D];
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) posn[dm] = O::splat(0.0);
+  if (kc > 1) {
+    Tn = io.time(mtg_seg<DIR>(K, 1));
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) posn[dm] = io.fixed(dm, coop_col_of_vertex<H>(K, mtg_vr<DIR>(K, 1)));
+  }
   for (int j = 1; j < kc; ++j) {
-    const V T = io.time(mtg_seg<DIR>(K, j));
-    const int cr = coop_col_of_vertex<H>(K, mtg_vr<DIR>(K, j));
+    const V T = Tn;
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
       fixl[dm][0] = posr[dm];
-      posr[dm] = io.fixed(dm, cr);
+      posr[dm] = posn[dm];
+    }
+    if (j + 1 < kc) {
+      Tn = io.time(mtg_seg<DIR>(K, j + 1));
+      const int cn = coop_col_of_vertex<H>(K, mtg_vr<DIR>(K, j + 1));
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) posn[dm] = io.fixed(dm, cn);
     }
     auto save = [&](int k, V v) { io.save(j, k, v); };
     if (((j + p0) & 1) == 0) cp.template forward_step<0, false>(T, (double)DIR, deriv, fixl, posr, save);
@@ -341,14 +360,23 @@ MTG_HD void coop_backward(Coop<O, H, D>& cp, IO& io, int K, int kc, int deriv, c
   V fixl[D][H], posr[D];
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) posr[dm] = posm[dm];
+  // (inputs one step ahead, as in the forward sweep; the last prefetch is step 0's time -- its end-vertex values follow below)
+  V Tn = io.time(mtg_seg<DIR>(K, kc - 1)), posn[D];
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) posn[dm] = kc > 1 ? io.fixed(dm, coop_col_of_vertex<H>(K, mtg_vl<DIR>(K, kc - 1))) : O::splat(0.0);
   for (int j = kc - 1; j >= 1; --j) {
     const int seg = mtg_seg<DIR>(K, j);
-    const V T = io.time(seg);
-    const int cl = coop_col_of_vertex<H>(K, mtg_vl<DIR>(K, j));
+    const V T = Tn;
 #pragma unroll
-    for (int dm = 0; dm < D; ++dm) fixl[dm][0] = io.fixed(dm, cl);
+    for (int dm = 0; dm < D; ++dm) fixl[dm][0] = posn[dm];
+    Tn = io.time(mtg_seg<DIR>(K, j - 1));
+    if (j > 1) {
+      const int cn = coop_col_of_vertex<H>(K, mtg_vl<DIR>(K, j - 1));
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) posn[dm] = io.fixed(dm, cn);
+    }
     auto load = [&](int k) { return io.load(j, k); };
-    auto store = [&](int dm, V v) { io.store(seg, dm, v); };
+    auto store = [&](const V (&v)[D]) { io.store(seg, v); };
     if (((j + p0) & 1) == 0) cp.template backward_step<0, false, DIR>(T, deriv, fixl, posr, load, store);
     else cp.template backward_step<1, false, DIR>(T, deriv, fixl, posr, load, store);
 #pragma unroll
@@ -356,7 +384,7 @@ MTG_HD void coop_backward(Coop<O, H, D>& cp, IO& io, int K, int kc, int deriv, c
   }
   {   // step 0: the trajectory's end vertex
     const int seg = mtg_seg<DIR>(K, 0);
-    const V T = io.time(seg);
+    const V T = Tn;
     const int cl = coop_col_of_vertex<H>(K, mtg_vl<DIR>(K, 0));
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
@@ -364,7 +392,7 @@ MTG_HD void coop_backward(Coop<O, H, D>& cp, IO& io, int K, int kc, int deriv, c
       for (int k = 0; k < H; ++k) fixl[dm][k] = io.fixed(dm, cl + k);
     }
     auto load = [&](int) { return O::splat(0.0); };
-    auto store = [&](int dm, V v) { io.store(seg, dm, v); };
+    auto store = [&](const V (&v)[D]) { io.store(seg, v); };
     if (p0 == 0) cp.template backward_step<0, true, DIR>(T, deriv, fixl, posr, load, store);
     else cp.template backward_step<1, true, DIR>(T, deriv, fixl, posr, load, store);
   }

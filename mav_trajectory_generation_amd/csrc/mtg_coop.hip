@@ -80,6 +80,8 @@ struct DevIO {
   long long b;
   bool active;
   int l16;
+  bool store_lane;        // active trajectory and lane < N: this lane stores a coefficient
+  unsigned cb;            // byte offset of (this row's trajectory, coefficient `lane`) in coeffs
   unsigned tb, fb;        // byte offsets of this row's trajectory in times / d_fixed
   unsigned tsk, fsd, fsc; // byte strides (segment; dimension, column)
   int colE, colO;         // this lane's column of the step area at even / odd step parity (COLS - 1: the dump column)
@@ -96,8 +98,12 @@ struct DevIO {
   }
   __device__ __forceinline__ void save(int j, int k, double v) const { *slot(j, k) = v; }
   __device__ __forceinline__ double load(int j, int k) const { return *slot(j, k); }
-  __device__ __forceinline__ void store(int seg, int dm, double v) const {
-    if (active && l16 < N) P.coeffs[(((long long)b * P.K + seg) * D + dm) * N + l16] = v;
+  // (32-bit byte offset from the wave-uniform coefficient base: the launcher checks B K D N 8 < 4 GiB)
+  __device__ __forceinline__ void store(int seg, const double (&v)[D]) const {
+    if (!store_lane) return;
+    char* base = reinterpret_cast<char*>(P.coeffs) + (cb + (unsigned)seg * (unsigned)(D * N * 8));
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) *reinterpret_cast<double*>(base + dm * N * 8) = v[dm];
   }
 };
 
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(2 * kWave) void mtg_solve_coop_kernel(CoopParams P)
   double* steps = lds + 2 * coop_xch_doubles<H, D>() + (dir == 0 ? 0 : (size_t)KA * coop_step_doubles<H, D>());
   const int g = l16 >> 3, i = l16 & 7;
   const int col = row * F + i;
-  DevIO<H, D> io{P, b, active, l16, (unsigned)(b * P.ts_b * 8), (unsigned)(b * P.fs_b * 8), (unsigned)(P.ts_k * 8), (unsigned)(P.fs_d * 8),
+  DevIO<H, D> io{P, b, active, l16, active && l16 < N, (unsigned)((b * K * D * N + l16) * 8), (unsigned)(b * P.ts_b * 8), (unsigned)(b * P.fs_b * 8), (unsigned)(P.ts_k * 8), (unsigned)(P.fs_d * 8),
                  (unsigned)(P.fs_c * 8), (g == 0 && i < F) ? col : 4 * F, (g == 1 && i < F) ? col : 4 * F, (kc - 1) & 1, steps};
   mtgc::Coop<CoopDev, H, D> cp;
   const double* h1 = kH1 + mtg_h1_offset(N, P.deriv);
@@ -171,6 +177,7 @@ int mtg_coop_launch(void* stream, int H, int D, int K, int deriv, long long B, c
     const long long n_fixed = 2 * H + (K - 1);
     const long long tmax = (B - 1) * ts_b + (K - 1) * ts_k, fmax = (B - 1) * fs_b + (D - 1) * fs_d + (n_fixed - 1) * fs_c;
     if (ts_b < 0 || ts_k < 0 || fs_b < 0 || fs_d < 0 || fs_c < 0 || tmax * 8 >= (1ll << 32) || fmax * 8 >= (1ll << 32)) return 1;
+    if (B * K * D * (2ll * H) * 8 >= (1ll << 32)) return 1;
   }
   CoopParams P{times, ts_b, ts_k, dfix, fs_b, fs_d, fs_c, coeffs, status, tstatus, B, K, deriv};
   switch (H) {

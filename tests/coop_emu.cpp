@@ -54,7 +54,10 @@ struct EmuIO {
   V16 fixed(int dm, int col) { return EmuOps::splat(dfix[dm * n_fixed + col]); }
   void save(int j, int k, V16 v) { steps[(size_t)j * (F + D) + k] = v; }
   V16 load(int j, int k) { return steps[(size_t)j * (F + D) + k]; }
-  void store(int seg, int dm, V16 v) { for (int l = 0; l < N; ++l) coeffs[((size_t)seg * D + dm) * N + l] = v.v[l]; }
+  void store(int seg, const V16 (&v)[D]) {
+    for (int dm = 0; dm < D; ++dm)
+      for (int l = 0; l < N; ++l) coeffs[((size_t)seg * D + dm) * N + l] = v[dm].v[l];
+  }
 };
 
 template <int H, int D>

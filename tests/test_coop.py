@@ -104,8 +104,24 @@ def test_gpu_cooperative_form_vs_other_forms(ctx, n, k, bsz, layout):
     ctx.sync()
     assert plan.launch_form(bsz, layout) != "coop"
     assert torch.isfinite(co[:bsz]).all() and float(co[bsz].min()) == 7.0 and float(co[bsz].max()) == 7.0
-    rel, _ = ctx.compare_coefficients(co[:bsz].contiguous(), ref)
-    assert rel < (1e-11 if n <= 10 else 1e-9), rel
+    # two float64 eliminations in different orders differ by round-off x conditioning: 1e-12 typically, 1e-9 (N = 10) ... 1e-6
+    # (N = 12) on the rare ill-conditioned trajectory of a large batch (a very short segment between long ones) -- where the
+    # 50-digit solution says which side is off (on the CPU emulation of both codes: the cooperative form is the closer one)
+    num = (co[:bsz] - ref).abs().amax(dim=-1)
+    den = ref.abs().amax(dim=-1).clamp_min(1e-300)
+    per_traj = (num / den).reshape(bsz, -1).amax(dim=1)
+    rel = float(per_traj.max())
+    assert rel < (5e-9 if n <= 10 else 5e-6), rel
+    assert float(per_traj.median()) < (1e-12 if n <= 10 else 1e-10)
+    if rel > (1e-11 if n <= 10 else 1e-9):
+        from oracle import oracle_mp
+        w = int(per_traj.argmax())
+        tw = (t[:, w:w + 1].t() if layout == "soa" else t[w:w + 1]).contiguous().cpu().numpy()
+        fw = (f[:, :, w:w + 1].permute(2, 0, 1) if layout == "soa" else f[w:w + 1]).contiguous().cpu().numpy()
+        truth = np.asarray(oracle_mp.solve_batch(n, d, masks, tw, fw)[0], dtype=np.float64)
+        e_coop = helpers.poly_relerr(co[w:w + 1].cpu().numpy(), truth)
+        e_other = helpers.poly_relerr(ref[w:w + 1].cpu().numpy(), truth)
+        assert e_coop <= max(2.0 * e_other, 1e-11 if n <= 10 else 1e-9), (w, e_coop, e_other)
     nb = min(bsz, 4)
     th = (t[:, :nb].t() if layout == "soa" else t[:nb]).contiguous().cpu().numpy()
     fh = (f[:, :, :nb].permute(2, 0, 1) if layout == "soa" else f[:nb]).contiguous().cpu().numpy()
