@@ -641,13 +641,14 @@ static int workspace(mtg_plan* p, size_t need, double** out) {
 }
 
 // The row-cooperative form (mtg_coop.hip): standard shapes (end vertices fully fixed, position-only interior vertices), D = 3,
-// coefficient output only, non-negative strides, 32-bit input offsets, the step storage of the chain within one CU's LDS.
-// Default range: LAUNCHES THAT DO NOT FILL THE CHIP in the lane-per-half forms -- a chain step costs ~2.4x the lane-instructions
-// here, but four trajectory-halves share a wavefront instead of 21-64: kCoopMaxUnitsPerSimd x SIMDs wavefronts at most, chains of
-// at least kCoopMinSegments segments (shorter chains are launch-latency-bound in every form).
-constexpr bool kCoopDefault = false;    // (opt-in -- MTG_FLAG_COOPERATIVE / option "coop" -- until its cross-over is measured)
-constexpr int kCoopMinSegments = 16;
-constexpr int kCoopMaxWavesPerSimd = 2;
+// coefficient output only, non-negative strides, 32-bit input / output offsets, the step storage of the chain within one CU's LDS.
+// Default range = where it was measured faster than the lane-per-half forms (profiles/r04d_coop_vs_default.jsonl: 0.54-0.87 of
+// their time): LONG chains in launches of at most one 2-wave workgroup per CU -- a chain step costs ~2.4x the lane-instructions
+// here, but its latency is ~1.2 us against 1.8-2.6 us, and four trajectory-halves share a wavefront instead of 21-64.
+//   N = 12: K >= 16 (K >= 32: up to two workgroups per CU);  N = 10: K >= 64;  N = 8: K >= 80;
+//   workgroups (four trajectories each) <= CUs x that factor, and all of them resident at once (LDS).
+// MTG_FLAG_COOPERATIVE forces the form wherever it is eligible; option "coop" = 0 takes it out of the default choice, 1 makes
+// it the choice wherever eligible.
 static bool coop_eligible(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P, bool cost_only) {
   if (p->D != 3 || p->H < 4 || p->H > 6 || p->K < 2 || cost_only || P.dfree || P.cost || P.pert_on) return false;
   const int full = (1 << p->H) - 1;
@@ -661,12 +662,16 @@ static bool coop_eligible(const mtg_plan* p, int64_t batch, const mtg_layout* L,
   return tmax * 8 < (1ll << 32) && fmax * 8 < (1ll << 32) && batch * p->K * p->D * p->N * 8 < (1ll << 32);
 }
 static bool pick_coop(const mtg_plan* p, int64_t batch, const mtg_layout* L, const MtgParams& P, uint32_t flags, bool cost_only) {
-  if (p->ctx->knob_coop == 0 || !coop_eligible(p, batch, L, P, cost_only)) return false;
+  if (!coop_eligible(p, batch, L, P, cost_only)) return false;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_DIMLANE)) return false;
   if ((flags & MTG_FLAG_COOPERATIVE) || p->ctx->knob_coop == 1) return true;
-  if (!kCoopDefault) return false;
-  const int64_t waves = 2 * ((batch + 3) / 4);
-  return p->K >= kCoopMinSegments && waves <= (int64_t)kCoopMaxWavesPerSimd * 4 * p->ctx->n_cu;
+  if (p->ctx->knob_coop == 0 || p->ctx->knob_dl_rt == 1) return false;   // (option "dl_rt" = 1 asks for the run-time-K body)
+  const int kmin = p->H == 6 ? 16 : (p->H == 5 ? 64 : 80);
+  if (p->K < kmin) return false;
+  const int64_t wgs = (batch + 3) / 4;
+  const int64_t resident = (int64_t)(160 * 1024 / mtg_coop_lds_bytes(p->H, p->D, p->K));   // workgroups per CU the LDS holds
+  const int64_t per_cu = std::min<int64_t>((p->H == 6 && p->K >= 32) ? 2 : 1, resident);
+  return wgs <= per_cu * p->ctx->n_cu;
 }
 
 // Which form a call takes: the run-time-K dimension-in-lane body where the plan has no static variant, the static

@@ -120,32 +120,41 @@ struct Coop {
 
   // ---- elimination of pivot J of the PI-group rows from every row (Gauss-Jordan) -------------------------------------------------
   // BL: the pivot vertex's column block, BR: the other vertex's (NR = F columns, or 0 at the middle vertex).
+  // r: 1 / (own element of the pivot column), computed by the caller (for pivot J + 1 right after the FIRST update of pivot J's
+  // batch has made that column final: the reciprocal's dependent chain runs under the rest of the batch); rnext: the same for
+  // the next pivot, on return.
   template <int PI, int J, int NR>
-  MTG_HD void pivot(V (&BL)[F], V (&BR)[F], V& rkeep) {
+  MTG_HD void pivot(V (&BL)[F], V (&BR)[F], V& rkeep, V r, V& rnext) {
     constexpr int L = PI * kGroup + J;
     const P mine = O::pand(PI == 0 ? in_g0 : in_g1, is_i[J]);
-    const V d = BL[J];
-    flag_singular = O::por(flag_singular, O::pand(mine, O::not_gt0(d)));
-    V r = O::rcp(d);                       // meaningful in lane L only
+    flag_singular = O::por(flag_singular, O::pand(mine, O::not_gt0(BL[J])));
     rkeep = O::sel(mine, r, rkeep);
     O::settle(r);                          // (device: the DPP read below must not follow r's VALU write within two wait states)
     V m = O::splat(0.0);
     O::template fmac_bcast<L>(m, r, BL[J]);   // m = (1 / pivot) * own element of the pivot column
     m = O::sel(mine, O::splat(0.0), O::neg(m));
+    rnext = r;
+    if constexpr (J + 1 < F) {
+      O::template fmac_bcast<L>(BL[J + 1], BL[J + 1], m);
+      rnext = O::rcp(BL[J + 1]);             // the next pivot's column is final now
+    }
 #pragma unroll
-    for (int c = J + 1; c < F; ++c) O::template fmac_bcast<L>(BL[c], BL[c], m);
+    for (int c = J + 2; c < F; ++c) O::template fmac_bcast<L>(BL[c], BL[c], m);
 #pragma unroll
     for (int c = 0; c < NR; ++c) O::template fmac_bcast<L>(BR[c], BR[c], m);
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) O::template fmac_bcast<L>(R[dm], R[dm], m);
   }
   template <int PI, int NR, int J = 0>
-  MTG_HD void eliminate(V (&BL)[F], V (&BR)[F], V& rkeep) {
+  MTG_HD void eliminate(V (&BL)[F], V (&BR)[F], V& rkeep, V r) {
     if constexpr (J < F) {
-      pivot<PI, J, NR>(BL, BR, rkeep);
-      eliminate<PI, NR, J + 1>(BL, BR, rkeep);
+      V rnext;
+      pivot<PI, J, NR>(BL, BR, rkeep, r, rnext);
+      eliminate<PI, NR, J + 1>(BL, BR, rkeep, rnext);
     }
   }
+  template <int PI, int NR>
+  MTG_HD void eliminate(V (&BL)[F], V (&BR)[F], V& rkeep) { eliminate<PI, NR, 0>(BL, BR, rkeep, O::rcp(BL[0])); }
 
   // ---- one forward step.  PI: parity of the step (LEFT vertex rows = group PI, its columns = block PI).
   // FIRST: the left vertex is the trajectory's end vertex (all h derivatives fixed: no rows, right-hand-side terms only).
@@ -254,22 +263,30 @@ struct Coop {
       const V t8 = O::mul(t4, t4);
       tp = O::mul(tp, O::sel(bit[3], t8, O::splat(1.0)));
     }
+    // (source lane outermost, the D accumulators innermost: the broadcast-FMAs are volatile asm and issue in program order --
+    // D independent chains interleave instead of one dependent chain per dimension)
     V cf[D];
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) {
-      V acc = O::mul(ai[KR], posr[dm]);
+      cf[dm] = O::mul(ai[KR], posr[dm]);
       if constexpr (FIRST) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) acc = O::fma(O::mul(ai[KL + k], s[k]), fixl[dm][k], acc);
+        for (int k = 0; k < H; ++k) cf[dm] = O::fma(O::mul(ai[KL + k], s[k]), fixl[dm][k], cf[dm]);
       } else {
-        acc = O::fma(ai[KL], fixl[dm][0], acc);
+        cf[dm] = O::fma(ai[KL], fixl[dm][0], cf[dm]);
+      }
+    }
 #pragma unroll
-        for (int q = 0; q < F; ++q) fmac_from<GL>(q, acc, sx[dm], ai[KL + q + 1]);
+    for (int q = 0; q < F; ++q) {
+      if constexpr (!FIRST) {
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) fmac_from<GL>(q, cf[dm], sx[dm], ai[KL + q + 1]);
       }
 #pragma unroll
-      for (int q = 0; q < F; ++q) fmac_from<GR>(q, acc, sx[dm], ai[KR + q + 1]);
-      cf[dm] = O::mul(acc, tp);
+      for (int dm = 0; dm < D; ++dm) fmac_from<GR>(q, cf[dm], sx[dm], ai[KR + q + 1]);
     }
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) cf[dm] = O::mul(cf[dm], tp);
     store(cf);
   }
 

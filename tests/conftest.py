@@ -9,6 +9,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The form-equivalence tests of this suite (bit-identity of queue / cross-structure launches with single launches, tight form-vs-
+# form tolerances) were written for the lane-per-half forms; the row-cooperative form (another elimination order: round-off-level
+# differences) has its own tests (tests/test_coop.py, which re-enable its default range on a context of their own).  The library
+# itself reads no environment: the Python layer forwards this variable as the context option "coop".
+os.environ.setdefault("MTG_COOP", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -132,6 +132,36 @@ def test_gpu_cooperative_form_vs_other_forms(ctx, n, k, bsz, layout):
 
 
 @pytest.mark.gpu
+def test_gpu_cooperative_form_default_range(ctx):
+    """Where the form is the DEFAULT (measured: profiles/r04d_coop_vs_default.jsonl): long chains in launches of at most one
+    workgroup (four trajectories) per CU; results as accurate as any other form's."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    c = m.Context(0)
+    c.set_option("coop", -1)          # (tests/conftest.py takes the form out of the default choice for the other suites)
+    try:
+        for (n, k, bsz, want) in ((12, 16, 4 * cus, True), (12, 16, 4 * cus + 1, False), (12, 32, 8 * cus, True), (12, 15, 64, False),
+                                  (10, 100, 4 * cus, True), (10, 50, 64, False), (10, 64, 100, True), (8, 100, 200, True),
+                                  (8, 64, 200, False), (10, 100, 100_000, False)):
+            plan = m.Plan(c, n, 3, k, n // 2 - 1, m.ends_full_masks(n, k, 1))
+            assert (plan.launch_form(bsz) == "coop") == want, (n, k, bsz, plan.launch_form(bsz))
+            plan.close()
+        masks = m.ends_full_masks(12, 24, 1)
+        plan = m.Plan(c, 12, 3, 24, 5, masks)
+        t, f = m.random_waypoint_batch(500, 24, 3, 12, masks, seed=9, device="cuda", layout="aos")
+        co, _, _ = plan.solve(t, f)                       # default choice: the cooperative form
+        assert plan.launch_form(500, "aos") == "coop"
+        c.sync()
+        from oracle import oracle_np as onp
+        c_lit, _, _ = onp.solve_batch(12, 5, masks, t[:6].cpu().numpy(), f[:6].cpu().numpy())
+        assert helpers.poly_relerr(co[:6].cpu().numpy(), c_lit) < 5e-7
+        plan.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_cooperative_form_status_and_eligibility(ctx):
     import torch
     import mav_trajectory_generation_amd as m
