@@ -21,6 +21,7 @@
  *   "rolled_wg_per_cu" >= 1 (default 4)            persistent workgroups per CU of the rolled kernels
  *   "dl_max_units"     -1 default, >= 0            upper limit of the dimension-in-lane default range (x CUs)
  *   "coop"             -1 default, 0 never, 1 always   row-cooperative form where eligible
+ *   "extrema_split"    -1 default, 1 / 2           lanes that share one root search of the extrema kernels
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
  *   "dl_stagger"       -1 default, >= 0            every second workgroup of a single dimension-in-lane launch starts
  *                                                  value x 2048 shader cycles late (default: 8 for the workspace hybrids in

@@ -111,6 +111,7 @@ ENV_OPTIONS = {
     "MTG_SLAB_POLICY": ("slab_policy", lambda e: 1 if int(e) else 0), "MTG_ROLLED_WG_PER_CU": ("rolled_wg_per_cu", int),
     "MTG_DL_MAX_UNITS": ("dl_max_units", int), "MTG_SAMPLE_GENERIC": ("sample_generic", _flag),
     "MTG_DL_STAGGER": ("dl_stagger", int), "MTG_COOP": ("coop", int),
+    "MTG_EXTREMA_SPLIT": ("extrema_split", int),
 }
 
 FLAG_HOST_POINTERS = 1

@@ -130,6 +130,7 @@ struct mtg_context {
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
+  int knob_extrema_split = -1;       // MTG_EXTREMA_SPLIT: lanes per root search of the extrema kernels (1 / 2; -1: by launch size)
   int knob_coop = -1;                // MTG_COOP: 1 always / 0 never take the row-cooperative form where eligible (default: by size)
   int knob_dl_stagger = -1;          // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
                                      // (-1: the default -- kDlStaggerWorkspace for the workspace hybrids in multi-round launches, else 0)
@@ -300,13 +301,15 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   else if (n == "dl_max_units") ctx->dl_max_units_per_cu = value;
   else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
   else if (n == "coop") ctx->knob_coop = value;
+  else if (n == "extrema_split") ctx->knob_extrema_split = value;
   else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(-1, std::min(value, 1 << 20));
   else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
   return MTG_OK;
 }
 
-// (mtg_sample.hip)
+// (mtg_sample.hip, mtg_extrema.hip)
 bool mtg_context_sample_generic(const mtg_context* ctx) { return ctx && ctx->knob_sample_generic; }
+int mtg_context_extrema_split(const mtg_context* ctx) { return ctx ? ctx->knob_extrema_split : -1; }
 
 int mtg_context_destroy(mtg_context* ctx) {
   if (!ctx) return MTG_OK;

@@ -16,6 +16,8 @@
 #include "../../include/mtg_hip.h"
 #include "mtg_extrema_lane.h"
 
+extern "C" int mtg_context_extrema_split(const mtg_context* ctx);   // measurement knob "extrema_split" (mtg_hip_lab.h): -1 auto
+
 namespace {
 
 constexpr int kThreads = 128;   // two root buffers of L - 1 doubles per lane in LDS: 128 x 2 x 21 x 8 B = 43 KB at most
@@ -31,26 +33,34 @@ struct ExtremaParams {
   int N, K, D;
   unsigned mask;
   int der[2];
+  int split;              // lanes that share one root search (launch_seg): 1, or 2 for small launches
 };
 
+template <int COLS>
 struct LdsRoots {
-  double* p;   // lane's column: element i at p[i * kThreads]
-  __device__ double& operator[](int i) { return p[i * kThreads]; }
+  double* p;   // the search's column: element i at p[i * COLS]
+  __device__ double& operator[](int i) { return p[i * COLS]; }
 };
 
-template <int NMAX>
+// SPLIT lanes share one (trajectory, segment) root search (mtg_extrema_lane.h, Share): small launches are bound by the latency
+// of one lane's chain of refinements -- 10k x 8 segments are 1250 wavefronts, ~1.2 per SIMD -- and two lanes halve it.  The
+// lanes of a search are neighbours in one wavefront and address the same LDS column; lane `part` 0 writes the result.
+template <int NMAX, int SPLIT>
 __global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
   extern __shared__ double lds[];
+  constexpr int COLS = kThreads / SPLIT;
   const long long total = P.B * P.K;
-  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const long long idx = ((long long)blockIdx.x * kThreads + threadIdx.x) / SPLIT;
+  const int part = threadIdx.x % SPLIT;
   if (idx >= total) return;
   const int slot = blockIdx.y;
   const long long b = idx / P.K;
   const int seg = (int)(idx - b * P.K);
   const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
-  LdsRoots roots{lds + threadIdx.x};
-  const mtgx::MinMax mm =
-      mtgx::segment_minmax<NMAX>(P.coeffs + idx * (long long)(P.D * P.N), P.N, P.D, P.mask, P.der[slot], T, roots);
+  LdsRoots<COLS> roots{lds + threadIdx.x / SPLIT};
+  const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(P.coeffs + idx * (long long)(P.D * P.N), P.N, P.D, P.mask, P.der[slot], T, roots,
+                                                     mtgx::Share{part, part + 1, SPLIT});
+  if (part != 0) return;
   double* o = P.seg_out + ((long long)slot * total + idx) * 4;
   reinterpret_cast<double2*>(o)[0] = make_double2(mm.t_min, mm.v_min);
   reinterpret_cast<double2*>(o)[1] = make_double2(mm.t_max, mm.v_max);
@@ -159,12 +169,20 @@ template <int NMAX>
 void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   constexpr int L = 2 * NMAX - 2;
   const long long total = P.B * P.K;
-  const size_t lds = (size_t)kThreads * 2 * (L - 1) * sizeof(double);   // two root buffers per lane (mtg_extrema_lane.h)
-  hipLaunchKernelGGL(mtg_minmax_seg_kernel<NMAX>, dim3((unsigned)((total + kThreads - 1) / kThreads), n_slots),
-                     dim3(kThreads), lds, stream, P);
+  if (P.split == 2) {
+    const size_t lds = (size_t)(kThreads / 2) * 2 * (L - 1) * sizeof(double);
+    hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2>), dim3((unsigned)((2 * total + kThreads - 1) / kThreads), n_slots), dim3(kThreads), lds, stream, P);
+  } else {
+    const size_t lds = (size_t)kThreads * 2 * (L - 1) * sizeof(double);   // two root buffers per lane (mtg_extrema_lane.h)
+    hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1>), dim3((unsigned)((total + kThreads - 1) / kThreads), n_slots), dim3(kThreads), lds, stream, P);
+  }
 }
 
-int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream) {
+// Two lanes per search while the launch is small: searches x slots <= kSplitMaxSearches (~1.5 per SIMD lane of the chip).  Beyond
+// that the chip is full either way and the shared form's repeated phase A (+ ~20 % instructions) costs more than it hides.
+constexpr long long kSplitMaxSearches = 96 * 1024;
+int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int split_option) {
+  P.split = split_option == 1 || split_option == 2 ? split_option : (P.B * P.K * n_slots <= kSplitMaxSearches ? 2 : 1);
   int n_d = 0;
   for (int s = 0; s < n_slots; ++s) {
     const int nd = P.N - P.der[s];
@@ -215,7 +233,7 @@ extern "C" int mtg_minmax_magnitude(mtg_context* ctx, int32_t n_coeffs, int32_t 
   P.seg_out = segment_minmax; P.traj_out = trajectory_minmax; P.traj_seg = trajectory_minmax ? trajectory_segment_idx : nullptr;
   P.B = batch; P.N = n_coeffs; P.K = n_segments; P.D = dimension; P.mask = dimension_mask;
   P.der[0] = derivative; P.der[1] = derivative;
-  return launch_minmax(P, 1, (hipStream_t)stream);
+  return launch_minmax(P, 1, (hipStream_t)stream, mtg_context_extrema_split(ctx));
 }
 
 extern "C" int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int32_t n_coeffs, int32_t n_segments,
@@ -246,7 +264,7 @@ extern "C" int mtg_scale_segment_times_to_meet_constraints(mtg_context* ctx, int
   S.scaling = scaling; S.within = within_range; S.B = batch; S.N = n_coeffs; S.K = n_segments; S.D = dimension;
   S.v_max = v_max; S.a_max = a_max; S.max_iterations = max_iterations;
   // ONE root search (velocity and acceleration in one launch), then the whole check / stretch loop analytically (mtg_scale_loop)
-  rc = launch_minmax(P, 2, (hipStream_t)stream);
+  rc = launch_minmax(P, 2, (hipStream_t)stream, mtg_context_extrema_split(ctx));
   if (rc != MTG_OK) return rc;
   const long long total = (long long)batch * n_segments * dimension;
   hipLaunchKernelGGL(mtg_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S);

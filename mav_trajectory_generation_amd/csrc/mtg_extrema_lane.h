@@ -182,9 +182,17 @@ MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, doub
 // other lane's j-th bracket -- the wave runs max-over-lanes(brackets) / 2 refinements per level, not one per interval that has
 // a sign change in ANY lane): (A) evaluate this level at every partition point, two points at a time, and note the
 // intervals with a sign change in a bit mask; (B) refine them two at a time.
+// Several lanes may SHARE one root search (small launches: the per-lane chain of refinements is the latency of the whole
+// kernel).  All of them run phase A -- identical arithmetic, identical bit mask -- and refine only the brackets whose rank
+// (position among the level's sign changes) falls to them: rank mod nparts in [part_begin, part_end).  Every root is written to
+// its rank's slot of the shared root buffer, which the lanes of a group address as ONE column.  A lone lane is {0, 1, 1}; the
+// host emulation runs a shared search as one lane that takes every part, {0, n, n}: a bracket's refinement does not depend on
+// which lane (or which pair) it is refined in, so the results are bit-identical by construction.
+struct Share { int part_begin, part_end, nparts; };
+
 template <int M, int K, class Roots>
 struct Level {
-  static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt) {
+  static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt, const Share& sh) {
     constexpr int SRC = ((K - 1) & 1) * M, DST = (K & 1) * M;
     const double tol = K < M ? kPartitionTol : kRootTol;
     double anorm = 0.0;
@@ -205,18 +213,14 @@ struct Level {
         flo = f1;
       }
     }
-    int cnt_new = 0;
 #if defined(MTGX_COUNT_ITERATIONS)
     mtgx_trace_slot = 0;
 #endif
-    while (mask != 0u) {
-      const int i0 = __builtin_ctz(mask);
-      mask &= mask - 1u;
-      const bool two = mask != 0u;
-      const int i1 = two ? __builtin_ctz(mask) : i0;
-      mask &= mask - 1u;       // (0 & anything = 0: harmless when there was only one)
-      const double lo0 = i0 > 0 ? roots[SRC + i0 - 1] : 0.0, hi0 = i0 < cnt ? roots[SRC + i0] : 1.0;
-      const double lo1 = i1 > 0 ? roots[SRC + i1 - 1] : 0.0, hi1 = i1 < cnt ? roots[SRC + i1] : 1.0;
+    int rank = 0, i0 = 0, r0 = 0;
+    bool have0 = false;
+    auto refine = [&](int ia, int ra, int ib, int rb, bool two) {
+      const double lo0 = ia > 0 ? roots[SRC + ia - 1] : 0.0, hi0 = ia < cnt ? roots[SRC + ia] : 1.0;
+      const double lo1 = ib > 0 ? roots[SRC + ib - 1] : 0.0, hi1 = ib < cnt ? roots[SRC + ib] : 1.0;
       double fl0, fh0, fl1, fh1;
       horner_pair<K>(a, lo0, hi0, fl0, fh0);
       horner_pair<K>(a, lo1, hi1, fl1, fh1);
@@ -224,13 +228,20 @@ struct Level {
       bracket_init(b0, lo0, hi0, fl0, fh0);
       bracket_init(b1, lo1, hi1, fl1, fh1);
       bracketed_root_pair<K>(a, b0, b1, tol, fnoise);
-      roots[DST + cnt_new] = b0.x;
-      ++cnt_new;
-      if (two) {
-        roots[DST + cnt_new] = b1.x;
-        ++cnt_new;
-      }
+      roots[DST + ra] = b0.x;
+      if (two) roots[DST + rb] = b1.x;
+    };
+    while (mask != 0u) {
+      const int i = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const int r = rank++;
+      const int part = r % sh.nparts;
+      if (part < sh.part_begin || part >= sh.part_end) continue;
+      if (!have0) { i0 = i; r0 = r; have0 = true; }
+      else { refine(i0, r0, i, r, true); have0 = false; }
     }
+    if (have0) refine(i0, r0, i0, r0, false);
+    const int cnt_new = rank;
     cnt = cnt_new;
     if constexpr (K < M) {
       // integrate once: divided derivative of order s-1 from order s, s = M-K:
@@ -239,7 +250,7 @@ struct Level {
 #pragma unroll
       for (int j = K + 1; j >= 1; --j) a[j] = a[j - 1] * ((double)s / (double)j);
       a[0] = g[s - 1];
-      Level<M, K + 1, Roots>::run(g, a, roots, cnt);
+      Level<M, K + 1, Roots>::run(g, a, roots, cnt, sh);
     }
   }
 };
@@ -247,7 +258,7 @@ struct Level {
 // Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 2 * (L - 1) elements (two
 // buffers the levels alternate between); returns the count and, in `base`, the offset of the buffer that holds the result.
 template <int L, class Roots>
-MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base) {
+MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base, const Share& sh = Share{0, 1, 1}) {
   constexpr int M = L - 1;   // degree
   static_assert(M <= 31, "interval bit mask");
   double a[L];
@@ -256,7 +267,7 @@ MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base) {
   a[0] = g[M - 1];
   a[1] = g[M] * (double)M;   // level 1 = (M-1)-th divided derivative: g[M-1] + M g[M] tau
   int cnt = 0;
-  Level<M, 1, Roots>::run(g, a, roots, cnt);
+  Level<M, 1, Roots>::run(g, a, roots, cnt, sh);
   base = (M & 1) * M;
   return cnt;
 }
@@ -283,7 +294,8 @@ MTGX_HD double magnitude_at(const double* c, int N, int D, unsigned dim_mask, in
 // magnitude is searched (N - der - 1 >= 0, polynomial.cpp:70-73), dim_mask = dimensions entering the magnitude.
 // NMAX >= N - der (compile-time bound on the derivative polynomial's coefficient count).
 template <int NMAX, class Roots>
-MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, int der, double T, Roots& roots) {
+MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, int der, double T, Roots& roots,
+                              const Share& sh = Share{0, 1, 1}) {
   constexpr int L = 2 * NMAX - 2 >= 2 ? 2 * NMAX - 2 : 2;   // coefficient count of g (getConvolutionLength, polynomial.h:230-232)
   const int n_d = N - der;
   double g[L];
@@ -315,7 +327,7 @@ MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, 
     }
   }
   int base = 0;
-  const int cnt = real_roots_unit<L>(g, roots, base);
+  const int cnt = real_roots_unit<L>(g, roots, base, sh);
 
   MinMax mm;
   mm.v_min = DBL_MAX;     // segment.cpp:172-173

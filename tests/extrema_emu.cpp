@@ -10,11 +10,14 @@ struct LocalRoots {
   double& operator[](int i) { return v[i]; }
 };
 
+int g_parts = 1;   // lanes that share a root search (extrema_emu_set_parts): this one lane takes every part
+
 template <int NMAX>
 void run(int N, int K, int D, long long B, const double* coeffs, const double* times, int der, unsigned mask, double* out) {
   for (long long idx = 0; idx < B * K; ++idx) {
     LocalRoots roots;
-    const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots);
+    const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots,
+                                                       mtgx::Share{0, g_parts, g_parts});
     out[idx * 4 + 0] = mm.t_min;
     out[idx * 4 + 1] = mm.v_min;
     out[idx * 4 + 2] = mm.t_max;
@@ -53,3 +56,6 @@ extern "C" long long extrema_emu_iterations() { const long long n = mtgx::mtgx_i
 extern "C" void extrema_emu_trace(int* out) {
   for (int k = 0; k < 32; ++k) for (int j = 0; j < 16; ++j) { out[k * 16 + j] = mtgx::mtgx_trace[k][j]; mtgx::mtgx_trace[k][j] = 0; }
 }
+
+// the searches that follow are shared by `parts` lanes (emulated as one lane that takes every part)
+extern "C" void extrema_emu_set_parts(int parts) { g_parts = parts < 1 ? 1 : parts; }

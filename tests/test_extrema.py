@@ -146,6 +146,23 @@ def test_oracle_scaling_meets_bounds_in_one_round():
                 assert abs(ox.evaluate(segs[k, d], new_t[k], 0) - ox.evaluate(coeffs[b, k, d], times[b, k], 0)) < 1e-9
 
 
+def test_shared_root_search_is_bit_identical_on_the_host(xemu):
+    """Round 4: two lanes may share one root search (each refines the brackets of its ranks).  A bracket's refinement does not
+    depend on who refines it: the emulation of a shared search (one lane taking every part) returns the same bits."""
+    _, times, _, coeffs = solved_batch(10, 8, 3, 12, 4711)
+    xemu.extrema_emu_set_parts.argtypes = [ctypes.c_int]
+    outs = []
+    for parts in (1, 2, 3):
+        xemu.extrema_emu_set_parts(parts)
+        out = np.zeros((12, 8, 4))
+        for der in (1, 2):
+            assert xemu.extrema_emu_segments(10, 8, 3, 12, coeffs.ctypes.data, times.ctypes.data, der, 7, out.ctypes.data) == 0
+            outs.append(out.copy())
+    xemu.extrema_emu_set_parts(1)
+    for k in range(2):
+        assert np.array_equal(outs[k], outs[2 + k]) and np.array_equal(outs[k], outs[4 + k])
+
+
 # ----------------------------------------------------------------------------------------------- GPU (C ABI)
 @pytest.fixture(scope="module")
 def ctx():
@@ -278,3 +295,32 @@ def test_gpu_extrema_argument_errors(ctx):
     seg, traj, idx = m.minmax_magnitude(ctx, co, t, 1)        # all-zero polynomials: no roots, extrema 0 at t_start
     ctx.sync()
     assert float(seg.abs().max()) == 0.0 and int(idx.abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_shared_root_search_is_bit_identical(ctx):
+    """Two lanes per root search (small launches, the default below ~96k searches) against one lane per search: the same bits,
+    for the extrema tables and for the time scaling built on them."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, bsz = 10, 8, 3, 3000
+    masks = m.ends_full_masks(n, k)
+    t, f = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=12, device="cuda")
+    plan = m.Plan(ctx, n, dim, k, 4, masks)
+    co, _, _ = plan.solve(t, f)
+    ctx.sync()
+    res = {}
+    try:
+        for split in (1, 2):
+            ctx.set_option("extrema_split", split)
+            seg_v, traj_v, idx_v = m.minmax_magnitude(ctx, co, t, 1)
+            seg_a, traj_a, _ = m.minmax_magnitude(ctx, co, t, 2, dimensions=[0, 2])
+            c2, t2 = co.clone(), t.clone()
+            sc, within, _ = m.scale_segment_times_to_meet_constraints(ctx, c2, t2, 1.5, 2.0)
+            ctx.sync()
+            res[split] = (seg_v, traj_v, idx_v, seg_a, traj_a, c2, t2, sc, within)
+    finally:
+        ctx.set_option("extrema_split", -1)
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b)
+    plan.close()
