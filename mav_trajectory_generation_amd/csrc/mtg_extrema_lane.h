@@ -188,7 +188,7 @@ MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, doub
 // its rank's slot of the shared root buffer, which the lanes of a group address as ONE column.  A lone lane is {0, 1, 1}; the
 // host emulation runs a shared search as one lane that takes every part, {0, n, n}: a bracket's refinement does not depend on
 // which lane (or which pair) it is refined in, so the results are bit-identical by construction.
-struct Share { int part_begin, part_end, nparts; };
+struct Share { int part_begin, part_end, nparts; };   // nparts <= 4
 
 template <int M, int K, class Roots>
 struct Level {
@@ -216,9 +216,11 @@ struct Level {
 #if defined(MTGX_COUNT_ITERATIONS)
     mtgx_trace_slot = 0;
 #endif
-    int rank = 0, i0 = 0, r0 = 0;
-    bool have0 = false;
-    auto refine = [&](int ia, int ra, int ib, int rb, bool two) {
+    // The brackets are taken in GROUPS of 2 x nparts consecutive ranks: every lane of a shared search pops the same bits in the
+    // same iteration (uniform control flow -- the lanes are neighbours in one wavefront) and picks its own two, ranks
+    // part and part + nparts of the group; all of them then refine at once.
+    int rank = 0;
+    auto refine = [&](int ia, int ra, int ib, int rb, bool wa, bool wb) {
       const double lo0 = ia > 0 ? roots[SRC + ia - 1] : 0.0, hi0 = ia < cnt ? roots[SRC + ia] : 1.0;
       const double lo1 = ib > 0 ? roots[SRC + ib - 1] : 0.0, hi1 = ib < cnt ? roots[SRC + ib] : 1.0;
       double fl0, fh0, fl1, fh1;
@@ -228,19 +230,25 @@ struct Level {
       bracket_init(b0, lo0, hi0, fl0, fh0);
       bracket_init(b1, lo1, hi1, fl1, fh1);
       bracketed_root_pair<K>(a, b0, b1, tol, fnoise);
-      roots[DST + ra] = b0.x;
-      if (two) roots[DST + rb] = b1.x;
+      if (wa) roots[DST + ra] = b0.x;
+      if (wb) roots[DST + rb] = b1.x;
     };
     while (mask != 0u) {
-      const int i = __builtin_ctz(mask);
-      mask &= mask - 1u;
-      const int r = rank++;
-      const int part = r % sh.nparts;
-      if (part < sh.part_begin || part >= sh.part_end) continue;
-      if (!have0) { i0 = i; r0 = r; have0 = true; }
-      else { refine(i0, r0, i, r, true); have0 = false; }
+      int idx[8], n_in_group = 0;
+      const int base = rank;
+      for (int u = 0; u < 2 * sh.nparts && u < 8 && mask != 0u; ++u) {
+        idx[u] = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        ++n_in_group;
+        ++rank;
+      }
+      for (int part = sh.part_begin; part < sh.part_end; ++part) {
+        const bool wa = part < n_in_group, wb = part + sh.nparts < n_in_group;
+        // (a lane without a bracket of its own in this group runs along on the group's first one and writes nothing)
+        const int ua = wa ? part : 0, ub = wb ? part + sh.nparts : ua;
+        refine(idx[ua], base + ua, idx[ub], base + ub, wa, wb);
+      }
     }
-    if (have0) refine(i0, r0, i0, r0, false);
     const int cnt_new = rank;
     cnt = cnt_new;
     if constexpr (K < M) {
