@@ -34,6 +34,7 @@ struct ExtremaParams {
   unsigned mask;
   int der[2];
   int split;              // lanes that share one root search (launch_seg): 1, or 2 for small launches
+  int rolled;             // one code body for all levels of the derivative chain (mtg_extrema_lane.h, Level) or one per level
 };
 
 template <int COLS>
@@ -45,7 +46,7 @@ struct LdsRoots {
 // SPLIT lanes share one (trajectory, segment) root search (mtg_extrema_lane.h, Share): small launches are bound by the latency
 // of one lane's chain of refinements -- 10k x 8 segments are 1250 wavefronts, ~1.2 per SIMD -- and two lanes halve it.  The
 // lanes of a search are neighbours in one wavefront and address the same LDS column; lane `part` 0 writes the result.
-template <int NMAX, int SPLIT>
+template <int NMAX, int SPLIT, bool ROLLED>
 __global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
   extern __shared__ double lds[];
   constexpr int COLS = kThreads / SPLIT;
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams 
   const int seg = (int)(idx - b * P.K);
   const double T = P.times[b * P.ts_b + (long long)seg * P.ts_k];
   LdsRoots<COLS> roots{lds + threadIdx.x / SPLIT};
-  const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(P.coeffs + idx * (long long)(P.D * P.N), P.N, P.D, P.mask, P.der[slot], T, roots,
-                                                     mtgx::Share{part, part + 1, SPLIT});
+  const mtgx::MinMax mm = mtgx::segment_minmax<NMAX, LdsRoots<COLS>, ROLLED>(P.coeffs + idx * (long long)(P.D * P.N), P.N, P.D, P.mask,
+                                                                             P.der[slot], T, roots, mtgx::Share{part, part + 1, SPLIT});
   if (part != 0) return;
   double* o = P.seg_out + ((long long)slot * total + idx) * 4;
   reinterpret_cast<double2*>(o)[0] = make_double2(mm.t_min, mm.v_min);
@@ -169,19 +170,24 @@ template <int NMAX>
 void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   constexpr int L = 2 * NMAX - 2;
   const long long total = P.B * P.K;
+  const dim3 grid((unsigned)((P.split * total + kThreads - 1) / kThreads), n_slots);
+  const size_t lds = (size_t)(kThreads / P.split) * 2 * (L - 1) * sizeof(double);   // two root buffers per search (mtg_extrema_lane.h)
   if (P.split == 2) {
-    const size_t lds = (size_t)(kThreads / 2) * 2 * (L - 1) * sizeof(double);
-    hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2>), dim3((unsigned)((2 * total + kThreads - 1) / kThreads), n_slots), dim3(kThreads), lds, stream, P);
+    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, true>), grid, dim3(kThreads), lds, stream, P);
+    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, false>), grid, dim3(kThreads), lds, stream, P);
   } else {
-    const size_t lds = (size_t)kThreads * 2 * (L - 1) * sizeof(double);   // two root buffers per lane (mtg_extrema_lane.h)
-    hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1>), dim3((unsigned)((total + kThreads - 1) / kThreads), n_slots), dim3(kThreads), lds, stream, P);
+    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, true>), grid, dim3(kThreads), lds, stream, P);
+    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, false>), grid, dim3(kThreads), lds, stream, P);
   }
 }
 
 // Two lanes per search while the launch is small: searches x slots <= kSplitMaxSearches (~1.5 per SIMD lane of the chip).  Beyond
 // that the chip is full either way and the shared form's repeated phase A (+ ~20 % instructions) costs more than it hides.
 constexpr long long kSplitMaxSearches = 96 * 1024;
-int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int split_option) {
+int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int option) {
+  // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1 / 2, 0 = by size); bit 2: unrolled levels
+  const int split_option = option < 0 ? 0 : (option & 3);
+  P.rolled = option < 0 ? 1 : ((option & 4) ? 0 : 1);
   P.split = split_option == 1 || split_option == 2 ? split_option : (P.B * P.K * n_slots <= kSplitMaxSearches ? 2 : 1);
   int n_d = 0;
   for (int s = 0; s < n_slots; ++s) {

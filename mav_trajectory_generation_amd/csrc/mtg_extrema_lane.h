@@ -190,14 +190,19 @@ MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, doub
 // which lane (or which pair) it is refined in, so the results are bit-identical by construction.
 struct Share { int part_begin, part_end, nparts; };   // nparts <= 4
 
-template <int M, int K, class Roots>
+// KH: degree the Horner chains run over.  The fully unrolled chain (KH = K, one body per level) is ~60 KB of straight-line code
+// for degree 15 -- each wavefront walks through it once, and a small launch spends most of its time waiting for instruction
+// fetches (a lone wave: ~12 cycles per instruction, whatever its arithmetic).  ROLLED: ONE body for all levels, the chains run
+// over the full length M with the coefficients above the level's degree zero (~1.6x the FMAs, 1/15 of the code).
+template <int M, int K, class Roots, bool ROLLED = false>
 struct Level {
-  static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt, const Share& sh) {
-    constexpr int SRC = ((K - 1) & 1) * M, DST = (K & 1) * M;
-    const double tol = K < M ? kPartitionTol : kRootTol;
+  static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt, const Share& sh, int kr = K) {
+    constexpr int KH = ROLLED ? M : K;
+    const int SRC = ROLLED ? ((kr - 1) & 1) * M : ((K - 1) & 1) * M, DST = ROLLED ? (kr & 1) * M : (K & 1) * M;
+    const double tol = (ROLLED ? kr < M : K < M) ? kPartitionTol : kRootTol;
     double anorm = 0.0;
 #pragma unroll
-    for (int j = 0; j <= K; ++j) anorm += fabs(a[j]);
+    for (int j = 0; j <= KH; ++j) anorm += fabs(a[j]);
     const double fnoise = kNoiseUlps * DBL_EPSILON * anorm;
     // partition points P_0 = 0, P_i = roots[SRC + i - 1] (i = 1 .. cnt), P_(cnt+1) = 1; interval i = [P_i, P_(i+1)]
     unsigned mask = 0;
@@ -207,7 +212,7 @@ struct Level {
         const double h0 = i < cnt ? roots[SRC + i] : 1.0;
         const double h1 = i + 1 < cnt ? roots[SRC + i + 1] : 1.0;
         double f0, f1;
-        horner_pair<K>(a, h0, h1, f0, f1);
+        horner_pair<KH>(a, h0, h1, f0, f1);
         if ((flo < 0.0) != (f0 < 0.0)) mask |= 1u << i;
         if (i + 1 <= cnt && (f0 < 0.0) != (f1 < 0.0)) mask |= 1u << (i + 1);
         flo = f1;
@@ -224,12 +229,12 @@ struct Level {
       const double lo0 = ia > 0 ? roots[SRC + ia - 1] : 0.0, hi0 = ia < cnt ? roots[SRC + ia] : 1.0;
       const double lo1 = ib > 0 ? roots[SRC + ib - 1] : 0.0, hi1 = ib < cnt ? roots[SRC + ib] : 1.0;
       double fl0, fh0, fl1, fh1;
-      horner_pair<K>(a, lo0, hi0, fl0, fh0);
-      horner_pair<K>(a, lo1, hi1, fl1, fh1);
+      horner_pair<KH>(a, lo0, hi0, fl0, fh0);
+      horner_pair<KH>(a, lo1, hi1, fl1, fh1);
       Bracket b0, b1;
       bracket_init(b0, lo0, hi0, fl0, fh0);
       bracket_init(b1, lo1, hi1, fl1, fh1);
-      bracketed_root_pair<K>(a, b0, b1, tol, fnoise);
+      bracketed_root_pair<KH>(a, b0, b1, tol, fnoise);
       if (wa) roots[DST + ra] = b0.x;
       if (wb) roots[DST + rb] = b1.x;
     };
@@ -251,7 +256,15 @@ struct Level {
     }
     const int cnt_new = rank;
     cnt = cnt_new;
-    if constexpr (K < M) {
+    if constexpr (ROLLED) {
+      // integrate once (run-time level kr): a'_j = a_(j-1) s / j, s = M - kr; the entries above the new degree stay zero
+      if (kr < M) {
+        const double sd = (double)(M - kr);
+#pragma unroll
+        for (int j = M; j >= 1; --j) a[j] = a[j - 1] * (sd * (1.0 / (double)j));
+        a[0] = g[M - kr - 1];
+      }
+    } else if constexpr (K < M) {
       // integrate once: divided derivative of order s-1 from order s, s = M-K:
       //   a'_j = g[j+s-1] C(j+s-1, s-1) = a_{j-1} * s / j   (j >= 1),   a'_0 = g[s-1]
       constexpr int s = M - K;
@@ -265,7 +278,7 @@ struct Level {
 
 // Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 2 * (L - 1) elements (two
 // buffers the levels alternate between); returns the count and, in `base`, the offset of the buffer that holds the result.
-template <int L, class Roots>
+template <int L, class Roots, bool ROLLED = true>
 MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base, const Share& sh = Share{0, 1, 1}) {
   constexpr int M = L - 1;   // degree
   static_assert(M <= 31, "interval bit mask");
@@ -275,7 +288,11 @@ MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base, const Shar
   a[0] = g[M - 1];
   a[1] = g[M] * (double)M;   // level 1 = (M-1)-th divided derivative: g[M-1] + M g[M] tau
   int cnt = 0;
-  Level<M, 1, Roots>::run(g, a, roots, cnt, sh);
+  if constexpr (ROLLED) {
+    for (int kr = 1; kr <= M; ++kr) Level<M, 1, Roots, true>::run(g, a, roots, cnt, sh, kr);
+  } else {
+    Level<M, 1, Roots>::run(g, a, roots, cnt, sh);
+  }
   base = (M & 1) * M;
   return cnt;
 }
@@ -301,7 +318,7 @@ MTGX_HD double magnitude_at(const double* c, int N, int D, unsigned dim_mask, in
 // Extrema of one segment.  c = [D][N] coefficients (increasing powers), T = segment time, der = derivative whose
 // magnitude is searched (N - der - 1 >= 0, polynomial.cpp:70-73), dim_mask = dimensions entering the magnitude.
 // NMAX >= N - der (compile-time bound on the derivative polynomial's coefficient count).
-template <int NMAX, class Roots>
+template <int NMAX, class Roots, bool ROLLED = true>
 MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, int der, double T, Roots& roots,
                               const Share& sh = Share{0, 1, 1}) {
   constexpr int L = 2 * NMAX - 2 >= 2 ? 2 * NMAX - 2 : 2;   // coefficient count of g (getConvolutionLength, polynomial.h:230-232)
@@ -335,7 +352,7 @@ MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, 
     }
   }
   int base = 0;
-  const int cnt = real_roots_unit<L>(g, roots, base, sh);
+  const int cnt = real_roots_unit<L, Roots, ROLLED>(g, roots, base, sh);
 
   MinMax mm;
   mm.v_min = DBL_MAX;     // segment.cpp:172-173

@@ -11,13 +11,15 @@ struct LocalRoots {
 };
 
 int g_parts = 1;   // lanes that share a root search (extrema_emu_set_parts): this one lane takes every part
+int g_rolled = 1;  // one code body for all levels (the kernels' default) or the fully unrolled chain
 
 template <int NMAX>
 void run(int N, int K, int D, long long B, const double* coeffs, const double* times, int der, unsigned mask, double* out) {
   for (long long idx = 0; idx < B * K; ++idx) {
     LocalRoots roots;
-    const mtgx::MinMax mm = mtgx::segment_minmax<NMAX>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots,
-                                                       mtgx::Share{0, g_parts, g_parts});
+    const mtgx::Share sh{0, g_parts, g_parts};
+    const mtgx::MinMax mm = g_rolled ? mtgx::segment_minmax<NMAX, LocalRoots, true>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots, sh)
+                                     : mtgx::segment_minmax<NMAX, LocalRoots, false>(coeffs + idx * D * N, N, D, mask, der, times[idx], roots, sh);
     out[idx * 4 + 0] = mm.t_min;
     out[idx * 4 + 1] = mm.v_min;
     out[idx * 4 + 2] = mm.t_max;
@@ -59,3 +61,4 @@ extern "C" void extrema_emu_trace(int* out) {
 
 // the searches that follow are shared by `parts` lanes (emulated as one lane that takes every part)
 extern "C" void extrema_emu_set_parts(int parts) { g_parts = parts < 1 ? 1 : parts; }
+extern "C" void extrema_emu_set_rolled(int rolled) { g_rolled = rolled; }

@@ -161,6 +161,14 @@ def test_shared_root_search_is_bit_identical_on_the_host(xemu):
     xemu.extrema_emu_set_parts(1)
     for k in range(2):
         assert np.array_equal(outs[k], outs[2 + k]) and np.array_equal(outs[k], outs[4 + k])
+    # one code body for all levels (zero-padded full-length chains: the kernels' default) against the per-level bodies: the same
+    # roots up to the rounding of the zero-padded Horner steps
+    xemu.extrema_emu_set_rolled(0)
+    out = np.zeros((12, 8, 4))
+    assert xemu.extrema_emu_segments(10, 8, 3, 12, coeffs.ctypes.data, times.ctypes.data, 1, 7, out.ctypes.data) == 0
+    xemu.extrema_emu_set_rolled(1)
+    assert np.abs(out[..., 3] - outs[0][..., 3]).max() <= 1e-12 * np.abs(out[..., 3]).max()
+    assert np.abs(out[..., 1] - outs[0][..., 1]).max() <= 1e-9 * np.abs(out[..., 3]).max()
 
 
 # ----------------------------------------------------------------------------------------------- GPU (C ABI)
@@ -312,7 +320,7 @@ def test_gpu_shared_root_search_is_bit_identical(ctx):
     res = {}
     try:
         for split in (1, 2):
-            ctx.set_option("extrema_split", split)
+            ctx.set_option("extrema_split", split)      # (bits 0-1: lanes per search)
             seg_v, traj_v, idx_v = m.minmax_magnitude(ctx, co, t, 1)
             seg_a, traj_a, _ = m.minmax_magnitude(ctx, co, t, 2, dimensions=[0, 2])
             c2, t2 = co.clone(), t.clone()

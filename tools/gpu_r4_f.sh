@@ -17,7 +17,7 @@ for B in (2500, 10000, 30000, 100000):
         t, f = m.random_waypoint_batch(B, 8, 3, 10, masks, seed=8, device="cuda")
         co, _, _ = plan.solve(t, f)
         torch.cuda.synchronize()
-        for split in (1, 2, -1):
+        for split in (1, 2, 5, 6, -1):   # bits 0-1 lanes per search, bit 2 (4): per-level code bodies; -1 default (one body, by size)
             ctx.set_option("extrema_split", split)
             def timed(fn, reps):
                 fn(); torch.cuda.synchronize(); e0.record(ctx.stream)
