@@ -22,7 +22,7 @@
  *   "dl_max_units"     -1 default, >= 0            upper limit of the dimension-in-lane default range (x CUs)
  *   "coop"             -1 default, 0 never, 1 always   row-cooperative form where eligible
  *   "extrema_split"    -1 default; bits 0-1: lanes that share one root search of the extrema kernels (1 / 2, 0 = by launch
- *                      size); bit 2: one code body per level of the derivative chain instead of one for all
+ *                      size); bit 2: one code body for all levels of the derivative chain instead of one per level
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
  *   "dl_stagger"       -1 default, >= 0            every second workgroup of a single dimension-in-lane launch starts
  *                                                  value x 2048 shader cycles late (default: 8 for the workspace hybrids in

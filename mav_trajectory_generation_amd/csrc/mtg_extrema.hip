@@ -185,9 +185,12 @@ void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
 // that the chip is full either way and the shared form's repeated phase A (+ ~20 % instructions) costs more than it hides.
 constexpr long long kSplitMaxSearches = 96 * 1024;
 int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int option) {
-  // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1 / 2, 0 = by size); bit 2: unrolled levels
+  // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1 / 2, 0 = by size); bit 2: ONE code body
+  // for all levels of the derivative chain.  Measured (profiles/r04f_extrema_variants.jsonl, 10k x 8 segments): per-level
+  // bodies 181 / 177 us (one / two lanes per search), one body 221 / 211 us -- the 60 KB of straight-line code are NOT what
+  // bounds the kernel (its zero-padded chains cost more than the instruction fetches they save): per-level bodies stay.
   const int split_option = option < 0 ? 0 : (option & 3);
-  P.rolled = option < 0 ? 1 : ((option & 4) ? 0 : 1);
+  P.rolled = option < 0 ? 0 : ((option & 4) ? 1 : 0);
   P.split = split_option == 1 || split_option == 2 ? split_option : (P.B * P.K * n_slots <= kSplitMaxSearches ? 2 : 1);
   int n_d = 0;
   for (int s = 0; s < n_slots; ++s) {

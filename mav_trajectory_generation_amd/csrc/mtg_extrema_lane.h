@@ -191,9 +191,10 @@ MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, doub
 struct Share { int part_begin, part_end, nparts; };   // nparts <= 4
 
 // KH: degree the Horner chains run over.  The fully unrolled chain (KH = K, one body per level) is ~60 KB of straight-line code
-// for degree 15 -- each wavefront walks through it once, and a small launch spends most of its time waiting for instruction
-// fetches (a lone wave: ~12 cycles per instruction, whatever its arithmetic).  ROLLED: ONE body for all levels, the chains run
-// over the full length M with the coefficients above the level's degree zero (~1.6x the FMAs, 1/15 of the code).
+// for degree 15, each wavefront walks through it once.  ROLLED: ONE body for all levels, the chains run over the full length M
+// with the coefficients above the level's degree zero (~1.6x the FMAs, 1/15 of the code) -- built to test whether instruction
+// fetch bounds small launches (a lone wave runs at ~12 cycles per instruction): it does not, the rolled form is 15-20 % SLOWER
+// (profiles/r04f_extrema_variants.jsonl); kept selectable (measurement knob), the per-level bodies are the default.
 template <int M, int K, class Roots, bool ROLLED = false>
 struct Level {
   static MTGX_HD void run(const double* g, double* a, Roots& roots, int& cnt, const Share& sh, int kr = K) {
@@ -278,7 +279,7 @@ struct Level {
 
 // Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 2 * (L - 1) elements (two
 // buffers the levels alternate between); returns the count and, in `base`, the offset of the buffer that holds the result.
-template <int L, class Roots, bool ROLLED = true>
+template <int L, class Roots, bool ROLLED = false>
 MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base, const Share& sh = Share{0, 1, 1}) {
   constexpr int M = L - 1;   // degree
   static_assert(M <= 31, "interval bit mask");
@@ -318,7 +319,7 @@ MTGX_HD double magnitude_at(const double* c, int N, int D, unsigned dim_mask, in
 // Extrema of one segment.  c = [D][N] coefficients (increasing powers), T = segment time, der = derivative whose
 // magnitude is searched (N - der - 1 >= 0, polynomial.cpp:70-73), dim_mask = dimensions entering the magnitude.
 // NMAX >= N - der (compile-time bound on the derivative polynomial's coefficient count).
-template <int NMAX, class Roots, bool ROLLED = true>
+template <int NMAX, class Roots, bool ROLLED = false>
 MTGX_HD MinMax segment_minmax(const double* c, int N, int D, unsigned dim_mask, int der, double T, Roots& roots,
                               const Share& sh = Share{0, 1, 1}) {
   constexpr int L = 2 * NMAX - 2 >= 2 ? 2 * NMAX - 2 : 2;   // coefficient count of g (getConvolutionLength, polynomial.h:230-232)

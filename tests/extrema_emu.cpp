@@ -11,7 +11,7 @@ struct LocalRoots {
 };
 
 int g_parts = 1;   // lanes that share a root search (extrema_emu_set_parts): this one lane takes every part
-int g_rolled = 1;  // one code body for all levels (the kernels' default) or the fully unrolled chain
+int g_rolled = 0;  // one code body for all levels or (the kernels' default) the fully unrolled chain
 
 template <int NMAX>
 void run(int N, int K, int D, long long B, const double* coeffs, const double* times, int der, unsigned mask, double* out) {

@@ -161,12 +161,12 @@ def test_shared_root_search_is_bit_identical_on_the_host(xemu):
     xemu.extrema_emu_set_parts(1)
     for k in range(2):
         assert np.array_equal(outs[k], outs[2 + k]) and np.array_equal(outs[k], outs[4 + k])
-    # one code body for all levels (zero-padded full-length chains: the kernels' default) against the per-level bodies: the same
+    # one code body for all levels (zero-padded full-length chains; a selectable variant) against the per-level bodies: the same
     # roots up to the rounding of the zero-padded Horner steps
-    xemu.extrema_emu_set_rolled(0)
+    xemu.extrema_emu_set_rolled(1)
     out = np.zeros((12, 8, 4))
     assert xemu.extrema_emu_segments(10, 8, 3, 12, coeffs.ctypes.data, times.ctypes.data, 1, 7, out.ctypes.data) == 0
-    xemu.extrema_emu_set_rolled(1)
+    xemu.extrema_emu_set_rolled(0)
     assert np.abs(out[..., 3] - outs[0][..., 3]).max() <= 1e-12 * np.abs(out[..., 3]).max()
     assert np.abs(out[..., 1] - outs[0][..., 1]).max() <= 1e-9 * np.abs(out[..., 3]).max()
 

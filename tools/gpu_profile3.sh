@@ -11,7 +11,7 @@ OUT=$R/gpurun_out; mkdir -p $OUT
 TAG=${1:-r03}; shift
 ARGS="${*:---steps 20 --warmup 5}"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --no-cpu-baseline --no-extras $ARGS"
+CMD="python $R/bench.py --no-cpu-baseline --no-extras --no-parity $ARGS"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -- $CMD > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o p -- $CMD > /dev/null 2> $OUT/${TAG}_fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o p -- $CMD > /dev/null 2> $OUT/${TAG}_write.err
