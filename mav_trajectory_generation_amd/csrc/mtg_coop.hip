@@ -157,11 +157,11 @@ int launch(hipStream_t st, const CoopParams& P) {
   const int KA = (P.K + 1) / 2, KB = P.K / 2;
   const size_t lds = (2 * coop_xch_doubles<H, D>() + (size_t)(KA + KB) * coop_step_doubles<H, D>()) * sizeof(double);
   if (lds > 160 * 1024) return 1;
-  static bool attr_set = false;   // (one attribute per instantiation; idempotent)
-  if (lds > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)mtg_solve_coop_kernel<H, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 2;
-    attr_set = true;
-  }
+  // (set on every launch that needs it: the attribute belongs to the CURRENT device's copy of the kernel -- a device group runs
+  // this on several devices -- and the call is a host-side table update)
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute((const void*)mtg_solve_coop_kernel<H, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return 2;
   const unsigned grid = (unsigned)((P.B + 3) / 4);
   hipLaunchKernelGGL((mtg_solve_coop_kernel<H, D>), dim3(grid), dim3(2 * kWave), lds, st, P);
   return 0;

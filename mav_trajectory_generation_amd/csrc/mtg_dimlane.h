@@ -25,12 +25,9 @@
 #ifndef MTG_DL_OCC
 #define MTG_DL_OCC 1   // waves per SIMD the register allocation is held to
 #endif
-#ifndef MTG_DL_PREFETCH
-#define MTG_DL_PREFETCH 0   // 1: next tile's inputs requested before the current tile is solved (N = 10 / 12, K = 8).  Built and
-                            // measured in round 3, off by default: 30 more registers, no effect (B = 125k 90.3 vs 91.4 us,
-                            // N = 12 / K = 8 at 100k 93.7 vs 92.0 us) -- the third of its lifetime a wave spends parked
-                            // (profiles/r03f_pmc_stalls.txt) is not the input round trip
-#endif
+// (Built, measured and removed in round 3 / 4: requesting the NEXT tile's inputs before the current tile is solved -- 30 more
+// registers, no effect: B = 125k 90.3 vs 91.4 us, N = 12 / K = 8 at 100k 93.7 vs 92.0 us.  The third of its lifetime a wave
+// spends parked, profiles/r03f_pmc_stalls.txt, is not the input round trip.)
 #ifndef MTG_DL_PEND
 #define MTG_DL_PEND true   // MtgSlabOut::PEND: a drained range's chunks wait in registers across one back-substitution step
 #endif
@@ -200,11 +197,6 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
     else mtg_dl_preload<C, -1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
   };
-  // Input prefetch (MTG_DL_PREFETCH, off by default -- see there): the NEXT tile's inputs requested before the current tile
-  // is solved instead of after its coefficient stores (loads retire behind stores in the in-order vmcnt counter).
-  // (N = 10 / 12 with K = 8 only: the N = 8 / K = 8 and N = 10 / K = 4 kernels fit 256 registers and run two per SIMD without it)
-  constexpr bool kPrefetch = MTG_DL_PREFETCH && C::H >= 5 && C::KT == 8 && C::WSJ == 0 && OCC == 1;
-  [[maybe_unused]] double nT[kPrefetch ? C::KCS : 1], nfx[1][kPrefetch ? C::NC : 1];
   Where cur{0, 0, times, dfix, coeffs};
   int tile_prev = 0;
   if ((int)blockIdx.x < nunits) {
@@ -241,7 +233,6 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
       const int tile_next = tile_of(it + nwg);
       nxt = advance(cur, tile_next - tile_prev);
       tile_prev = tile_next;
-      if constexpr (kPrefetch) fetch(nxt, nT, nfx);
     }
     if constexpr (QUEUE) { P.times = cur.t; P.dfix = cur.f; P.coeffs = cur.c; }
     const long long b0 = (long long)cur.local * TPW;
@@ -284,14 +275,7 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if (lane == 0 && first) { tdbg[5] = clock64(); tdbg[15] = wall_clock64(); }
 #endif
     if (has_next) {
-      if constexpr (kPrefetch) {
-#pragma unroll
-        for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];
-#pragma unroll
-        for (int c = 0; c < C::NC; ++c) ln.fx[0][c] = nfx[0][c];
-      } else {
-        fetch(nxt, ln.T, ln.fx);
-      }
+      fetch(nxt, ln.T, ln.fx);
       cur = nxt;
     }
     __syncthreads();

@@ -181,9 +181,11 @@ void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   }
 }
 
-// Two lanes per search while the launch is small: searches x slots <= kSplitMaxSearches (~1.5 per SIMD lane of the chip).  Beyond
-// that the chip is full either way and the shared form's repeated phase A (+ ~20 % instructions) costs more than it hides.
-constexpr long long kSplitMaxSearches = 96 * 1024;
+// Two lanes per search (mtg_extrema_lane.h, Share) were built to halve the latency of a lane's refinement chain in small launches.
+// Measured (profiles/r04f_extrema_variants.jsonl, r04_next_rows_pmc.json): 10k x 8 segments 177 vs 181 us, 2 500 x 8 134 vs
+// 134 us -- for 39 % more VALU instructions (phase A is repeated by both lanes).  Not the default: selectable (measurement knob
+// "extrema_split"), bit-identical results (tests/test_extrema.py).
+constexpr long long kSplitMaxSearches = 0;
 int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int option) {
   // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1 / 2, 0 = by size); bit 2: ONE code body
   // for all levels of the derivative chain.  Measured (profiles/r04f_extrema_variants.jsonl, 10k x 8 segments): per-level

@@ -170,14 +170,8 @@ MTG_HD double mtg_fma(double a, double b, double c) {
 
 // a * b.  (Measured and rejected: multiplying through v_fma_f64 with a zero addend -- a lone wave issues independent
 // v_mul_f64 every 5.5 cycles against 4.4 for v_fma_f64 in the microbenchmark, but in the kernels the three-operand
-// encoding costs more than it gains: B = 10k 7.46 -> 7.74 us.  MTG_MUL_AS_FMA re-enables it for A/B runs.)
-MTG_HD double mtg_mul(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(MTG_MUL_AS_FMA)
-  return __builtin_fma(a, b, 0.0);
-#else
-  return a * b;
-#endif
-}
+// encoding costs more than it gains: B = 10k 7.46 -> 7.74 us.)
+MTG_HD double mtg_mul(double a, double b) { return a * b; }
 
 // 1/x for the LDL^T pivots and segment times.  v_rcp_f64 seed + Newton steps (no IEEE
 // division sequence); accuracy is checked on the device by mtg_selftest_rcp().
@@ -188,14 +182,8 @@ MTG_HD double mtg_rcp(double x) {
   // reaches the same result as two Newton steps (error e^4) with three dependent operations instead of four: the pivots
   // sit on the kernels' longest dependency chain (8 cycles per dependent FP64 operation for a lone wave).
   const double r0 = __builtin_amdgcn_rcp(x);
-#if defined(MTG_RCP_TWO_NEWTON)
-  double r = mtg_fma(mtg_fma(-x, r0, 1.0), r0, r0);
-  r = mtg_fma(mtg_fma(-x, r, 1.0), r, r);
-  return r;
-#else
   const double e = mtg_fma(-x, r0, 1.0);
   return mtg_fma(r0, mtg_fma(e, e, e), r0);
-#endif
 #else
   return 1.0 / x;
 #endif
