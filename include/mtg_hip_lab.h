@@ -24,9 +24,8 @@
  *   "extrema_split"    -1 default; bits 0-1: lanes that share one root search of the extrema kernels (1 / 2, 0 = by launch
  *                      size); bit 2: one code body for all levels of the derivative chain instead of one per level
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
- *   "dl_stagger"       -1 default, >= 0            every second workgroup of a single dimension-in-lane launch starts
- *                                                  value x 2048 shader cycles late (default: 8 for the workspace hybrids in
- *                                                  launches of three or more rounds, else 0)
+ *   "dl_stagger"       >= 0 (default 0)            every second workgroup of a single dimension-in-lane launch starts
+ *                                                  value x 2048 shader cycles late (phase-lock experiment: no effect)
  * Returns MTG_OK, or MTG_ERR_INVALID_ARGUMENT for an unknown name.                                                  */
 #ifndef MTG_HIP_LAB_H_
 #define MTG_HIP_LAB_H_

@@ -132,8 +132,7 @@ struct mtg_context {
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
   int knob_extrema_split = -1;       // MTG_EXTREMA_SPLIT: lanes per root search of the extrema kernels (1 / 2; -1: by launch size)
   int knob_coop = -1;                // MTG_COOP: 1 always / 0 never take the row-cooperative form where eligible (default: by size)
-  int knob_dl_stagger = -1;          // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
-                                     // (-1: the default -- kDlStaggerWorkspace for the workspace hybrids in multi-round launches, else 0)
+  int knob_dl_stagger = 0;           // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
@@ -302,7 +301,7 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
   else if (n == "coop") ctx->knob_coop = value;
   else if (n == "extrema_split") ctx->knob_extrema_split = value;
-  else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(-1, std::min(value, 1 << 20));
+  else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(0, std::min(value, 1 << 20));
   else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
   return MTG_OK;
 }
@@ -770,13 +769,12 @@ static int launch_dimlane(SolveCall& c) {
     const int rc = workspace(p, dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave, &dl_ws);
     if (rc != MTG_OK) return rc;
   }
-  // Phase stagger (mtg_dimlane.h): the long-chain hybrids whose head steps go through the global workspace run 5-11 % faster
-  // when every second persistent workgroup starts ~7 us late (profiles/r04a_stagger_sweep.jsonl: N = 12 / K = 16 210 -> 186 us,
-  // N = 10 / K = 32 291 -> 267 us, N = 12 / K = 32 520 -> 500 us at 100k; the all-register variants lose 0-15 %) -- where the
-  // launch runs several rounds, so that the delay is small against the whole
-  constexpr int kDlStaggerWorkspace = 8;
-  const int stagger = ctx->knob_dl_stagger >= 0 ? ctx->knob_dl_stagger
-                                                : ((dl->ws_per_lane && units >= 3 * grid) ? kDlStaggerWorkspace : 0);
+  // Phase stagger (mtg_dimlane.h; measurement knob "dl_stagger", default off).  Round 4 tested whether persistent one-wave-per-
+  // SIMD workgroups stay phase-locked (everyone eliminating, then everyone storing).  A sweep inside ONE process seemed to show
+  // 5-11 % for the workspace hybrids (profiles/r04a_stagger_sweep.jsonl) -- but with a fresh context, plan and buffers per setting
+  // the effect is gone (profiles/r04g_stagger_check_fresh_contexts.jsonl: N = 10 / K = 32 300 / 300 / 299 us for default / 0 / 8):
+  // the sweep had measured the process warming up (the same kernel gets ~10 % faster over its first ~200 launches), not the stagger.
+  const int stagger = ctx->knob_dl_stagger > 0 ? ctx->knob_dl_stagger : 0;
   const int aos = dimlane_input_kind(p, c.L, c.batch) | (stagger << 8);
   const int lrc = (P.dfree || P.cost)
                       ? dl->launch_extra((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, dl_ws, aos,

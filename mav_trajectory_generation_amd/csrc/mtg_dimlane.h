@@ -126,8 +126,9 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   constexpr int TPW = kWave / DL;
   // Phase stagger (measurement knob "dl_stagger", bits 8.. of the layout word; 0 = off): every second workgroup starts
-  // `stagger` x 2048 cycles late, so that half of the chip is in its (memory-silent) forward phase while the other half streams
-  // its coefficients out -- persistent one-wave-per-SIMD workgroups of equal work otherwise stay phase-locked
+  // `stagger` x 2048 cycles late -- the round-4 test of "persistent one-wave-per-SIMD workgroups of equal work stay phase-locked
+  // (everyone eliminating, then everyone storing)".  They do not: no effect on any variant once the process is warm
+  // (profiles/r04g_stagger_check_fresh_contexts.jsonl)
   const int stagger = aos >> 8;
   aos &= 1;
   if (stagger > 0 && (blockIdx.x & 1)) {

@@ -1,7 +1,10 @@
 """Phase-stagger experiment (measurement knob "dl_stagger", include/mtg_hip_lab.h): every second workgroup of a dimension-in-lane
 launch starts n x 2048 cycles late.  Persistent one-wave-per-SIMD workgroups of equal work start together and stay phase-locked
 (everyone in the memory-silent forward phase, then everyone streaming coefficients): launch time ~ issue time + memory time
-(profiles/r03d_long_pmc.json).  Does de-phasing them overlap the two?"""
+(profiles/r03d_long_pmc.json).  Does de-phasing them overlap the two?
+CAUTION (found in round 4): the settings run one after the other in ONE process, and the same kernel gets ~10 % faster over its
+first ~200 launches -- the apparent gain of the middle settings is that warm-up; tools/stagger_check.py (fresh context, plan and
+buffers per setting) shows no effect."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,5 +30,5 @@ for (N, K, D, d, mi, B, dims) in CASES:
             base = base or us
             print(json.dumps(dict(N=N, K=K, D=D, B=B, form=plan.launch_form(B, "soa", dims), stagger_x2048_cycles=stag, kernel_us=round(us, 2),
                                   vs_no_stagger=round(us / base, 3), frac=round(B * plan.bytes_per_trajectory / us * 1e-3 / 8000, 3))), flush=True)
-    ctx.set_option("dl_stagger", -1)
+    ctx.set_option("dl_stagger", 0)
     plan.close()
