@@ -58,7 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="trajectories per step per GPU (default: the config's)")
     ap.add_argument("--buffer-sets", type=int, default=16, help="independent input/output buffer sets the timed loop "
                     "rotates over (1 = everything stays resident in the Infinity Cache)")
-    ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
+    ap.add_argument("--layout", default=None, choices=["aos", "soa", "soa16"],
+                    help="input layout (default: soa; config 5: soa16 = SoA with the row stride padded to a multiple of 16 "
+                         "trajectories, so that the row pieces of a 12 500-trajectory batch start on 128-byte boundaries)")
     ap.add_argument("--dims", default="auto", choices=["auto", "fused", "split", "dimlane"], help="kernel launch form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the solve + all_gather measurement")
@@ -202,8 +204,9 @@ class ParitySample:
         for it in self.items:
             idx = it["idx"]
             t, f = it["t"], it["f"]
-            it["times_h"] = (t[:, idx].t() if it["layout"] == "soa" else t[idx]).contiguous().cpu().numpy()
-            it["fixed_h"] = (f[:, :, idx].permute(2, 0, 1) if it["layout"] == "soa" else f[idx]).contiguous().cpu().numpy()
+            soa = it["layout"] in ("soa", "soa16")    # (padded SoA: the sampled columns are below the batch size)
+            it["times_h"] = (t[:, idx].t() if soa else t[idx]).contiguous().cpu().numpy()
+            it["fixed_h"] = (f[:, :, idx].permute(2, 0, 1) if soa else f[idx]).contiguous().cpu().numpy()
             it["coeffs_h"] = it["co"][idx].cpu().numpy()
             for key in ("t", "f", "co"):
                 it[key] = None
@@ -549,6 +552,8 @@ def main():
         assert ranks_seen == world
 
     cfg = CONFIGS[args.config]
+    if args.layout is None:
+        args.layout = "soa16" if args.config == 5 else "soa"
     mixed = args.config == 4
     N, K, D, d = 10, (cfg["K"] or 8), cfg["D"], 4
     B = args.batch if args.batch is not None else cfg["batch"]
@@ -736,20 +741,20 @@ def main():
                 for bigb in ((125_000, 1_000_000) if args.extra else (125_000,)):
                     tb, fb = m.random_waypoint_batch(bigb, K, D, N, masks, seed=99, device=dev, layout=args.layout)
                     cb = torch.empty((bigb, K, D, N), dtype=torch.float64, device=dev)
-                    plan.solve(tb, fb, layout=args.layout, coeffs=cb, dims=args.dims)
+                    plan.solve(tb, fb, layout=args.layout, coeffs=cb, dims=args.dims, batch=bigb)
                     torch.cuda.synchronize()
                     us = plan.time_last_solve(20)
                     extra[f"batch_{bigb}"] = {"kernel_us": us, "traj_per_s": bigb / us * 1e6,
                                               "GBps": bigb * plan.bytes_per_trajectory / us * 1e-3,
                                               "frac_of_8TBps": bigb * plan.bytes_per_trajectory / us * 1e-3 / HBM_PEAK_GBS}
                     del tb, fb, cb
-            if args.config == 2 and not args.no_next:
+            if args.config == 2 and not args.no_next and args.layout != "soa16":
                 extra["next"] = next_rows(m, ctx, plan, sets, B, K, D, N)
         if args.extra and rank == 0 and args.config == 2:
             # host buffers in / out (MTG_FLAG_HOST_POINTERS): PCIe-inclusive rate, never the reported value.
             t, f, _ = sets[0]
-            th = (t.t().contiguous() if args.layout == "soa" else t).cpu()
-            fh = (f.permute(2, 0, 1).contiguous() if args.layout == "soa" else f).cpu()
+            th = (t[:, :B].t().contiguous() if args.layout != "aos" else t).cpu()
+            fh = (f[:, :, :B].permute(2, 0, 1).contiguous() if args.layout != "aos" else f).cpu()
             for tag, tt_, ff_ in (("pageable", th.numpy(), fh.numpy()),
                                   ("pinned", th.pin_memory().numpy(), fh.pin_memory().numpy())):
                 co_h = torch.empty((B, K, D, N), dtype=torch.float64, pin_memory=(tag == "pinned")).numpy()
@@ -765,7 +770,10 @@ def main():
             # solve; reported beside the solve-only number, never part of `value`
             from mav_trajectory_generation_amd import dist as mdist
             t, f, _ = sets[0]
-            runner = mdist.ChunkedSolveGather(plan, t, f, layout=args.layout, n_chunks=args.gather_chunks)
+            g_layout = args.layout
+            if g_layout == "soa16":     # (the chunked runner slices the batch: plain SoA copies of the same inputs)
+                t, f, g_layout = t[:, :B].contiguous(), f[:, :, :B].contiguous(), "soa"
+            runner = mdist.ChunkedSolveGather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks)
             for _ in range(3):
                 runner.run()
             barrier()
@@ -834,7 +842,9 @@ def main():
             what = (f"batch of {B} random-waypoint trajectories per GPU per step ({cfg['name']}): {K} segments, N=10, "
                     f"dim={D}, snap" + (", velocity + acceleration fixed at interior vertices" if cfg["interior"] == 7 else "")
                     + f"; {form}; rotating over {nsets} independent input/output buffer sets "
-                      f"({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; inputs {args.layout.upper()}, coeffs [B][K][D][N]")
+                      f"({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; inputs {args.layout.upper()}"
+                      + (" (SoA, row stride padded to a multiple of 16 trajectories: mtg_layout_soa_padded)" if args.layout == "soa16" else "")
+                      + ", coeffs [B][K][D][N]")
         traffic_prof = profile_traffic(traj_per_step, args.config, args.steps, args.warmup)
         if args.settle_ms > 0:
             what += (f"; set-up before the contract's warm-up + timed steps: {args.settle_ms:g} ms of the same work (a fresh process "

@@ -153,6 +153,11 @@ mtg_context* mtg_plan_context(const mtg_plan* plan);
 int mtg_plan_launch_form(const mtg_plan* plan, int64_t batch, const mtg_layout* layout, uint32_t flags);
 void mtg_layout_aos(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 void mtg_layout_soa(const mtg_plan* plan, int64_t batch, mtg_layout* out);
+/* SoA with the row stride padded to the next multiple of 16 trajectories (times[K][Bs], d_fixed[D][n_fixed][Bs], d_free likewise;
+ * Bs = (batch + 15) & ~15): every 16-trajectory row piece starts on a 128-byte boundary whatever the batch size -- with the plain
+ * SoA stride a batch of 12 500 (100 000-byte rows) reads 1.75x its input bytes.  Read by the dimension-in-lane kernels like
+ * the two canonical layouts (any other kernel takes it as the general strided layout it is).                              */
+void mtg_layout_soa_padded(const mtg_plan* plan, int64_t batch, mtg_layout* out);
 
 /* Optional: caller-owned scratch for the generic kernels' back-substitution workspace (no allocation inside
  * mtg_solve_linear then, e.g. for graph capture).  bytes == 0 restores library-managed scratch.               */

@@ -47,6 +47,7 @@ EXPORTS = {
     "mtg_plan_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_uint32]),
     "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_layout_soa": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
+    "mtg_layout_soa_padded": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_plan_set_workspace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mtg_solve_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), c_double_p, c_double_p,
                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint32]),

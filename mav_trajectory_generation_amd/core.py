@@ -208,6 +208,8 @@ class Plan:
             self.lib.mtg_layout_aos(self.handle, batch, ctypes.byref(lay))
         elif kind == "soa":
             self.lib.mtg_layout_soa(self.handle, batch, ctypes.byref(lay))
+        elif kind == "soa16":     # SoA, row stride padded to a multiple of 16 trajectories (mtg_layout_soa_padded)
+            self.lib.mtg_layout_soa_padded(self.handle, batch, ctypes.byref(lay))
         else:
             raise ValueError(kind)
         return lay
@@ -239,7 +241,7 @@ class Plan:
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
               coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True,
-              traj_status=None, basic_solution: bool = False):
+              traj_status=None, basic_solution: bool = False, batch: Optional[int] = None):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
         dims: launch form -- 'auto', 'fused', 'split' (one dimension group per workgroup) or 'dimlane' (all dimensions of
@@ -252,14 +254,19 @@ class Plan:
         context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors
         must then be passed in, allocated by the caller before the fork."""
         import torch
-        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        if layout == "soa16":
+            # times [K][Bs], d_fixed [D][n_fixed][Bs] with Bs = batch rounded up to a multiple of 16: the batch size itself
+            # cannot be read off the tensors
+            assert batch is not None and times.shape[1] == ((batch + 15) & ~15), "layout 'soa16' needs batch= and padded tensors"
+        else:
+            batch = times.shape[0] if layout == "aos" else times.shape[1]
         assert times.dtype == torch.float64 and times.is_cuda and times.is_contiguous()
         assert d_fixed.dtype == torch.float64 and d_fixed.is_cuda and d_fixed.is_contiguous()
         dev = times.device
         if coeffs is None:
             coeffs = torch.empty((batch, self.K, self.D, self.N), dtype=torch.float64, device=dev)
         if want_free and d_free is None:
-            shape = (batch, self.D, self.n_free) if layout == "aos" else (self.D, self.n_free, batch)
+            shape = (batch, self.D, self.n_free) if layout == "aos" else (self.D, self.n_free, batch if layout == "soa" else (batch + 15) & ~15)
             d_free = torch.empty(shape, dtype=torch.float64, device=dev)
         if want_cost and cost is None:
             cost = torch.empty((batch,), dtype=torch.float64, device=dev)

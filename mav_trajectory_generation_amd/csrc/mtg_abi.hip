@@ -474,6 +474,13 @@ void mtg_layout_aos(const mtg_plan* p, int64_t batch, mtg_layout* L) {
   L->free_stride_b = (int64_t)p->D * p->n_free; L->free_stride_d = p->n_free; L->free_stride_c = 1;
 }
 
+void mtg_layout_soa_padded(const mtg_plan* p, int64_t batch, mtg_layout* L) {
+  const int64_t bs = (batch + 15) & ~(int64_t)15;
+  L->times_stride_b = 1; L->times_stride_k = bs;
+  L->fixed_stride_b = 1; L->fixed_stride_d = (int64_t)p->n_fixed * bs; L->fixed_stride_c = bs;
+  L->free_stride_b = 1; L->free_stride_d = (int64_t)p->n_free * bs; L->free_stride_c = bs;
+}
+
 void mtg_layout_soa(const mtg_plan* p, int64_t batch, mtg_layout* L) {
   L->times_stride_b = 1; L->times_stride_k = batch;
   L->fixed_stride_b = 1; L->fixed_stride_d = (int64_t)p->n_fixed * batch; L->fixed_stride_c = batch;
@@ -519,11 +526,18 @@ static bool dimlane_is_default(const mtg_plan* p, const MtgDimlaneEntry* dl, int
 }
 
 // Input layout kinds the dimension-in-lane kernels read: 0 = canonical SoA (times[K][B], d_fixed[D][n_fixed][B]), 1 = canonical
-// AoS (times[B][K], d_fixed[B][D][n_fixed]: the reference's natural order), -1 = anything else (fused / generic kernels).
+// AoS (times[B][K], d_fixed[B][D][n_fixed]: the reference's natural order), 2 = SoA with the row stride padded to the next
+// multiple of 16 trajectories (mtg_layout_soa_padded; the static variants' single and queue launches only), -1 = anything else
+// (fused / generic kernels).
+static int64_t padded16(int64_t batch) { return (batch + 15) & ~(int64_t)15; }
 static int dimlane_input_kind(const mtg_plan* p, const mtg_layout* L, int64_t batch) {
   if (L->times_stride_b == 1 && L->times_stride_k == batch && L->fixed_stride_b == 1 && L->fixed_stride_c == batch &&
       L->fixed_stride_d == (int64_t)p->n_fixed * batch)
     return 0;
+  const int64_t bs = padded16(batch);
+  if (bs != batch && L->times_stride_b == 1 && L->times_stride_k == bs && L->fixed_stride_b == 1 && L->fixed_stride_c == bs &&
+      L->fixed_stride_d == (int64_t)p->n_fixed * bs)
+    return 2;
   if (L->times_stride_b == p->K && L->times_stride_k == 1 && L->fixed_stride_b == (int64_t)p->D * p->n_fixed &&
       L->fixed_stride_c == 1 && L->fixed_stride_d == p->n_fixed)
     return 1;
@@ -542,7 +556,7 @@ static const MtgDimlaneEntry* pick_dimlane(const mtg_plan* p, int64_t batch, con
   if ((P.dfree || P.cost) && dl->h == 6 && dl->k == 32 && batch > 20000 && !(flags & MTG_FLAG_DIMLANE)) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
   if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
-  if (batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
+  if (padded16(batch) * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) return nullptr;
   if (flags & MTG_FLAG_DIMLANE) return dl;
   return dimlane_is_default(p, dl, batch) ? dl : nullptr;
 }
@@ -556,7 +570,7 @@ static const MtgDimlaneRtEntry* pick_dimlane_rt(const mtg_plan* p, int64_t batch
   if (!rt || p->ctx->knob_dl_rt == 0 || p->ctx->knob_no_dimlane || cost_only || P.dfree || P.cost) return nullptr;
   if (p->dimlane && p->ctx->knob_dl_rt != 1) return nullptr;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS)) return nullptr;
-  if (dimlane_input_kind(p, L, batch) < 0) return nullptr;
+  { const int kind = dimlane_input_kind(p, L, batch); if (kind < 0 || kind > 1) return nullptr; }
   // the body keeps the batch size and its tile count in 32-bit integers (its input addresses are 64-bit, unlike the static
   // variants' 32-bit byte offsets)
   if (batch + rt->tpw >= (1ll << 31)) return nullptr;
@@ -1183,7 +1197,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
   const MtgDimlaneEntry* dl = p->dimlane;
   if (dl && (!dl->launch_queue || ctx->knob_no_dimlane || (flags & MTG_FLAG_FUSED_DIMS))) dl = nullptr;
   if (dl && (dimlane_input_kind(p, L, batch) < 0 ||
-             batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32) ||
+             padded16(batch) * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32) ||
              ((batch + dl->tpw - 1) / dl->tpw) * (int64_t)n_launch >= (1ll << 31)))
     dl = nullptr;
   if (slab && dl && !(flags & MTG_FLAG_DIMLANE) && !dimlane_is_default(p, dl, batch * (int64_t)n_launch)) dl = nullptr;
@@ -1445,7 +1459,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
       const mtg_plan* p = it.plan;
       if (it.batch <= 0 || it.cost || (it.d_free && p->n_free > 0) || mtg_dl_any_index(p->dimlane) < 0) continue;
       const mtg_layout& L = it.layout;
-      if (dimlane_input_kind(p, &L, it.batch) < 0) continue;
+      { const int kind = dimlane_input_kind(p, &L, it.batch); if (kind < 0 || kind > 1) continue; }   // (padded SoA: single / queue launches only)
       if (it.batch * 8 * (int64_t)std::max(p->K, p->n_fixed * p->D) >= (1ll << 32)) continue;
       cand.push_back(i);
     }

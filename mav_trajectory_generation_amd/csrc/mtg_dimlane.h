@@ -66,6 +66,7 @@ template <class C, int DIR>
 __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times, const double* __restrict__ dfix,
                                                unsigned B, unsigned b, unsigned d, unsigned dl, int aos,
                                                double (&T)[C::KCS], double (&fx)[1][C::NC]) {
+  // B: row stride of the SoA layouts in elements (the batch size, or -- padded SoA -- its multiple of 16: mtg_solve_dl_body)
   constexpr int KC = DIR > 0 ? C::KA : C::KB;
   constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
   constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
@@ -130,6 +131,12 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   // (everyone eliminating, then everyone storing)".  They do not: no effect on any variant once the process is warm
   // (profiles/r04g_stagger_check_fresh_contexts.jsonl)
   const int stagger = aos >> 8;
+  // Layout word, bit 1: SoA with the row stride PADDED to a multiple of 16 trajectories (times[K][Bs], d_fixed[DL][n_fixed][Bs],
+  // Bs = (B + 15) & ~15).  A tile's row pieces (16 or 21 trajectories x 8 bytes) then start on 128-byte boundaries whatever B is;
+  // with the plain stride B the pieces of B = 12 500 (BASELINE config 5 per GPU: 100 000-byte rows) straddle two 128-byte lines
+  // each -- measured 1.75x the algorithmic input bytes, 1.20x in total, on a kernel that runs at the HBM ceiling on ACTUAL traffic
+  // (profiles/r04_config5_pmc_traffic.json).
+  const unsigned Bs = (aos & 2) ? (((unsigned)B + 15u) & ~15u) : (unsigned)B;
   aos &= 1;
   if (stagger > 0 && (blockIdx.x & 1)) {
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
@@ -145,8 +152,8 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   const bool dup = d >= DL;            // surplus lanes (64 % DL) duplicate the last lane's work, outputs suppressed
   if (dup) { d = DL - 1; t = TPW - 1; }
   MtgParams P;
-  P.times = times; P.ts_b = aos ? C::KT : 1; P.ts_k = aos ? 1 : B;
-  P.dfix = dfix; P.fs_b = aos ? DL * C::offFEnd : 1; P.fs_c = aos ? 1 : B; P.fs_d = aos ? C::offFEnd : (long long)C::offFEnd * B;
+  P.times = times; P.ts_b = aos ? C::KT : 1; P.ts_k = aos ? 1 : Bs;
+  P.dfix = dfix; P.fs_b = aos ? DL * C::offFEnd : 1; P.fs_c = aos ? 1 : Bs; P.fs_d = aos ? C::offFEnd : (long long)C::offFEnd * Bs;
   P.coeffs = coeffs;
   P.dfree = nullptr; P.ps_b = P.ps_d = P.ps_c = 0;
   P.cost = nullptr; P.ws = ws; P.ws_stride = (long long)nwg * (NP * 2 * kWave);
@@ -195,8 +202,8 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   auto fetch = [&](const Where& w, double (&T_)[C::KCS], double (&fx_)[1][C::NC]) {
     unsigned bb = (unsigned)w.local * TPW + t;
     if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
-    else mtg_dl_preload<C, -1>(w.t, w.f, (unsigned)B, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
+    if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
+    else mtg_dl_preload<C, -1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
   };
   Where cur{0, 0, times, dfix, coeffs};
   int tile_prev = 0;

@@ -21,7 +21,7 @@ def ends_full_masks(n_coeffs: int, n_segments: int, interior_mask: int = 1) -> L
 def random_waypoint_batch(batch: int, n_segments: int, dimension: int, n_coeffs: int, fixed_mask: Sequence[int],
                           seed: int = 0, device="cuda", layout: str = "aos", box: float = 10.0, v_max: float = 3.0,
                           a_max: float = 5.0, magic: float = 6.5, yaw_dim: bool = False):
-    """Returns (times, d_fixed) float64 tensors on `device` in `layout`.
+    """Returns (times, d_fixed) float64 tensors on `device` in `layout` ('aos', 'soa' or the padded 'soa16').
 
     Positions uniform in [-box, box]^D with consecutive spacing > 0.2 (re-drawn otherwise); end vertices:
     position random, higher fixed derivatives zero; interior vertices: fixed velocity uniform direction with
@@ -61,4 +61,13 @@ def random_waypoint_batch(batch: int, n_segments: int, dimension: int, n_coeffs:
     d_fixed = torch.stack(cols, dim=-1)  # [B][D][n_fixed]
     if layout == "soa":
         return times.t().contiguous(), d_fixed.permute(1, 2, 0).contiguous()
+    if layout == "soa16":
+        # SoA with the row stride padded to a multiple of 16 trajectories (mtg_layout_soa_padded): [K][Bs], [D][n_fixed][Bs];
+        # the padding columns hold 1.0 / 0.0 and are never read (pass batch= to Plan.solve)
+        bs = (batch + 15) & ~15
+        t = torch.ones((k, bs), device=device, dtype=torch.float64)
+        f = torch.zeros((d, d_fixed.shape[-1], bs), device=device, dtype=torch.float64)
+        t[:, :batch] = times.t()
+        f[:, :, :batch] = d_fixed.permute(1, 2, 0)
+        return t, f
     return times.contiguous(), d_fixed.contiguous()

@@ -555,3 +555,36 @@ def test_dimlane_extra_outputs(ctx, shape, bsz, layout):
     assert np.allclose(cost[:nb].cpu().numpy(), j_lit, rtol=1e-6)
     assert np.allclose(fra.contiguous().cpu().numpy(), f_lit, rtol=1e-6, atol=1e-6 * np.abs(f_lit).max())
     plan.close()
+
+
+# ---- SoA with the row stride padded to a multiple of 16 trajectories (mtg_layout_soa_padded; round 4) ----------------------------
+@pytest.mark.parametrize("shape", [(10, 16, 4, 4, 7, 12_500), (10, 8, 3, 4, 1, 10_007), (12, 8, 3, 5, 1, 333), (8, 5, 3, 3, 1, 1)])
+def test_dimlane_reads_padded_soa_inputs(ctx, shape):
+    """The dimension-in-lane kernels (single launch and queue) read the padded SoA layout like the canonical ones: same lanes,
+    same arithmetic, only the row stride differs -> bit-identical coefficients; the launch form stays dimension-in-lane (with the
+    plain stride a 12 500-trajectory batch -- BASELINE config 5 per GPU -- reads 1.75x its input bytes: every 128-byte row
+    piece straddles two lines)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, k, dim, d, mi, bsz = shape
+    masks = m.ends_full_masks(n, k, mi)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    ts, fs = m.random_waypoint_batch(bsz, k, dim, n, masks, seed=5 * n + k, device="cuda", layout="soa", yaw_dim=(dim == 4))
+    bs = (bsz + 15) & ~15
+    tp = torch.full((k, bs), float("nan"), dtype=torch.float64, device="cuda")
+    fp = torch.full((dim, fs.shape[1], bs), float("nan"), dtype=torch.float64, device="cuda")
+    tp[:, :bsz], fp[:, :, :bsz] = ts, fs                  # (the padding columns are never read: NaN would show)
+    assert plan.launch_form(bsz, "soa16", "dimlane") == "dimlane" and plan.launch_form(bsz, "soa16") == plan.launch_form(bsz, "soa")
+    co_p = torch.full((bsz + 1, k, dim, n), 7.0, dtype=torch.float64, device="cuda")
+    plan.solve(tp, fp, layout="soa16", coeffs=co_p[:bsz], dims="dimlane", batch=bsz)
+    co_s, _, _ = plan.solve(ts, fs, layout="soa", dims="dimlane")
+    ctx.sync()
+    assert float(co_p[bsz].min()) == 7.0 and float(co_p[bsz].max()) == 7.0
+    assert torch.equal(co_p[:bsz], co_s)
+    # the queue form (what the bench times)
+    outs = [torch.full((bsz, k, dim, n), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+    plan.solve_sequence([(tp, fp, o) for o in outs], layout="soa16", dims="dimlane")
+    ctx.sync()
+    for o in outs:
+        assert torch.equal(o, co_s)
+    plan.close()
