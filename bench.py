@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the solve + all_gather measurement")
     ap.add_argument("--gather-chunks", type=int, default=4)
+    ap.add_argument("--exercise-collectives", action="store_true",
+                    help="run every collective branch of the N > 1 path on a ONE-rank group (RCCL on a 1-GPU box: init, "
+                         "all_reduce, all_gather, barrier, the chunked solve + all_gather_into_tensor); extra.collectives_exercised")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the multi-process path on a box with fewer GPUs than ranks)")
     ap.add_argument("--same-device", action="store_true", help="all ranks on HIP device 0 (multi-process tests on a 1-GPU box)")
@@ -82,6 +85,9 @@ def parse_args(argv=None):
                     "second half: max coefficient rel-err vs the reference build / the port)")
     ap.add_argument("--parity-samples", type=int, default=768, help="trajectories of the timed launch's outputs that are "
                     "compared with the oracles (spread over >= 3 of the rotating buffer sets the TIMED launch wrote)")
+    ap.add_argument("--timed-repeats", type=int, default=0,
+                    help="diagnostic: repeat the warm-up + timed region this many more times AFTER the contract's one and "
+                         "report each repeat's host-clock breakdown (extra.timed_region_repeats); never part of `value`")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (profiling runs: the kernel statistics then cover the same launches as the metric)")
     return ap.parse_args(argv)
@@ -157,10 +163,10 @@ class ParitySample:
     call oracle/ -- with the C++ restatement (`port`) and, where the prebuilt library travelled, the reference's own code
     (oracle/_ref/libmtg_ref.so).  A row the timed launch did not write stays NaN and fails the check."""
 
-    def __init__(self, nsets, steps, warmup, n_rows, seed=20260925):
+    def __init__(self, nsets, steps, warmup, n_rows, seed=20260925, settle_sets=()):
         import numpy as np
         timed_sets = [(warmup + i) % nsets for i in range(steps)]
-        warm_sets = {i % nsets for i in range(warmup)}
+        warm_sets = {i % nsets for i in range(warmup)} | set(settle_sets)   # (+ what the settle phase rewrites after the prefill)
         uniq = list(dict.fromkeys(timed_sets))
         only_timed = [s for s in uniq if s not in warm_sets]
         # sets nobody but the timed launch writes between the prefill and the read-back; else every set it writes
@@ -325,24 +331,24 @@ class SolveLoop:
         self.ptrs = [(t.data_ptr(), f.data_ptr(), co.data_ptr()) for (t, f, co) in sets]
         self._cache = {}
 
-    def _arrays(self, steps, first):
-        key = (steps, first % len(self.ptrs))
+    def _arrays(self, steps, first, within=None):
+        n = within or len(self.ptrs)        # within: rotate over the first `within` buffer sets only (the settle phase)
+        key = (steps, first % n, n)
         if key not in self._cache:
-            n = len(self.ptrs)
             arr = [(ctypes.c_void_p * steps)(*[self.ptrs[(first + i) % n][j] for i in range(steps)]) for j in range(3)]
             self._cache[key] = arr
         return self._cache[key]
 
-    def prepare(self, steps, first=0):
-        self._arrays(steps, first)
+    def prepare(self, steps, first=0, within=None):
+        self._arrays(steps, first, within)
 
-    def run(self, steps, first=0, start_event=None, stop_event=None):
+    def run(self, steps, first=0, start_event=None, stop_event=None, within=None):
         """start_event / stop_event: torch.cuda.Event objects (already recorded once, so that their hipEvent_t exists)
         recorded by the library right before the first / after the last launch -- the measured interval then does not
         contain Python's latency between an `event.record()` and the first launch."""
         if steps <= 0:
             return
-        t, f, c = self._arrays(steps, first)
+        t, f, c = self._arrays(steps, first, within)
         ev = [ctypes.c_void_p(e.cuda_event) if e is not None else None for e in (start_event, stop_event)]
         rc = self.plan.lib.mtg_solve_linear_sequence_events(self.plan.handle, steps, self.batch, ctypes.byref(self.lay),
                                                             t, f, c, self.flags, ev[0], ev[1])
@@ -534,15 +540,21 @@ def main():
     device_index = 0 if args.same_device else local
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if world > 1:
+    grouped = world > 1 or args.exercise_collectives
+    if grouped:
+        if not launched:     # one rank, no launcher: rendezvous with ourselves
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
         assert dist.get_world_size() == args.gpus
-    red_dev = dev if (world > 1 and args.backend == "nccl") else "cpu"
+    red_dev = dev if (grouped and args.backend == "nccl") else "cpu"
     ranks_seen, rank_devices = 1, [device_index]
-    if world > 1:   # evidence that the collective backend really spans `world` ranks, and where each rank runs
+    if grouped:   # evidence that the collective backend really spans `world` ranks, and where each rank runs
         ones = torch.ones(1, dtype=torch.float64, device=red_dev)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
@@ -564,7 +576,7 @@ def main():
     per_batch = args.sequence == "launches"
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -598,10 +610,10 @@ def main():
             stamps["done"] = time.perf_counter()
             barrier()               # ... then the contract's barrier + torch.cuda.synchronize()
 
-        def timed(loop_, steps, warmup, parity_=None):
+        def timed(loop_, steps, warmup, parity_=None, prefilled=False):
             loop_.prepare(warmup, 0)
             loop_.prepare(steps, warmup)
-            if parity_ is not None and not parity_.after_warmup:
+            if parity_ is not None and not parity_.after_warmup and not prefilled:
                 parity_.prefill()       # NaN into the sampled output rows (sets the warm-up steps do not write)
             loop_.run(warmup)
             if parity_ is not None and parity_.after_warmup:
@@ -633,11 +645,17 @@ def main():
             return {"buffer_sets": sets_, "steps": steps, "us_per_step": us, "traj_per_s": traj_per_step * steps / wall,
                     "frac_of_8TBps": bytes_per_step / us * 1e-3 / HBM_PEAK_GBS}
 
+        # The settle phase of the single-structure configs rotates over the warm-up's buffer sets only, so that the parity
+        # sample's NaN prefill can precede it: NO host work but the library calls themselves then sits between the settle
+        # phase and the timed call (visit K of round 4, profiles/r04k_*: the same call costs 5 us of host time in a loop,
+        # 7-8 us right after such calls, and 12-21 us after the prefill's few torch launches -- 5-10 % of a 20-step region).
+        settle_within = max(1, min(args.warmup, nsets)) if (args.settle_ms > 0 and not mixed) else None
         # (built BEFORE the settle phase: no host work may sit between that phase and the contract's warm-up + timed steps)
         parity = None
         if rank == 0 and not args.no_parity:
             # (config 4: >= 512 sampled trajectories per polynomial order)
-            parity = ParitySample(nsets, args.steps, args.warmup, args.parity_samples * (3 if mixed else 1))
+            parity = ParitySample(nsets, args.steps, args.warmup, args.parity_samples * (3 if mixed else 1),
+                                  settle_sets=range(settle_within or 0))
             if mixed:
                 parity.plan(len(loop.SHAPES))
                 for si in parity.sets:
@@ -653,7 +671,7 @@ def main():
         # as in any pipeline that has been running for longer than one rotation
         loop.run(nsets)
         torch.cuda.synchronize()
-        cold = None
+        cold, prefilled = None, False
         if args.settle_ms > 0:
             # A fresh process starts on a GPU that has just come out of idle (rocm-smi: sclk level 543 MHz); the contract's W
             # warm-up steps are ~30 us of work, and the first timed region then runs 10-15 % slower than every later one
@@ -662,14 +680,18 @@ def main():
             # with the same work for settle_ms (set-up, not a step), then the contract's warm-up + timed steps follow.
             dt_c, us_c = timed(loop, args.steps, args.warmup)
             cold = {"kernel_us_per_step": us_c, "frac": bytes_per_step / us_c * 1e-3 / HBM_PEAK_GBS, "wall_us": dt_c * 1e6,
-                    "units_per_s_this_rank": traj_per_step * args.steps / dt_c,
+                    "units_per_s_this_rank": traj_per_step * args.steps / dt_c, "wall_breakdown_us": dict(stamps["breakdown_us"]),
                     "is": "the same warm-up + timed region, run once BEFORE the settle phase: what a process that starts on an idle GPU sees first"}
-            loop.prepare(nsets, 0)
+            if settle_within and parity is not None and not parity.after_warmup:
+                parity.prefill()
+                prefilled = True
+            kw = {"within": settle_within} if settle_within else {}
+            loop.prepare(nsets, 0, **kw)
             t_end = time.perf_counter() + args.settle_ms * 1e-3
             while time.perf_counter() < t_end:
-                loop.run(nsets)
+                loop.run(nsets, **kw)
                 torch.cuda.synchronize()
-        dt, step_us = timed(loop, args.steps, args.warmup, parity)
+        dt, step_us = timed(loop, args.steps, args.warmup, parity, prefilled)
         wall_breakdown = dict(stamps["breakdown_us"])
         ctx.sync()  # raises if any trajectory flagged bad time / singular
         if parity is not None:
@@ -678,6 +700,12 @@ def main():
             assert torch.isfinite(co).all()
 
         extra, fill_us, peer = {}, None, None
+        if args.timed_repeats > 0:
+            reps_ = []
+            for _ in range(args.timed_repeats):
+                dt_r, us_r = timed(loop, args.steps, args.warmup)
+                reps_.append(dict(stamps["breakdown_us"], device_us_per_step=us_r))
+            extra["timed_region_repeats"] = reps_
         if rank == 0 and not args.no_extras:
             # The OTHER hand-over form of the same K steps under the same protocol (W warm-up steps, K timed steps, wall clock
             # around them), reported as a PEER of `value`: one kernel launch per step (what a caller whose batches arrive one
@@ -765,7 +793,7 @@ def main():
                 extra[f"host_pointers_{tag}_pcie_inclusive_traj_per_s"] = 5 * B / (time.perf_counter() - t1)
 
         gather = None
-        if world > 1 and not args.no_gather and not mixed:
+        if grouped and not args.no_gather and not mixed:
             # solve + final all_gather of the coefficients: chunked, chunk i's gather overlaps chunk i+1's
             # solve; reported beside the solve-only number, never part of `value`
             from mav_trajectory_generation_amd import dist as mdist
@@ -795,12 +823,15 @@ def main():
                 runner.run(solve=False)
             barrier()
             gather_only = (time.perf_counter() - t0) / reps
-            gather = {"chunks": runner.n_chunks, "solve_plus_gather_ms": both * 1e3, "solve_only_ms": solve_only * 1e3,
+            runner.run()
+            barrier()
+            own_slice_ok = bool(torch.equal(runner.gathered[:, rank], runner.local))   # this rank's slice of the gathered buffer
+            gather = {"chunks": runner.n_chunks, "own_slice_matches_local_solve": own_slice_ok, "solve_plus_gather_ms": both * 1e3, "solve_only_ms": solve_only * 1e3,
                       "gather_only_ms": gather_only * 1e3,
                       "gathered_bytes_per_rank": world * B * K * D * N * 8, "backend": args.backend}
 
     per_rank = None
-    if world > 1:
+    if grouped:
         mine = torch.tensor([dt, step_us], dtype=torch.float64, device=red_dev)
         allv = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
         dist.all_gather(allv, mine)
@@ -848,7 +879,8 @@ def main():
         traffic_prof = profile_traffic(traj_per_step, args.config, args.steps, args.warmup)
         if args.settle_ms > 0:
             what += (f"; set-up before the contract's warm-up + timed steps: {args.settle_ms:g} ms of the same work (a fresh process "
-                     f"starts on an idle GPU; the timed region measured before that phase is reported as cold_start)")
+                     f"starts on an idle GPU; the timed region measured before that phase is reported as cold_start)"
+                     + (f", as {nsets}-batch calls rotating over the warm-up's {settle_within} buffer set(s)" if settle_within else ""))
         out = {
             "metric": {2: "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)",
                        3: "trajectories/sec (8-seg, N=10, 3D min-snap solveLinear)",
@@ -898,6 +930,10 @@ def main():
                                           "and solved repeatedly; value_other_form is one pre-built 12-item request per step"}
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if args.exercise_collectives:
+            out["collectives_exercised"] = {"backend": args.backend, "world": world, "ranks_seen": ranks_seen,
+                                            "calls": ["init_process_group", "all_reduce", "all_gather", "barrier"]
+                                                     + (["all_gather_into_tensor (chunked solve + gather)"] if gather else [])}
         if extra:
             out["extra"] = extra
         if gather is not None:
@@ -914,7 +950,7 @@ def main():
             print("bench.py: PARITY FAILED: " + json.dumps(out["parity"]), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

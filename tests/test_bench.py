@@ -62,6 +62,33 @@ def test_two_rank_bench_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("launcher", [False, True])
+def test_rccl_branches_run_on_a_one_rank_group(launcher):
+    """The `nccl` (= RCCL) branches of the N > 1 path -- init with a device id, all_reduce / all_gather of device tensors,
+    barrier, the chunked solve overlapped with all_gather_into_tensor on the communication stream -- executed on the GPU
+    box's one device (a one-rank group): everything but the cross-device transport itself.  launcher=True: under the very
+    command the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with N = 1."""
+    argv = ["--gpus", "1", "--exercise-collectives", "--steps", "6", "--warmup", "2", "--batch", "4000", "--buffer-sets", "2",
+            "--no-cpu-baseline", "--no-extras", "--gather-chunks", "2"]
+    if launcher:
+        e = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            e.pop(k, None)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py")] + argv,
+                           capture_output=True, text=True, cwd=ROOT, env=e, timeout=600)
+    else:
+        r = run_bench(*argv)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    ce = out["collectives_exercised"]
+    assert ce["backend"] == "nccl" and ce["ranks_seen"] == 1 and any("all_gather_into_tensor" in c for c in ce["calls"])
+    assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["solve_plus_gather_ms"] > 0
+    assert out["gather"]["own_slice_matches_local_solve"] is True
+    assert out["per_rank"][0]["device_us_per_step"] > 0 and out["parity"]["ok"]
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_carries_the_cpu_baseline():
     r = run_bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "2", "--batch", "2000",
                   "--buffer-sets", "2", "--no-gather", "--no-extras")
