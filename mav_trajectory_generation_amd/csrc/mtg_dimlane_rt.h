@@ -214,7 +214,8 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
         for (int k = 0; k < C::DLW; ++k) pt[k] = perm[k] + zt;
         mtg_rs_unpack<C>(pt, tail.Gs[r], C::MI, C::MI, Gw);
       }
-      mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, tail.g[r], xr, xl);
+      if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl);
+      else mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, tail.g[r], xr, xl);
       tie_on = xl[0][H - 1];
       if (r > 0 && j - 1 >= 1) request_inputs(j - 1);    // next: tail position r - 1 (its G comes from registers)
       else request_head(j - 1);                          // next: the last head step, or step 0
@@ -224,7 +225,8 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
   for (int j = (nh - 1 < kc - 1 ? nh - 1 : kc - 1); j >= 1; --j) {     // head steps nh - 1 .. 1
     double xl[1][H];
     const double T_use = T_cur;
-    mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, gw, xr, xl);
+    if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl);
+    else mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, gw, xr, xl);
     tie_on = xl[0][H - 1];
     request_head(j - 1);
     mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io);

@@ -34,14 +34,16 @@ int launch_rt(void* stream, int grid, const double* times, const double* dfix, d
    (size_t)MTG_RTCFG(H, MS, MI, ME, DV, DL)::WSE * sizeof(double), launch_rt<MTG_RTCFG(H, MS, MI, ME, DV, DL), DL, R, L>},
 const MtgDimlaneRtEntry kRtTable[] = {
     // (R, L) = the largest register / LDS step counts without scratch spills / with two workgroups per CU (probed with
-    // hipcc -Rpass-analysis=kernel-resource-usage): half-chains of up to 1 + R + L steps stay on chip -- K <= 66 / 34 / 18 (D = 3)
-    MTG_RT(4, 15, 1, 15, 3, 3, 24, 8)
-    MTG_RT(5, 31, 1, 31, 4, 3, 11, 5)
-    MTG_RT(6, 63, 1, 63, 5, 3, 5, 3)
+    // hipcc -Rpass-analysis=kernel-resource-usage): half-chains of up to 1 + R + L steps stay on chip
+    // (round 4, factor store: a kept step is f (f + 1) / 2 + DL f numbers per trajectory instead of f * f + DL f -- was (24, 8) / (11, 5) /
+    // (5, 3) and K <= 66 / 34 / 18; now K <= 74 / 40 / 26)
+    MTG_RT(4, 15, 1, 15, 3, 3, 27, 9)
+    MTG_RT(5, 31, 1, 31, 4, 3, 13, 6)
+    MTG_RT(6, 63, 1, 63, 5, 3, 8, 4)
     // the same with a yaw dimension (x, y, z, yaw; 16 trajectories per wave)
-    MTG_RT(4, 15, 1, 15, 3, 4, 24, 8)
-    MTG_RT(5, 31, 1, 31, 4, 4, 13, 5)
-    MTG_RT(6, 63, 1, 63, 5, 4, 6, 3)
+    MTG_RT(4, 15, 1, 15, 3, 4, 24, 9)
+    MTG_RT(5, 31, 1, 31, 4, 4, 15, 6)
+    MTG_RT(6, 63, 1, 63, 5, 4, 8, 4)
     // N = 10 with more fixed at the interior vertices: position + velocity (+ acceleration: BASELINE config 5's pattern, any K)
     MTG_RT(5, 31, 7, 31, 4, 4, 24, 8)
     MTG_RT(5, 31, 7, 31, 4, 3, 24, 8)

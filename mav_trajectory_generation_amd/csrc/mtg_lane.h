@@ -78,6 +78,9 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
+#ifndef MTG_FACTOR_STORE
+#define MTG_FACTOR_STORE 1     // (0: the round-3 form, G itself in the workspace -- A/B builds)
+#endif
 template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0, int RS_ = 0>
 struct MtgCfg {
   // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
@@ -111,13 +114,20 @@ struct MtgCfg {
   // LS_ > 0 (with DLW_): the LAST LS_ of the WS_ workspace steps (the ones next to the register steps) are kept in the
   // wave's LDS instead of global memory -- same row layout, row stride 64 lanes (MtgParams::lds_steps).
   static constexpr int LSJ = (kStatic && DLW_ > 0) ? LS_ : 0;
-  static constexpr int WSE = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW + FMAXW
+  // Factor store (round 4; shared-G configurations whose steps leave the registers): what a step keeps for the back-substitution
+  // is the LDL^T factor of its pivot block (strict lower triangle of L + 1 / d: f (f + 1) / 2 numbers) instead of
+  // G = Dtilde^-1 U (f * f numbers).  The back-substitution then forms x_l = g - Dtilde^-1 (U x_r) with U rebuilt from the
+  // constant table and the segment time (mtg_bwd_backsub_fs): ~2 f^2 more FP64 operations per step and dimension lane, on a
+  // kernel whose time is the workspace round trip -- 14 -> 10 rows per step for N = 12, 10 -> 8 for N = 10, 6 -> 5 for N = 8.
+  static constexpr bool kFS = MTG_FACTOR_STORE != 0 && DLW_ > 0 && ((kStatic && WS_ > 0) || kRolled);
+  static constexpr int FCNT = kFS ? FMAXW * (FMAXW + 1) / 2 : FMAXW * FMAXW;   // kept numbers per step besides g
+  static constexpr int WSE = DLW > 0 ? (FCNT + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
   // RS_ != 0 (with DLW_): the REGISTER steps keep G shared as well -- lane of dimension k holds elements k, DLW + k, ... of
   // G (GROWS doubles instead of up to H * H) and fetches its siblings' elements with ds_bpermute at back-substitution time
   // (the three lanes of a trajectory compute identical G): half the registers per step, i.e. twice the steps on chip.
   static constexpr bool kRegShared = (kStatic || kRolled) && DLW_ > 0 && RS_ != 0;
-  static constexpr int GROWS = DLW > 0 ? (FMAXW * FMAXW + DLW - 1) / DLW : 1;
+  static constexpr int GROWS = DLW > 0 ? (FCNT + DLW - 1) / DLW : 1;
   static constexpr int FULL = (1 << H_) - 1;
   // static mode: fixed-slot column prefix and the column range each direction touches
   static constexpr int offF(int v) { return v == 0 ? 0 : popc(MS_) + (v - 1) * popc(MI_); }
@@ -172,6 +182,15 @@ MTG_HD double mtg_fma(double a, double b, double c) {
 // v_mul_f64 every 5.5 cycles against 4.4 for v_fma_f64 in the microbenchmark, but in the kernels the three-operand
 // encoding costs more than it gains: B = 10k 7.46 -> 7.74 us.)
 MTG_HD double mtg_mul(double a, double b) { return a * b; }
+
+// The value, opaque to the optimiser from here on (no instruction): a product that went through it cannot be contracted into
+// a later addition.
+MTG_HD double mtg_pin(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+  return x;
+}
 
 // 1/x for the LDL^T pivots and segment times.  v_rcp_f64 seed + Newton steps (no IEEE
 // division sequence); accuracy is checked on the device by mtg_selftest_rcp().
@@ -556,6 +575,15 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-U[m][p], g[dm][m], ln.rc[dm][p]);
     }
   }
+  if constexpr (C::kFS) {
+    // factor store: the caller keeps the pivot block's factor in place of G (strict lower triangle: L, diagonal: 1 / d)
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+#pragma unroll
+      for (int q = 0; q < H; ++q)
+        G[p][q] = (((ml >> p) & 1) || ((ml >> q) & 1) || q > p) ? 0.0 : (q == p ? dinv[p] : A[p][q]);
+    }
+  }
 }
 
 // segment time of chain step j (static mode: preloaded register; otherwise a global load)
@@ -835,6 +863,98 @@ MTG_HD void mtg_store_free(const MtgParams& P, long long b, int v, int mask, con
   mtg_store_free_impl<C>(P, b, v, mask, x);
 }
 
+// Which entries (p, q) of a step's kept matrix exist: G's free x free block, or (factor store) the lower triangle of the
+// left vertex's free x free pivot block.
+template <class C>
+MTG_HD constexpr bool mtg_keep(int p, int q, int ml, int mr) {
+  if ((ml >> p) & 1) return false;
+  if (C::kFS) return q <= p && !((ml >> q) & 1);
+  return !((mr >> q) & 1);
+}
+
+// Back-substitution of one chain step from the FACTOR of its pivot block (MtgCfg::kFS): F strict lower = L, diagonal = 1 / d,
+// xl = [fixed values | g - (L D L^T)^-1 (U xr)], U = T^(1-2d) S_l H1_lr S_r rebuilt from the table and the segment time.
+template <class C, int DIR>
+MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
+                               const double (&F)[C::H][C::H], const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H],
+                               double (&xl)[C::D][C::H]) {
+  constexpr int H = C::H, D = C::D, N = C::N;
+  double s[H], bs[H], tinv;
+  int dummy = 0;
+  mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, dummy);
+  const double* hc = mtg_h1<C>(P);
+  double y[D][H], w[H][D], dinv[H];
+#pragma unroll
+  for (int q = 0; q < H; ++q) {
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) y[dm][q] = mtg_pin(mtg_mul(s[q], mtg_pin(xr[dm][q])));
+  }
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+    dinv[p] = F[p][p];
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) w[p][dm] = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < H; ++q) {          // source column outermost: independent accumulators adjacent
+    if ((mr >> q) & 1) continue;
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if ((ml >> p) & 1) continue;
+      const double c = hc[p * N + H + q];
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_fma(c, y[dm][q], w[p][dm]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_pin(mtg_mul(bs[p], w[p][dm]));
+  }
+  // (y above is formed from a pinned COPY of xr: the same product s x_r is formed by mtg_recover for the segment's coefficients
+  // (dl), where the A^-1 row of coefficient h has entries +-1, fma(1, dl, acc) folds to an addition and the compiler contracts
+  // the product into it or not depending on the product's other uses.  Sharing the product with this function changed that
+  // decision in the coefficient-only kernel of N = 10 / K = 32 but not in its extra-output twin: c_h off by 4 - 140 ulps
+  // between two kernels that must agree bit for bit.)
+  // (L D L^T)^-1 w in place.  Every product that feeds an addition or subtraction below is pinned (an empty asm the value
+  // passes through): with -ffp-contract=fast the compiler may otherwise fuse a product into the final subtraction in one
+  // kernel and not in another instantiation of the same step -- observed: g of a REGISTER step is the forward phase's
+  // x * (1 / d), still visible as a product when "g - w" is formed here, and the coefficient-only and extra-output kernels of
+  // N = 10 / K = 32 differed in the last bit of 3 % of their coefficients -- and the coefficient-only / extra-output / queue
+  // kernels of a shape are required to be bit-identical (tests/test_gpu_dimlane.py).
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if ((ml >> i) & 1) continue;
+#pragma unroll
+    for (int k = 0; k < i; ++k) {
+      if ((ml >> k) & 1) continue;
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) w[i][dm] = mtg_fma(-F[i][k], w[k][dm], w[i][dm]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if ((ml >> i) & 1) continue;
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) w[i][dm] = mtg_pin(mtg_mul(w[i][dm], dinv[i]));
+  }
+#pragma unroll
+  for (int i = H - 1; i >= 0; --i) {
+    if ((ml >> i) & 1) continue;
+#pragma unroll
+    for (int k = i + 1; k < H; ++k) {
+      if ((ml >> k) & 1) continue;
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) w[i][dm] = mtg_fma(-F[k][i], w[k][dm], w[i][dm]);
+    }
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(g[dm][p]) - w[p][dm];
+  }
+}
+
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
 // Back-substitution of one chain step: xl = [fixed values | g - G xr] (all slots of the left vertex).  fix_l: the
@@ -974,10 +1094,9 @@ MTG_HD void mtg_ws_store_shared(PTR w, long long stride, int d, const double (&G
   int cnt = 0;
 #pragma unroll
   for (int p = 0; p < H; ++p) {
-    if ((ml >> p) & 1) continue;
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-      if ((mr >> q) & 1) continue;
+      if (!mtg_keep<C>(p, q, ml, mr)) continue;
       cand[cnt % DL] = G[p][q];
       ++cnt;
       if (cnt % DL == 0) {
@@ -1014,7 +1133,7 @@ MTG_HD void mtg_ws_load_shared(PTR w, long long stride, long long share, double 
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       G[p][q] = 0.0;
-      if (((ml >> p) & 1) || ((mr >> q) & 1)) continue;
+      if (!mtg_keep<C>(p, q, ml, mr)) continue;
       G[p][q] = *col[cnt % DL];
       col[cnt % DL] += stride;
       ++cnt;
@@ -1040,10 +1159,9 @@ MTG_HD void mtg_rs_pack(int d, const double (&G)[C::H][C::H], int ml, int mr, do
   int cnt = 0;
 #pragma unroll
   for (int p = 0; p < H; ++p) {
-    if ((ml >> p) & 1) continue;
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-      if ((mr >> q) & 1) continue;
+      if (!mtg_keep<C>(p, q, ml, mr)) continue;
       cand[cnt % DL] = G[p][q];
       ++cnt;
       if (cnt % DL == 0) {
@@ -1082,7 +1200,7 @@ __device__ __forceinline__ void mtg_rs_unpack(const int (&perm)[C::DLW > 0 ? C::
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       G[p][q] = 0.0;
-      if (((ml >> p) & 1) || ((mr >> q) & 1)) continue;
+      if (!mtg_keep<C>(p, q, ml, mr)) continue;
       G[p][q] = mtg_bperm(perm[cnt % DL], Gs[cnt / DL]);
       ++cnt;
     }
@@ -1260,9 +1378,17 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       if constexpr (C::WSJ > 0 || C::kRegShared) {
         double fix_l[D][H], xl[D][H];
         mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(C::KT, j), ml, ln, fix_l);
-        if (j < C::WSJ) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, gw, xr, xl);
-        else if constexpr (C::kRegShared) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, ln.g[j - C::WSJ < 0 ? 0 : j - C::WSJ], xr, xl);
-        else mtg_bwd_backsub<C>(ml, mr, fix_l, ln.G[j - C::WSJ < 0 ? 0 : j - C::WSJ], ln.g[j - C::WSJ < 0 ? 0 : j - C::WSJ], xr, xl);
+        const int jr = j - C::WSJ < 0 ? 0 : j - C::WSJ;
+        if constexpr (C::kFS) {
+          const double Tj = mtg_step_time<C, DIR>(P, b, j, ln);
+          if (j < C::WSJ) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, gw, xr, xl);
+          else if constexpr (C::kRegShared) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl);
+          else mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl);
+        } else {
+          if (j < C::WSJ) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, gw, xr, xl);
+          else if constexpr (C::kRegShared) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, ln.g[jr], xr, xl);
+          else mtg_bwd_backsub<C>(ml, mr, fix_l, ln.G[jr], ln.g[jr], xr, xl);
+        }
         // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
         // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);

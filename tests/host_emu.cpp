@@ -43,6 +43,45 @@ void emu_update(MtgParams P) {
   }
 }
 
+// Dimension-in-lane form with the SHARED step storage (MtgCfg::DLW = 3) and every step of the half-chain in the lane-coalesced
+// workspace (WS = all steps, no LDS / register steps: those branches exist on the device only): three dimension lanes of one
+// trajectory share a step's kept matrix -- G, or with MtgCfg::kFS the LDL^T factor of the pivot block -- through a 64-column
+// workspace exactly as a wavefront does (lane = dimension * 21 + trajectory, trajectory 0 here).
+template <class C>
+void emu_solve_shared(MtgParams P) {
+  constexpr int DL = 3, TPW = 64 / DL;
+  static_assert(C::D == 1 && C::DLW == DL && C::WSJ >= C::KCS && C::LSJ == 0 && !C::kRegShared, "all steps through the shared workspace");
+  const int K = C::KT, vm = (K + 1) / 2, mm = mtg_mask<C>(P, vm);
+  const int nslots = mtg_mid_slots<C>(mm);
+  std::vector<double> wsa((size_t)C::KCS * C::WSE * 64 + 64, 0.0), wsb(wsa.size(), 0.0);
+  std::vector<double> bufa[DL], bufb[DL];
+  P.ws_stride = 64;
+  P.Dtot = DL;
+  for (long long b = 0; b < P.B; ++b) {
+    MtgLane<C> la[DL], lb[DL];
+    for (int d = 0; d < DL; ++d) {
+      MtgParams Q = P;
+      Q.dim0 = d;
+      Q.ws_share = -(long long)(d * TPW);
+      mtg_lane_forward<C, 1>(Q, b, la[d], wsa.data() + d * TPW);
+      mtg_lane_forward<C, -1>(Q, b, lb[d], wsb.data() + d * TPW);
+      bufa[d].assign(nslots + 1, 0.0);
+      bufb[d].assign(nslots + 1, 0.0);
+      mtg_pack_mid<C>(la[d], mm, bufa[d].data(), 1);
+      mtg_pack_mid<C>(lb[d], mm, bufb[d].data(), 1);
+    }
+    for (int d = 0; d < DL; ++d) {
+      MtgParams Q = P;
+      Q.dim0 = d;
+      Q.ws_share = -(long long)(d * TPW);
+      MtgDirectOut<C> io;
+      io.b = b;
+      mtg_lane_finish<C, 1, 0>(Q, b, la[d], wsa.data() + d * TPW, bufb[d].data(), 1, io, true);
+      mtg_lane_finish<C, -1, 0>(Q, b, lb[d], wsb.data() + d * TPW, bufa[d].data(), 1, io, true);
+    }
+  }
+}
+
 using Fn = void (*)(MtgParams);
 template <int H, int D> using GenericCfg = MtgCfg<H, D, 0, 0, 0, 0>;
 
@@ -134,4 +173,33 @@ extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long
   }
   if (status) *status = st;
   return 0;
+}
+
+// Shared-workspace dimension-in-lane emulation (emu_solve_shared): D = 3, trajectory ends fully fixed, interior vertices
+// position-only, derivative N / 2 - 1; K in {4, 8}.  Returns -2 for any other shape.  kept_is_factor: MtgCfg::kFS of the build.
+extern "C" int mtg_emu_run_shared(int N, int K, long long B, const double* times, const double* dfix, double* coeffs,
+                                  int* status, int* kept_is_factor) {
+  const int H = N / 2, D = 3;
+  const int n_fixed = 2 * H + (K - 1);
+  MtgParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.times = times; P.ts_b = K; P.ts_k = 1;
+  P.dfix = dfix; P.fs_b = (long long)D * n_fixed; P.fs_d = n_fixed; P.fs_c = 1;
+  P.coeffs = coeffs;
+  int st = 0;
+  P.status = &st;
+  P.B = B; P.K = K; P.Dtot = D; P.deriv = H - 1;
+  P.ainvoff = kAinvLoOff[H];
+  P.h1off = kH1Off[H][H - 1];
+#define SHARED(HH, KK)                                                                                   \
+  if (H == HH && K == KK) {                                                                              \
+    using C = MtgCfg<HH, 1, KK, (1 << HH) - 1, 1, (1 << HH) - 1, HH - 1, 0, (KK + 1) / 2, 3, 0, 0>;       \
+    if (kept_is_factor) *kept_is_factor = C::kFS ? 1 : 0;                                                \
+    emu_solve_shared<C>(P);                                                                              \
+    if (status) *status = st;                                                                            \
+    return 0;                                                                                            \
+  }
+  SHARED(4, 4) SHARED(4, 8) SHARED(5, 4) SHARED(5, 8) SHARED(6, 4) SHARED(6, 8)
+#undef SHARED
+  return -2;
 }

@@ -76,7 +76,10 @@ def test_dimlane_vs_oracle_and_split_form(ctx, shape, bsz):
     assert float(co[bsz].min()) == 7.0 and float(co[bsz].max()) == 7.0, "stores past the end of the batch"
     got = co[:bsz].cpu().numpy()
     ref = ref.cpu().numpy()
-    assert helpers.poly_relerr(got, ref) < 1e-12
+    # Long chains keep the LDL^T FACTOR of a step's pivot block where the split form keeps G = Dtilde^-1 U (MtgCfg::kFS, round 4):
+    # x_l = g - (L D L^T)^-1 (U x_r) against g - G x_r -- the same numbers up to the association of f^2 products per step
+    # (measured: <= 6e-12 over these shapes; both are equally far from the 50-digit solution, tests/test_lane_emu.py)
+    assert helpers.poly_relerr(got, ref) < (1e-12 if k <= 10 else 3e-11)
     if shape in BITWISE_VS_SPLIT:
         assert np.array_equal(got, ref), "dimension-in-lane and dimension-split forms share the lane arithmetic"
     nchk = min(bsz, 64)
@@ -543,7 +546,9 @@ def test_dimlane_extra_outputs(ctx, shape, bsz, layout):
     tol = 1e-12 if n <= 10 else 1e-10
     rel, _ = ctx.compare_coefficients(co, cf)
     assert rel < tol
-    assert torch.allclose(cost, jf, rtol=1e-11 if n <= 10 else 1e-9, atol=0)
+    # (N = 12 long chains: factor-store back-substitution here, G in the fused kernel; the cost is second order in the
+    # coefficients but N = 12's are themselves only good to ~1e-8 -- measured 1.2e-9 at N = 12 / K = 32, 1.3e-11 at N = 10 / K = 32)
+    assert torch.allclose(cost, jf, rtol=(1e-11 if k < 32 else 5e-11) if n <= 10 else (1e-9 if k < 32 else 5e-9), atol=0)
     scale = ff.abs().amax().clamp_min(1e-300)
     assert float((fr - ff).abs().amax() / scale) < tol
     nb = min(bsz, 4)

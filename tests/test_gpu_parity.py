@@ -363,8 +363,27 @@ def test_merged_mixed_request(ctx):
     got = req.solve()
     torch.cuda.synchronize()
     solver.sync()
-    for (c, j), (c0, j0) in zip(got, ref):
-        assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
+    def same(b, c, j, c0, j0):
+        n_, k_ = b["n_coeffs"], b["times"].shape[1]
+        if (n_, k_) in ((10, 32), (12, 16), (12, 32)):
+            # the per-bucket launches of these shapes are the factor-store dimension-in-lane kernels (MtgCfg::kFS, round 4: the
+            # back-substitution works from the LDL^T factor of a step's pivot block), the merged launch WITH cost output runs the
+            # G-form bodies: the same solution up to the association of f^2 products per chain step
+            den = c0.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+            assert float(((c - c0).abs() / den).max()) < (1e-12 if n_ == 10 else 2e-10)
+            assert torch.allclose(j, j0, rtol=1e-10 if n_ == 10 else 1e-8)
+        else:
+            assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
+
+    for b, (c, j), (c0, j0) in zip(buckets, got, ref):
+        same(b, c, j, c0, j0)
+    # (coefficient-only merged launches run the same factor-store bodies as the per-bucket ones: bit for bit, every bucket)
+    req_c = solver.merged(buckets)
+    got_c = req_c.solve()
+    torch.cuda.synchronize()
+    solver.sync()
+    for (c, _), (c0, _) in zip(got_c, ref):
+        assert torch.equal(c, c0)
     graph = req.capture()
     for c, j in req.out:
         c.zero_()
@@ -373,10 +392,11 @@ def test_merged_mixed_request(ctx):
     graph.replay()
     fresh = one.solve_device(buckets, want_cost=True)
     torch.cuda.synchronize()
-    for (c, j), (c1, j1) in zip(req.out, fresh):
-        assert torch.equal(c, c1) and torch.allclose(j, j1, rtol=1e-12)
+    for b, (c, j), (c1, j1) in zip(buckets, req.out, fresh):
+        same(b, c, j, c1, j1)
     del graph
     req.close()
+    req_c.close()
     # d_P output through the C-ABI wrapper directly, SoA layout, two items of one structure
     plan_a = m.Plan(ctx, 10, 3, 16, 4, m.ends_full_masks(10, 16))
     plan_b = m.Plan(ctx, 10, 3, 5, 4, m.ends_full_masks(10, 5))
@@ -703,6 +723,7 @@ def test_sequence_with_events(ctx):
     for s in range(3):
         t, f = m.random_waypoint_batch(1000, 8, 3, 10, masks, seed=40 + s, device="cuda", layout="soa")
         sets.append((t, f, torch.zeros((1000, 8, 3, 10), dtype=torch.float64, device="cuda")))
+    torch.cuda.synchronize()     # (the raw C call below does not order the context's stream behind torch's: inputs first)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(ctx.stream):
         e0.record(ctx.stream)

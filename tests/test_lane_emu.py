@@ -142,3 +142,39 @@ def test_extreme_time_ratios_stay_closer_to_truth_than_the_literal_route(host_em
     assert rc == 0 and st == 0
     e_kernel, e_lit = helpers.poly_relerr(co, c_mp), helpers.poly_relerr(c_lit, c_mp)
     assert e_kernel < 1e-5 and e_kernel < 1e-2 * e_lit
+
+
+@pytest.mark.parametrize("n,k", [(8, 4), (8, 8), (10, 4), (10, 8), (12, 4), (12, 8)])
+def test_shared_workspace_factor_store_emulation(host_emu, n, k):
+    """The dimension-in-lane form with shared step storage, every step through the lane-coalesced workspace: three dimension
+    lanes of a trajectory keep ONE copy of a step's matrix between them -- since round 4 the LDL^T factor of the pivot block
+    (MtgCfg::kFS), with U rebuilt from the table at back-substitution time -- and must reproduce the generic lane code
+    (which keeps G = Dtilde^-1 U per lane) to round-off, and the C++ port / the 50-digit oracle to the usual tolerance."""
+    import ctypes
+    from oracle import cpu_ref
+    dp = ctypes.POINTER(ctypes.c_double)
+    host_emu.mtg_emu_run_shared.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, dp, dp, dp,
+                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    host_emu.mtg_emu_run_shared.restype = ctypes.c_int
+    d, dim, bsz = n // 2 - 1, 3, 24
+    masks = helpers.masks_ends_full(n, k)
+    _, times, fixed = helpers.reference_batch(bsz, k, n, dim, 900 + n + k, masks)
+    times, fixed = np.ascontiguousarray(times), np.ascontiguousarray(fixed)
+    co = np.zeros((bsz, k, dim, n))
+    st, fs = ctypes.c_int(0), ctypes.c_int(-1)
+    rc = host_emu.mtg_emu_run_shared(n, k, bsz, times.ctypes.data_as(dp), fixed.ctypes.data_as(dp), co.ctypes.data_as(dp),
+                                     ctypes.byref(st), ctypes.byref(fs))
+    assert rc == 0 and st.value == 0
+    assert fs.value == 1        # this build keeps factors
+    rc0, co0, _, _, st0 = helpers.emu_run(host_emu, n, dim, k, d, masks, times, fixed, 0, want_cost=False)
+    assert rc0 == 0 and st0 == 0
+    # same algorithm up to the back-substitution's association: g - G x  vs  g - (L D L^T)^-1 (U x)
+    assert helpers.poly_relerr(co, co0) < (2e-9 if n == 12 else 2e-11)
+    port = cpu_ref.solve_batch(n, d, masks, times, fixed)[0]
+    assert helpers.poly_relerr(co, port) < (5e-7 if n == 12 else 1e-9)
+    from oracle import oracle_mp
+    truth = np.asarray(oracle_mp.solve_batch(n, d, masks, times[:3], fixed[:3])[0], dtype=np.float64)
+    e_fs, e_g = helpers.poly_relerr(co[:3], truth), helpers.poly_relerr(co0[:3], truth)
+    assert e_fs < (1e-7 if n == 12 else 1e-11)
+    assert e_fs < 20 * e_g + 1e-13      # not materially further from the truth than the G form
+    assert helpers.check_path(masks, times, fixed, co) < 1e-6
