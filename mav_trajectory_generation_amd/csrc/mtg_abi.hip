@@ -512,6 +512,7 @@ static const MtgDimlaneEntry* dimlane_twin(const mtg_plan* p, const MtgDimlaneEn
   if (!dl || dl != p->dimlane || !p->dimlane2 || p->ctx->knob_dl_occ2 == 0) return dl;
   if (p->ctx->knob_dl_occ2 == 1) return p->dimlane2;
   const int64_t units = ((trajectories + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
+  if (p->dimlane2->ws_per_lane) return dl;      // long-chain twins (MTG_DLO2): lab option only
   return units > (int64_t)kOcc2MinWgPerCu * p->ctx->n_cu ? p->dimlane2 : dl;
 }
 
@@ -779,7 +780,7 @@ static int launch_dimlane(SolveCall& c) {
   if (dl->ws_per_lane) {
     // long chains: part of the back-substitution data goes through the workspace; persistent workgroups only (two
     // 2-wave workgroups per CU, one wave per SIMD), so the workspace stays small enough to live in the Infinity Cache
-    grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
+    grid = std::min(units, ctx->n_cu * 4 * dl->occ / (2 * dl->np));
     const int rc = workspace(p, dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave, &dl_ws);
     if (rc != MTG_OK) return rc;
   }
@@ -1230,7 +1231,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
       int grid = std::min(units, ctx->n_cu * 8);
       double* dl_ws = nullptr;
       if (dl->ws_per_lane) {   // long chains: persistent workgroups only, as in single launches
-        grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
+        grid = std::min(units, ctx->n_cu * 4 * dl->occ / (2 * dl->np));
         const size_t need = dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave;
         if (p->user_ws) {
           if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");

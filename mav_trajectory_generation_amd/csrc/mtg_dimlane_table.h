@@ -91,6 +91,8 @@ int launch_dl_extra(void* stream, int grid, const double* times, const double* d
 #define MTG_DLW(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 0, 1)
 #define MTG_DLR(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, WS, LS, 1, 1)
 #define MTG_DLO(H, K, MS, MI, ME, DV, DL, NP, RS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, 0, 0, 0, 0, RS, 2)
+// MTG_DLO2: the twin of a LONG chain -- one shared register step, LS LDS steps, the rest in the workspace, 256 registers
+#define MTG_DLO2(H, K, MS, MI, ME, DV, DL, NP, WS, LS) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, 0, 0, WS, LS, 1, 2)
 #define MTG_DL(H, K, MS, MI, ME, DV, DL, NP, LO, HI) MTG_DLX(H, K, MS, MI, ME, DV, DL, NP, LO, HI, 0, 0, 0, 1)
 static const MtgDimlaneEntry kDimlaneTable[] = {
 #include MTG_DL_TABLE_INC
@@ -99,6 +101,7 @@ static const MtgDimlaneEntry kDimlaneTable[] = {
 #undef MTG_DLW
 #undef MTG_DLR
 #undef MTG_DLO
+#undef MTG_DLO2
 #undef MTG_DLX
 #undef MTG_DLCFG
 #undef MTG_DL_QUEUE_FN
