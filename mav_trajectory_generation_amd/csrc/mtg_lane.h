@@ -81,6 +81,9 @@ constexpr int mtg_ainv_offset(int n) {
 #ifndef MTG_FACTOR_STORE
 #define MTG_FACTOR_STORE 1     // (0: the round-3 form, G itself in the workspace -- A/B builds)
 #endif
+#ifndef MTG_FS_PARTIAL
+#define MTG_FS_PARTIAL 1       // (0: factor-store steps still solve for G in the forward sweep -- A/B builds)
+#endif
 template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0, int RS_ = 0>
 struct MtgCfg {
   // PT_ != 0: the kernel serves perturbed-time virtual batches (mtg_mellinger_cost_gradient); only the cost-only
@@ -525,6 +528,84 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   }
   mtg_ldl<H>(A, dinv, ml, ln.flags);
 
+  const double* hrr = mtg_h1<C>(P);
+  if constexpr (C::kFS && MTG_FS_PARTIAL != 0) {
+    // Factor store, partial elimination: nothing in the FORWARD sweep needs G = Dtilde^-1 U itself.  With W = L^-1 U and
+    // z = L^-1 rv (forward substitution only), U^T G = W^T D^-1 W and U^T g = W^T D^-1 z: the carried Schur complement is what
+    // f pivots of the 2f x 2f block [Dtilde U; U^T a_rr] leave behind.  The back-substitution half of the solve is needed for
+    // g alone (D columns instead of f + D), and no later forward step depends on it: it leaves the dependent chain
+    // pivot -> column -> update -> next pivot, which is what a lone wave per SIMD waits on.
+    double X[H][H + D], Y[H][H + D];
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+#pragma unroll
+      for (int q = 0; q < H; ++q) X[p][q] = U[p][q];
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) X[p][H + dm] = rv[dm][p];
+    }
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      if ((ml >> i) & 1) continue;
+#pragma unroll
+      for (int k = 0; k < i; ++k) {
+        if ((ml >> k) & 1) continue;
+#pragma unroll
+        for (int c = 0; c < H + D; ++c) {
+          if (c < H && ((mr >> c) & 1)) continue;
+          X[i][c] = mtg_fma(-A[i][k], X[k][c], X[i][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+#pragma unroll
+      for (int c = 0; c < H + D; ++c) Y[i][c] = ((ml >> i) & 1) ? 0.0 : mtg_mul(X[i][c], dinv[i]);
+    }
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+#pragma unroll
+      for (int q = 0; q < H; ++q) {
+        ln.Sc[p][q] = 0.0;
+        if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
+      }
+    }
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+      for (int p = 0; p < H; ++p) ln.rc[dm][p] = rnext[dm][p];
+    }
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+      if ((ml >> m) & 1) continue;
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+        if ((mr >> p) & 1) continue;
+#pragma unroll
+        for (int q = 0; q <= p; ++q) {
+          if ((mr >> q) & 1) continue;
+          ln.Sc[p][q] = mtg_fma(-X[m][p], Y[m][q], ln.Sc[p][q]);
+        }
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-X[m][p], Y[m][H + dm], ln.rc[dm][p]);
+      }
+    }
+    // g = L^-T D^-1 z (kept for the back-substitution; off the forward chain)
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+      if ((ml >> i) & 1) continue;
+#pragma unroll
+      for (int k = i + 1; k < H; ++k) {
+        if ((ml >> k) & 1) continue;
+#pragma unroll
+        for (int dm = 0; dm < D; ++dm) Y[i][H + dm] = mtg_fma(-A[k][i], Y[k][H + dm], Y[i][H + dm]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) g[dm][p] = ((ml >> p) & 1) ? 0.0 : Y[p][H + dm];
+    }
+  } else {
   // [G | g] = Dtilde^-1 [U | rv]: H + D right-hand sides solved together
   {
     double X[H][H + D];
@@ -546,7 +627,6 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   }
 
   // carried onto the right vertex: Sc' = a_rr - U^T G,  rc' = rnext - U^T g   (m outermost => independent FMAs adjacent)
-  const double* hrr = mtg_h1<C>(P);
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
@@ -574,6 +654,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-U[m][p], g[dm][m], ln.rc[dm][p]);
     }
+  }
   }
   if constexpr (C::kFS) {
     // factor store: the caller keeps the pivot block's factor in place of G (strict lower triangle: L, diagonal: 1 / d)

@@ -78,8 +78,9 @@ def test_dimlane_vs_oracle_and_split_form(ctx, shape, bsz):
     ref = ref.cpu().numpy()
     # Long chains keep the LDL^T FACTOR of a step's pivot block where the split form keeps G = Dtilde^-1 U (MtgCfg::kFS, round 4):
     # x_l = g - (L D L^T)^-1 (U x_r) against g - G x_r -- the same numbers up to the association of f^2 products per step
-    # (measured: <= 6e-12 over these shapes; both are equally far from the 50-digit solution, tests/test_lane_emu.py)
-    assert helpers.poly_relerr(got, ref) < (1e-12 if k <= 10 else 3e-11)
+    # (and the forward sweep eliminates the 2f x 2f step block partially instead of solving for G; measured: <= 6e-12 for N <= 10; both
+    # forms are equally far from the 50-digit solution, tests/test_lane_emu.py; N = 12: <= 1e-9, a tenth of what either form is from it)
+    assert helpers.poly_relerr(got, ref) < (1e-12 if k <= 10 else (3e-11 if n <= 10 else 3e-9))
     if shape in BITWISE_VS_SPLIT:
         assert np.array_equal(got, ref), "dimension-in-lane and dimension-split forms share the lane arithmetic"
     nchk = min(bsz, 64)
@@ -313,7 +314,7 @@ def test_runtime_k_body(ctx, ctx_rt, n, k, bsz):
     ref, _, _ = plan.solve(t, f, layout="soa")
     ctx.sync()
     rel, _ = ctx.compare_coefficients(co, ref)
-    assert rel < (1e-12 if n <= 10 else 1e-10), (plan.launch_form(bsz), rel)
+    assert rel < (1e-11 if n <= 10 else 3e-9), (plan.launch_form(bsz), rel)     # (factor-store body against the G form)
     nb = min(bsz, 6)
     th, fh = t.t()[:nb].contiguous().cpu().numpy(), f.permute(2, 0, 1)[:nb].contiguous().cpu().numpy()
     c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
@@ -336,7 +337,7 @@ def test_runtime_k_body_four_dimensions(ctx, n, k):
     ref, _, _ = plan.solve(t, f, layout="soa", dims="fused")
     ctx.sync()
     rel, _ = ctx.compare_coefficients(co, ref)
-    assert rel < (1e-11 if n <= 10 else 1e-9)
+    assert rel < (1e-11 if n <= 10 else 3e-9)
     th, fh = t.t()[:5].contiguous().cpu().numpy(), f.permute(2, 0, 1)[:5].contiguous().cpu().numpy()
     c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
     assert helpers.poly_relerr(co[:5].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
@@ -402,7 +403,17 @@ def test_runtime_k_body_many_tiles_per_workgroup(ctx, ctx_rt, case):
     ctx.sync()
     assert plan.launch_form(bsz, layout, other) != "dimlane_rt"
     rel, _ = ctx.compare_coefficients(co[:bsz].contiguous(), ref)
-    assert rel < (1e-11 if n <= 10 else 1e-9), (plan.launch_form(bsz, layout, other), rel)
+    if n <= 10:
+        assert rel < 1e-10, (plan.launch_form(bsz, layout, other), rel)
+    else:
+        # N = 12: the run-time-K body eliminates each step's block partially and keeps factors (MtgCfg::kFS), the other form solves
+        # for G -- different roundings of an R_PP whose condition number reaches 1e9 on a few of these 12k - 25k trajectories.
+        # Measured (K = 37): median 1.4e-11, 99.9 % below 4e-9, max 1.8e-7 on a trajectory where BOTH forms are 1.1e-6 / 1.3e-6
+        # from the 50-digit solution (this body the closer one).
+        den = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+        per = ((co[:bsz] - ref).abs() / den).amax(dim=(1, 2, 3))
+        assert float(per.median()) < 1e-9 and float(torch.quantile(per, 0.999)) < 1e-7 and float(per.max()) < 5e-6, \
+            (plan.launch_form(bsz, layout, other), float(per.median()), float(per.max()))
     rows = torch.tensor([0, 1, tpw, bsz // 2, bsz // 2 + 1, 2 * cus * tpw + 3, bsz - 2, bsz - 1], device="cuda")
     th = (t[:, rows].t() if layout == "soa" else t[rows]).contiguous().cpu().numpy()
     fh = (f[:, :, rows].permute(2, 0, 1) if layout == "soa" else f[rows]).contiguous().cpu().numpy()
@@ -543,12 +554,12 @@ def test_dimlane_extra_outputs(ctx, shape, bsz, layout):
     ctx.sync()
     assert torch.equal(co, co2) and torch.equal(fr, fr2) and torch.equal(cost, cost2) and torch.equal(cost, cost_only)
     assert torch.equal(co, co0)
-    tol = 1e-12 if n <= 10 else 1e-10
+    tol = (1e-12 if k < 32 else 1e-11) if n <= 10 else (1e-10 if k < 16 else 3e-9)     # (N = 12 long chains: factor-store form against the fused kernel's G form)
     rel, _ = ctx.compare_coefficients(co, cf)
     assert rel < tol
     # (N = 12 long chains: factor-store back-substitution here, G in the fused kernel; the cost is second order in the
     # coefficients but N = 12's are themselves only good to ~1e-8 -- measured 1.2e-9 at N = 12 / K = 32, 1.3e-11 at N = 10 / K = 32)
-    assert torch.allclose(cost, jf, rtol=(1e-11 if k < 32 else 5e-11) if n <= 10 else (1e-9 if k < 32 else 5e-9), atol=0)
+    assert torch.allclose(cost, jf, rtol=(1e-11 if k < 32 else 5e-11) if n <= 10 else (1e-9 if k < 16 else 3e-8), atol=0)
     scale = ff.abs().amax().clamp_min(1e-300)
     assert float((fr - ff).abs().amax() / scale) < tol
     nb = min(bsz, 4)
