@@ -105,5 +105,6 @@ def test_host_backend_single_call_latency(ctx):
         plan.lib.mtg_solve_linear(*args_d)
     us_d = (time.perf_counter() - t0) / 500 * 1e6
     print(f"single K=2 solve: host backend {us_h:.2f} us, device round trip {us_d:.2f} us (both incl. ctypes call overhead)")
-    assert us_h < 10.0 and us_h < us_d
+    # (2 us on an idle box; the suite may run six workers deep on a loaded one -- the claim is the ratio to a device round trip)
+    assert us_h < 100.0 and us_h < 0.5 * us_d
     plan.close()
