@@ -117,10 +117,10 @@ def test_dimlane_is_the_default_for_the_bench_call(ctx):
     plan = m.Plan(ctx, 10, 3, 8, 4, masks)
     t, f = m.random_waypoint_batch(10_000, 8, 3, 10, masks, seed=3, device="cuda", layout="soa")
     a, _, _ = plan.solve(t, f, layout="soa")
-    us_auto = plan.time_last_solve(20)
+    us_auto = min(plan.time_last_solve(20) for _ in range(4))      # (best of four replays: other test workers share the GPU)
     b, _, _ = plan.solve(t, f, layout="soa", dims="dimlane")
     c, _, _ = plan.solve(t, f, layout="soa", dims="fused")
-    us_fused = plan.time_last_solve(20)
+    us_fused = min(plan.time_last_solve(20) for _ in range(4))
     ctx.sync()
     assert torch.equal(a, b)
     den = c.abs().amax(dim=-1).clamp_min(1e-300)
