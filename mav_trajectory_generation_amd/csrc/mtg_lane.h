@@ -81,6 +81,14 @@ constexpr int mtg_ainv_offset(int n) {
 #ifndef MTG_FACTOR_STORE
 #define MTG_FACTOR_STORE 1     // (0: the round-3 form, G itself in the workspace -- A/B builds)
 #endif
+#ifndef MTG_PARTIAL_ALL
+// 1: EVERY kernel's forward step eliminates partially (Schur update from W = L^-1 U, the back-substitution for G after it).  Built and
+// measured in round 4 (profiles/r04v_*): the K = 8 kernels are unchanged at 100k (38.0 / 49.5 / 93.0 us), the bench line 0.668-0.671
+// (inside the box-to-box spread), and it exposed that a rank-deficient system is recognised by the SIGN of a pivot that is pure
+// round-off (mtg_ldl: !(d > 0)): with this association the under-constrained case of tests/cpp/test_veneer.cpp:424 gets a tiny
+// positive pivot and is not flagged.  Off until the pivot test is a relative threshold.
+#define MTG_PARTIAL_ALL 0
+#endif
 #ifndef MTG_FS_PARTIAL
 #define MTG_FS_PARTIAL 1       // (0: factor-store steps still solve for G in the forward sweep -- A/B builds)
 #endif
@@ -529,7 +537,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   mtg_ldl<H>(A, dinv, ml, ln.flags);
 
   const double* hrr = mtg_h1<C>(P);
-  if constexpr (C::kFS && MTG_FS_PARTIAL != 0) {
+  if constexpr ((C::kFS && MTG_FS_PARTIAL != 0) || MTG_PARTIAL_ALL != 0) {
     // Factor store, partial elimination: nothing in the FORWARD sweep needs G = Dtilde^-1 U itself.  With W = L^-1 U and
     // z = L^-1 rv (forward substitution only), U^T G = W^T D^-1 W and U^T g = W^T D^-1 z: the carried Schur complement is what
     // f pivots of the 2f x 2f block [Dtilde U; U^T a_rr] leave behind.  The back-substitution half of the solve is needed for
@@ -589,7 +597,10 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         for (int dm = 0; dm < D; ++dm) ln.rc[dm][p] = mtg_fma(-X[m][p], Y[m][H + dm], ln.rc[dm][p]);
       }
     }
-    // g = L^-T D^-1 z (kept for the back-substitution; off the forward chain)
+    // g = L^-T D^-1 z (kept for the back-substitution; off the forward chain) -- and, where the step keeps G itself rather than the
+    // factor (MTG_PARTIAL_ALL: every other kernel), G = L^-T D^-1 W as well: the same operations as before, after the Schur update
+    // instead of in front of it
+    constexpr int C0 = C::kFS ? H : 0;       // first column that is back-substituted
 #pragma unroll
     for (int i = H - 1; i >= 0; --i) {
       if ((ml >> i) & 1) continue;
@@ -597,11 +608,18 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       for (int k = i + 1; k < H; ++k) {
         if ((ml >> k) & 1) continue;
 #pragma unroll
-        for (int dm = 0; dm < D; ++dm) Y[i][H + dm] = mtg_fma(-A[k][i], Y[k][H + dm], Y[i][H + dm]);
+        for (int c = C0; c < H + D; ++c) {
+          if (c < H && ((mr >> c) & 1)) continue;
+          Y[i][c] = mtg_fma(-A[k][i], Y[k][c], Y[i][c]);
+        }
       }
     }
 #pragma unroll
     for (int p = 0; p < H; ++p) {
+      if constexpr (!C::kFS) {
+#pragma unroll
+        for (int q = 0; q < H; ++q) G[p][q] = (((ml >> p) & 1) || ((mr >> q) & 1)) ? 0.0 : Y[p][q];
+      }
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) g[dm][p] = ((ml >> p) & 1) ? 0.0 : Y[p][H + dm];
     }
