@@ -175,12 +175,13 @@ extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long
   return 0;
 }
 
-// Shared-workspace dimension-in-lane emulation (emu_solve_shared): D = 3, trajectory ends fully fixed, interior vertices
-// position-only, derivative N / 2 - 1; K in {4, 8}.  Returns -2 for any other shape.  kept_is_factor: MtgCfg::kFS of the build.
-extern "C" int mtg_emu_run_shared(int N, int K, long long B, const double* times, const double* dfix, double* coeffs,
+// Shared-workspace dimension-in-lane emulation (emu_solve_shared): D = 3, trajectory ends fully fixed, every interior vertex with
+// the mask `mi` (1 = position only; 3 / 7 = + velocity / + acceleration, N = 10 only: the run-time-K table's other patterns),
+// derivative N / 2 - 1; K in {4, 8}.  Returns -2 for any other shape.  kept_is_factor: MtgCfg::kFS of the build.
+extern "C" int mtg_emu_run_shared(int N, int K, int mi, long long B, const double* times, const double* dfix, double* coeffs,
                                   int* status, int* kept_is_factor) {
   const int H = N / 2, D = 3;
-  const int n_fixed = 2 * H + (K - 1);
+  const int n_fixed = 2 * H + (K - 1) * __builtin_popcount((unsigned)mi);
   MtgParams P;
   std::memset(&P, 0, sizeof(P));
   P.times = times; P.ts_b = K; P.ts_k = 1;
@@ -191,15 +192,16 @@ extern "C" int mtg_emu_run_shared(int N, int K, long long B, const double* times
   P.B = B; P.K = K; P.Dtot = D; P.deriv = H - 1;
   P.ainvoff = kAinvLoOff[H];
   P.h1off = kH1Off[H][H - 1];
-#define SHARED(HH, KK)                                                                                   \
-  if (H == HH && K == KK) {                                                                              \
-    using C = MtgCfg<HH, 1, KK, (1 << HH) - 1, 1, (1 << HH) - 1, HH - 1, 0, (KK + 1) / 2, 3, 0, 0>;       \
+#define SHARED(HH, KK, MI)                                                                               \
+  if (H == HH && K == KK && mi == MI) {                                                                  \
+    using C = MtgCfg<HH, 1, KK, (1 << HH) - 1, MI, (1 << HH) - 1, HH - 1, 0, (KK + 1) / 2, 3, 0, 0>;      \
     if (kept_is_factor) *kept_is_factor = C::kFS ? 1 : 0;                                                \
     emu_solve_shared<C>(P);                                                                              \
     if (status) *status = st;                                                                            \
     return 0;                                                                                            \
   }
-  SHARED(4, 4) SHARED(4, 8) SHARED(5, 4) SHARED(5, 8) SHARED(6, 4) SHARED(6, 8)
+  SHARED(4, 4, 1) SHARED(4, 8, 1) SHARED(5, 4, 1) SHARED(5, 8, 1) SHARED(6, 4, 1) SHARED(6, 8, 1)
+  SHARED(5, 8, 3) SHARED(5, 8, 7) SHARED(5, 5, 3) SHARED(6, 5, 1)
 #undef SHARED
   return -2;
 }

@@ -144,8 +144,9 @@ def test_extreme_time_ratios_stay_closer_to_truth_than_the_literal_route(host_em
     assert e_kernel < 1e-5 and e_kernel < 1e-2 * e_lit
 
 
-@pytest.mark.parametrize("n,k", [(8, 4), (8, 8), (10, 4), (10, 8), (12, 4), (12, 8)])
-def test_shared_workspace_factor_store_emulation(host_emu, n, k):
+@pytest.mark.parametrize("n,k,mi", [(8, 4, 1), (8, 8, 1), (10, 4, 1), (10, 8, 1), (12, 4, 1), (12, 8, 1),
+                                    (10, 8, 3), (10, 8, 7), (10, 5, 3), (12, 5, 1)])     # + other interior masks, odd K
+def test_shared_workspace_factor_store_emulation(host_emu, n, k, mi):
     """The dimension-in-lane form with shared step storage, every step through the lane-coalesced workspace: three dimension
     lanes of a trajectory keep ONE copy of a step's matrix between them -- since round 4 the LDL^T factor of the pivot block
     (MtgCfg::kFS), with U rebuilt from the table at back-substitution time -- and must reproduce the generic lane code
@@ -153,16 +154,16 @@ def test_shared_workspace_factor_store_emulation(host_emu, n, k):
     import ctypes
     from oracle import cpu_ref
     dp = ctypes.POINTER(ctypes.c_double)
-    host_emu.mtg_emu_run_shared.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, dp, dp, dp,
+    host_emu.mtg_emu_run_shared.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, dp, dp, dp,
                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     host_emu.mtg_emu_run_shared.restype = ctypes.c_int
     d, dim, bsz = n // 2 - 1, 3, 24
-    masks = helpers.masks_ends_full(n, k)
+    masks = helpers.masks_ends_full(n, k, mi)
     _, times, fixed = helpers.reference_batch(bsz, k, n, dim, 900 + n + k, masks)
     times, fixed = np.ascontiguousarray(times), np.ascontiguousarray(fixed)
     co = np.zeros((bsz, k, dim, n))
     st, fs = ctypes.c_int(0), ctypes.c_int(-1)
-    rc = host_emu.mtg_emu_run_shared(n, k, bsz, times.ctypes.data_as(dp), fixed.ctypes.data_as(dp), co.ctypes.data_as(dp),
+    rc = host_emu.mtg_emu_run_shared(n, k, mi, bsz, times.ctypes.data_as(dp), fixed.ctypes.data_as(dp), co.ctypes.data_as(dp),
                                      ctypes.byref(st), ctypes.byref(fs))
     assert rc == 0 and st.value == 0
     assert fs.value == 1        # this build keeps factors
