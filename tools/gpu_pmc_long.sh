@@ -1,21 +1,22 @@
 #!/bin/bash
 # FP64-issue evidence for the long-chain kernels: VALU instructions and busy cycles per launch (rocprofv3 --pmc, its own
-# run, kernel trace only) next to the kernel durations -> gpurun_out/r03_long_pmc.json
+# run, kernel trace only) next to the kernel durations -> gpurun_out/${TAG}_long_pmc.json
 set -u
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/r03_long_pmc -o p -- python $R/tools/bench_configs.py long > $OUT/r03_long_pmc_bench.txt 2> $OUT/r03_long_pmc.err
-python - $OUT <<'PY'
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_long_pmc -o p -- python $R/tools/bench_configs.py long > $OUT/${TAG}_long_pmc_bench.txt 2> $OUT/${TAG}_long_pmc.err
+python - $OUT $TAG <<'PY'
 import csv, glob, json, os, sys, collections
-out = sys.argv[1]
-f = glob.glob(os.path.join(out, "r03_long_pmc", "**", "*counter_collection.csv"), recursive=True)
+out, tag = sys.argv[1], sys.argv[2]
+f = glob.glob(os.path.join(out, tag + "_long_pmc", "**", "*counter_collection.csv"), recursive=True)
 rows = list(csv.DictReader(open(f[0]))) if f else []
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     if "mtg_solve_dl" in r["Kernel_Name"]:
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-tr = glob.glob(os.path.join(out, "r03_long_pmc", "**", "*kernel_trace.csv"), recursive=True)
+tr = glob.glob(os.path.join(out, tag + "_long_pmc", "**", "*kernel_trace.csv"), recursive=True)
 dur = collections.defaultdict(list)
 if tr:
     for r in csv.DictReader(open(tr[0])):
@@ -32,7 +33,8 @@ for k, c in acc.items():
         d["issue_bound_us_at_2p4GHz"] = d["valu_issue_cycles_per_simd"] / 2400.0
         d["issue_utilisation_if_2p4GHz"] = d["issue_bound_us_at_2p4GHz"] / (d["mean_ns_profiled"] * 1e-3)
     res.append(d)
-json.dump(res, open(os.path.join(out, "r03_long_pmc.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, tag + "_long_pmc.json"), "w"), indent=1)
 for d in res:
     print(json.dumps(d))
 PY
+rm -rf $OUT/${TAG}_long_pmc   # (raw traces: gpurun_out/ is capped at 64 MiB)
