@@ -56,8 +56,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="trajectories per step per GPU (default: the config's)")
-    ap.add_argument("--buffer-sets", type=int, default=16, help="independent input/output buffer sets the timed loop "
-                    "rotates over (1 = everything stays resident in the Infinity Cache)")
+    ap.add_argument("--buffer-sets", type=int, default=None, help="independent input/output buffer sets the timed loop "
+                    "rotates over (1 = everything stays resident in the Infinity Cache).  Default (round 5): enough sets that "
+                    "the timed steps touch NO set the warm-up / settle phases used (steps + warmup) and that the rotation is "
+                    ">= 1.25 GiB, 5x the 256 MiB Infinity Cache -- at least 16 (rounds 2-4 rotated over 16 sets = 382 MiB "
+                    "for config 2, 1.4x the cache; measured in round 5: 0.665 with 16, 0.644 with 48, 0.639 with 128 sets)")
     ap.add_argument("--layout", default=None, choices=["aos", "soa", "soa16"],
                     help="input layout (default: soa; config 5: soa16 = SoA with the row stride padded to a multiple of 16 "
                          "trajectories, so that the row pieces of a 12 500-trajectory batch start on 128-byte boundaries)")
@@ -572,8 +575,16 @@ def main():
     masks = m.ends_full_masks(N, K, cfg["interior"])
     ctx = m.Context(device_index)
     plan = m.Plan(ctx, N, D, K, d, masks)
-    nsets = max(1, args.buffer_sets)
     per_batch = args.sequence == "launches"
+    if args.buffer_sets is None:
+        if mixed:
+            nsets = max(16, min(args.steps + args.warmup, 32))
+        else:
+            per_set = B * plan.bytes_per_trajectory
+            nsets = max(16, args.steps + args.warmup, -(-(5 * 2**28) // per_set))
+            nsets = min(nsets, 256, max(2, (24 * 2**30) // per_set))
+    else:
+        nsets = max(1, args.buffer_sets)
 
     def barrier():
         if grouped:
@@ -752,6 +763,11 @@ def main():
             if args.steps != 96 and not per_batch and not big:
                 us, wall = side_run(loop, 96, warm=96)
                 extra["rotating_buffers_96_steps_one_full_launch"] = side_entry(us, wall, 96, nsets)
+            if nsets > 16:
+                # the rotation rounds 2-4 reported `value` on (16 sets: 382 MiB for config 2, 1.4x the Infinity Cache), same steps
+                small = SolveLoop(plan, sets[:16], args.layout, args.dims, per_batch)
+                us, wall = side_run(small, args.steps, warm=args.warmup)
+                extra["rotation_over_16_sets_as_in_rounds_2_to_4"] = side_entry(us, wall, args.steps, 16)
             # context for small launches: a write-only fill of the same coefficient buffer (zero compute, zero reads)
             co0 = sets[0][2]
             co0_copy = co0.clone()

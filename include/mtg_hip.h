@@ -120,9 +120,12 @@ enum {
                                      /* variables beyond the rank zero) and their outputs     */
                                      /* replaced; the call then reports MTG_OK for them (bit 2 */
                                      /* stays set in trajectory_status: WHICH ones were basic).*/
-                                     /* The call is SYNCHRONOUS and, for device pointers,     */
-                                     /* consumes the context's status word like               */
-                                     /* mtg_context_sync.  Not with MTG_FLAG_COST_ONLY.       */
+                                     /* The call is SYNCHRONOUS and carries its OWN status     */
+                                     /* word (host and device pointers alike): flags raised   */
+                                     /* by earlier asynchronous launches stay in the context  */
+                                     /* for the next mtg_context_sync.  Not with              */
+                                     /* MTG_FLAG_COST_ONLY; rejected (invalid argument) by    */
+                                     /* mtg_solve_linear_sequence* and mtg_multi_create.      */
 };
 #define MTG_HOST_BACKEND_MAX_BATCH 64
 
@@ -145,6 +148,17 @@ int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
 /* The context a plan was created on (its stream, status word and error text): host objects that hold a plan and may be
  * used from another thread than their creator synchronise THIS context, not their own thread's.                     */
 mtg_context* mtg_plan_context(const mtg_plan* plan);
+/* STRUCTURAL rank deficiency of the plan's free system R_PP (0: regular).  The cost's null space is the polynomials of degree
+ * < derivative_to_optimize over the whole trajectory; what the fixed slots leave of it is a property of the constraint pattern,
+ * not of a batch's values (under-constrained problems: fewer than d independent position / velocity / ... constraints in the
+ * whole trajectory).  Every trajectory of such a plan is flagged MTG_ERR_SINGULAR (bit 1 of the per-trajectory status) by every
+ * solve -- the reference's rank-revealing SparseQR returns a basic solution there (LIN:365-378): ask for it with
+ * MTG_FLAG_BASIC_SOLUTION.  On regular plans the kernels' own pivot test (d_j <= 20 (n_free + n_free) eps R_PP[j][j], the form
+ * of SparseQR's default threshold relative to the variable's own diagonal) flags trajectories whose pivots lost every digit.  */
+int mtg_plan_rank_deficiency(const mtg_plan* plan);
+/* The same number from the description alone (host arithmetic only: no context, no device): fixed_mask[n_segments + 1] as in
+ * mtg_plan_desc.  Negative: mtg_status.                                                                                      */
+int mtg_structural_rank_deficiency(int32_t n_coeffs, int32_t n_segments, int32_t derivative_to_optimize, const uint32_t* fixed_mask);
 /* Which kernel form a device-pointer mtg_solve_linear(plan, batch, layout, ..., flags) call with coefficient output only
  * (with MTG_FLAG_QUERY_EXTRA_OUTPUTS: a call that also returns the cost / d_free) takes on this device: 0 generic (run-time K / masks), 1 fused static, 2 dimension-split static, 3 rolled (run-time K),
  * 4 fused with slab output (whole-sector stores), 5 dimension-in-lane (one unrolled body per chain length), 6 dimension-in-lane

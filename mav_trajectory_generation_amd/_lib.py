@@ -44,6 +44,8 @@ EXPORTS = {
     "mtg_plan_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mtg_plan_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]),
     "mtg_plan_context": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mtg_plan_rank_deficiency": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_structural_rank_deficiency": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32)]),
     "mtg_plan_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_uint32]),
     "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),
     "mtg_layout_soa": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),

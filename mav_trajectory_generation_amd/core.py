@@ -201,6 +201,9 @@ class Plan:
         self.n_all, self.n_fixed, self.n_free = info.n_all, info.n_fixed, info.n_free
         self.kernel_variant = info.kernel_variant
         self.bytes_per_trajectory = info.algorithmic_bytes_per_trajectory
+        # structural rank deficiency of the free system (0: regular; > 0: every solve flags every trajectory singular and
+        # basic_solution=True gives the reference's basic solution, LIN:365-378)
+        self.rank_deficiency = self.lib.mtg_plan_rank_deficiency(h)
 
     def layout(self, batch: int, kind: str) -> L.Layout:
         lay = L.Layout()

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,6 +162,7 @@ struct mtg_plan {
   std::vector<int> mask;            // [K+1]
   std::vector<int> offF, offP;      // [K+2]
   int n_fixed = 0, n_free = 0;
+  int null_dim = 0;                 // STRUCTURAL rank deficiency of the free system R_PP (structural_null_dim below)
   int* d_tables = nullptr;          // vmask | offF | offP
   const MtgStaticEntry* fast = nullptr;        // all dimensions in one workgroup
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
@@ -179,6 +181,9 @@ struct mtg_plan {
   // staging for MTG_FLAG_HOST_POINTERS
   double* stage = nullptr;
   size_t stage_bytes = 0;
+  // MTG_FLAG_BASIC_SOLUTION with device pointers: [status word (8 bytes) | per-trajectory status int32 [batch]] of the call itself
+  double* basic_status = nullptr;
+  size_t basic_status_bytes = 0;
   std::vector<LaunchRecord> last;
 };
 
@@ -401,6 +406,94 @@ int mtg_context_sync(mtg_context* ctx) {
   return status_code(ctx, *ctx->h_status);
 }
 
+// STRUCTURAL rank deficiency of R_PP.  The cost 0.5 d^T R d = sum over segments of the integral of (p^(d))^2 (LIN:124-140) vanishes
+// exactly on the trajectories whose every segment is a polynomial of degree < d; interior vertices share all h >= d + 1
+// derivative slots (LIN:199-205), so those are ONE polynomial of degree < d over the whole trajectory, and the null space of R_PP
+// is the subspace of it on which every FIXED slot vanishes: the functionals  p -> p^(q)(t_v)  for the fixed slots (v, q), q < d.
+// Its dimension d - rank(those functionals on P_(d-1)) depends on the constraint PATTERN only (Hermite data at distinct
+// instants are always independent; Birkhoff-type patterns -- a derivative fixed without the lower ones -- generically), not on
+// the batch's segment times: it is computed here, once per plan, at two sets of generic vertex instants.
+// Why not in the kernels: the reference decides "rank-deficient" with a rank-revealing QR (LIN:365-367); an LDL^T sweep sees a
+// zero pivot as round-off x the conditioning of everything eliminated before it -- on chains of free vertices that is anything
+// between 1e-12 and 1e0 of the diagonal, of either sign (tests/test_pivot_threshold.py), overlapping the legitimate pivots of
+// regular ill-conditioned problems (1e-7 of the diagonal).  No pivot threshold separates the two; the structure does.
+static int structural_null_dim(int H, int K, int d, const std::vector<int>& mask) {
+  if (d <= 0) return 0;
+  int best_rank = 0;
+  for (int trial = 0; trial < 2 && best_rank < d; ++trial) {
+    std::vector<long double> rows;     // [nrows][d]
+    long double t = 0.0L;
+    for (int v = 0; v <= K; ++v) {
+      // generic instants in [0, 1]: increments from a fixed irrational rotation (no two trials share a ratio)
+      const long double u = (v + 1) * (trial == 0 ? 0.6180339887498948482L : 0.4142135623730950488L);
+      if (v > 0) t += (0.35L + (u - (long long)u)) / (long double)K;
+      for (int q = 0; q < H && q < d; ++q) {
+        if (!((mask[v] >> q) & 1)) continue;
+        for (int m = 0; m < d; ++m) {
+          long double c = 0.0L;
+          if (m >= q) {
+            c = 1.0L;
+            for (int i = 0; i < q; ++i) c *= (long double)(m - i);
+            for (int i = 0; i < m - q; ++i) c *= t;
+          }
+          rows.push_back(c);
+        }
+      }
+    }
+    const int nr = (int)(rows.size() / (size_t)d);
+    int rank = 0;
+    std::vector<char> used((size_t)nr, 0);
+    for (int col = 0; col < d; ++col) {          // Gaussian elimination, largest remaining entry of the column as pivot
+      int piv = -1;
+      long double big = 1e-9L;                   // entries are O(1) .. O(d!) on [0, 1]
+      for (int r = 0; r < nr; ++r)
+        if (!used[r] && std::fabs(rows[(size_t)r * d + col]) > big) { big = std::fabs(rows[(size_t)r * d + col]); piv = r; }
+      if (piv < 0) continue;
+      used[piv] = 1;
+      ++rank;
+      for (int r = 0; r < nr; ++r) {
+        if (r == piv) continue;
+        const long double f = rows[(size_t)r * d + col] / rows[(size_t)piv * d + col];
+        if (f == 0.0L) continue;
+        for (int c = 0; c < d; ++c) rows[(size_t)r * d + c] -= f * rows[(size_t)piv * d + c];
+      }
+    }
+    best_rank = std::max(best_rank, rank);
+  }
+  return d - best_rank;
+}
+
+namespace {
+// Plans whose free system is structurally rank-deficient: every trajectory of a solve is flagged (context word and, when the
+// caller asked for it, the per-trajectory status), whatever the sweep's pivots looked like.
+__global__ void mtg_flag_all_kernel(int* status, int* tstatus, long long B, int flag) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0 && status) atomicOr(status, flag);
+  if (tstatus && b < B) atomicOr(tstatus + b, flag);
+}
+}  // namespace
+static void flag_structurally_singular(const mtg_plan* p, hipStream_t st, int* status, int* tstatus, int64_t batch) {
+  if (p->null_dim <= 0 || p->n_free == 0) return;
+  const int64_t n = tstatus ? batch : 1;
+  hipLaunchKernelGGL(mtg_flag_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, status, tstatus, (long long)batch, (int)MTG_FLAG_SINGULAR);
+}
+
+int mtg_plan_rank_deficiency(const mtg_plan* p) { return p ? p->null_dim : MTG_ERR_INVALID_ARGUMENT; }
+
+int mtg_structural_rank_deficiency(int32_t n_coeffs, int32_t n_segments, int32_t derivative_to_optimize, const uint32_t* fixed_mask) {
+  if (n_coeffs < 2 || n_coeffs > MTG_MAX_N || (n_coeffs & 1) || n_segments < 1 || !fixed_mask || derivative_to_optimize < 0 ||
+      derivative_to_optimize > n_coeffs / 2 - 1)
+    return MTG_ERR_INVALID_ARGUMENT;
+  const int H = n_coeffs / 2;
+  std::vector<int> mask((size_t)n_segments + 1);
+  int n_free = 0;
+  for (int v = 0; v <= n_segments; ++v) {
+    mask[v] = (int)(fixed_mask[v] & (uint32_t)((1 << H) - 1));
+    n_free += H - __builtin_popcount((unsigned)mask[v]);
+  }
+  return n_free > 0 ? structural_null_dim(H, n_segments, derivative_to_optimize, mask) : 0;
+}
+
 int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out) {
   if (!ctx || !desc || !out || !desc->fixed_mask) return MTG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -423,6 +516,7 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   }
   p->n_fixed = p->offF[K + 1];
   p->n_free = p->offP[K + 1];
+  p->null_dim = p->n_free > 0 ? structural_null_dim(p->H, K, d, p->mask) : 0;
   p->fast = mtg_find_static(p->H, D, K, d, p->mask.data());
   for (int dg = 1; dg < D && !p->fast_split; ++dg) {
     if (D % dg == 0) p->fast_split = mtg_find_static(p->H, dg, K, d, p->mask.data());
@@ -451,6 +545,7 @@ int mtg_plan_destroy(mtg_plan* p) {
   if (p->ws) hipFree(p->ws);
   if (p->pert_cost) hipFree(p->pert_cost);
   if (p->stage) hipFree(p->stage);
+  if (p->basic_status) hipFree(p->basic_status);
   delete p;
   return MTG_OK;
 }
@@ -976,6 +1071,10 @@ static int solve_on_host_backend(mtg_plan* p, int64_t batch, const mtg_layout* L
   P.vmask = p->mask.data(); P.offF = p->offF.data(); P.offP = p->offP.data();
   if (traj_status) std::memset(traj_status, 0, (size_t)batch * sizeof(int32_t));
   if (mtg_host_run(P, p->H, update_only) != 0) return MTG_ERR_UNSUPPORTED;
+  if (!update_only && p->null_dim > 0 && p->n_free > 0) {      // structurally rank-deficient free system: every trajectory
+    st_word |= MTG_FLAG_SINGULAR;
+    if (traj_status) for (int64_t b = 0; b < batch; ++b) traj_status[b] |= MTG_FLAG_SINGULAR;
+  }
   if (st_word & MTG_FLAG_BAD_TIME) return MTG_ERR_BAD_SEGMENT_TIME;
   if (st_word & MTG_FLAG_SINGULAR) return MTG_ERR_SINGULAR;
   return MTG_OK;
@@ -984,7 +1083,9 @@ static int solve_on_host_backend(mtg_plan* p, int64_t batch, const mtg_layout* L
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only,
                       int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr,
-                      hipStream_t on_stream = nullptr) {
+                      hipStream_t on_stream = nullptr, int* own_status_dev = nullptr) {
+  // own_status_dev: a device status word of the CALL (zeroed here) instead of the context's -- flags of earlier asynchronous
+  // launches stay where the next mtg_context_sync finds them
   const bool cost_only = !update_only && (flags & MTG_FLAG_COST_ONLY) != 0;
   if (!p || !L || !times || (!coeffs && !cost_only) || batch < 0) return MTG_ERR_INVALID_ARGUMENT;
   if (cost_only && (!cost || (flags & MTG_FLAG_HOST_POINTERS))) return MTG_ERR_INVALID_ARGUMENT;
@@ -1014,9 +1115,11 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   if (dcs) MTG_HIP_TRY(ctx, hipMemsetAsync(dcs, 0, (pert ? (size_t)(p->K + 1) : (size_t)1) * batch * sizeof(double), c.st));
   if (c.dts) MTG_HIP_TRY(ctx, hipMemsetAsync(c.dts, 0, batch * sizeof(int32_t), c.st));
   if (h.status_dev) MTG_HIP_TRY(ctx, hipMemsetAsync(h.status_dev, 0, sizeof(double), c.st));
+  if (own_status_dev && !host) MTG_HIP_TRY(ctx, hipMemsetAsync(own_status_dev, 0, sizeof(double), c.st));
 
   fill_common(p, c.P, batch, L);
   if (h.status_dev) c.P.status = h.status_dev;
+  else if (own_status_dev) c.P.status = own_status_dev;
   c.P.times = dt; c.P.dfix = dfx; c.P.coeffs = dco; c.P.dfree = (p->n_free ? dfr : nullptr); c.P.cost = dcs;
   c.P.tstatus = c.dts;
   c.wc = dcs != nullptr || (!update_only && c.P.dfree != nullptr);
@@ -1037,6 +1140,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
     case SolveForm::kFused: rc = launch_fused(c); break;
   }
   if (rc != MTG_OK) return rc;
+  if (!update_only) flag_structurally_singular(p, c.st, c.P.status, c.P.tstatus, batch);
   MTG_HIP_TRY(ctx, hipGetLastError());
 
   if (host) {
@@ -1101,28 +1205,36 @@ static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layou
   if (batch <= 0) return solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, traj_status);
   std::vector<int32_t> ts((size_t)batch, 0);
   int32_t* dev_ts = nullptr;           // device-pointer calls: the per-trajectory status the kernels write
-  bool own_dev_ts = false;
   int rc;
   if (host) {
     rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, ts.data());
     if (traj_status) std::memcpy(traj_status, ts.data(), (size_t)batch * sizeof(int32_t));
     if (rc != MTG_ERR_SINGULAR && rc != MTG_ERR_BAD_SEGMENT_TIME) return rc;
   } else {
-    dev_ts = traj_status;
-    if (!dev_ts) {
+    // The call has its OWN device status word and (when the caller passes none) per-trajectory status, in a buffer of the plan:
+    // it neither reads nor clears the context's word, so SINGULAR / BAD_TIME flags left by earlier asynchronous launches of
+    // this context are still there for the caller's next mtg_context_sync (round 4 went through mtg_context_sync and lost them).
+    int* own_word = nullptr;
+    {
       std::lock_guard<std::mutex> lock(ctx->mu);
       MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-      MTG_HIP_TRY(ctx, hipMalloc((void**)&dev_ts, (size_t)batch * sizeof(int32_t)));
-      own_dev_ts = true;
+      const int rb = ensure_buffer(ctx, &p->basic_status, &p->basic_status_bytes, sizeof(double) + (size_t)batch * sizeof(int32_t));
+      if (rb != MTG_OK) return rb;
+      own_word = reinterpret_cast<int*>(p->basic_status);
+      dev_ts = traj_status ? traj_status : reinterpret_cast<int32_t*>(p->basic_status + 1);
     }
-    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, dev_ts);
-    if (rc == MTG_OK) rc = mtg_context_sync(ctx);      // (consumes the context's status word: documented with the flag)
-    if (rc == MTG_ERR_SINGULAR || rc == MTG_ERR_BAD_SEGMENT_TIME) {
+    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, dev_ts, nullptr, nullptr, own_word);
+    if (rc != MTG_OK) return rc;
+    {
       std::lock_guard<std::mutex> lock(ctx->mu);
-      if (hipMemcpy(ts.data(), dev_ts, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = MTG_ERR_DEVICE;
+      MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+      int word = 0;
+      MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, own_word, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      word = *ctx->h_status;
+      if (word == 0) return MTG_OK;
+      MTG_HIP_TRY(ctx, hipMemcpy(ts.data(), dev_ts, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
-    if (own_dev_ts) { std::lock_guard<std::mutex> lock(ctx->mu); hipFree(dev_ts); }
-    if (rc != MTG_ERR_SINGULAR && rc != MTG_ERR_BAD_SEGMENT_TIME) return rc;
   }
   // one flagged trajectory after the other: gather its inputs (any strides), solve, recover, scatter
   const int K = p->K, D = p->D, nf = p->n_fixed, np = p->n_free, N = p->N;
@@ -1188,7 +1300,7 @@ int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* lay
 static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_layout* L, const double* const* times,
                              const double* const* d_fixed, double* const* coeffs, uint32_t flags) {
   mtg_context* ctx = p->ctx;
-  if (n < 2 || batch <= 0 || ctx->knob_no_queue) return 1;
+  if (n < 2 || batch <= 0 || ctx->knob_no_queue || p->null_dim > 0) return 1;
   if (flags & (MTG_FLAG_GENERIC_KERNEL | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH)) return 1;
   const int32_t n_launch = std::min<int32_t>(n, kSeqMax);       // batches per launch
   const MtgSlabEntry* slab = nullptr;
@@ -1259,6 +1371,8 @@ int mtg_solve_linear_sequence_events(mtg_plan* plan, int32_t n, int64_t batch, c
   if (!plan || !layout || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
   if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = plan->ctx;
+  if (flags & MTG_FLAG_BASIC_SOLUTION)   // (a synchronous per-call service of mtg_solve_linear / _status: a queue stays asynchronous)
+    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_BASIC_SOLUTION: mtg_solve_linear / mtg_solve_linear_status only");
   if (start_event) {
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)start_event, ctx->stream));
@@ -1394,6 +1508,8 @@ int mtg_multi_destroy(mtg_multi* m) {
 int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* items, uint32_t flags, mtg_multi** out) {
   if (!ctx || !items || !out || n_items < 1) return MTG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  if (flags & MTG_FLAG_BASIC_SOLUTION)
+    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_BASIC_SOLUTION: mtg_solve_linear / mtg_solve_linear_status only");
   for (int i = 0; i < n_items; ++i) {
     const mtg_multi_item& it = items[i];
     if (!it.plan || it.plan->ctx != ctx || it.batch < 0 || !it.times || !it.coeffs || (it.plan->n_fixed > 0 && !it.d_fixed))
@@ -1685,6 +1801,8 @@ int mtg_multi_solve(mtg_multi* m) {
       }
       hipLaunchKernelGGL(fn, dim3(g.grid, g.ngroups), dim3(kBlock), g.lds, ctx->stream, (const MtgParams*)g.d_table,
                          (const MtgTileRef*)g.d_tiles, g.ntiles);
+      for (int i : g.items)   // (merged groups are compile-time-mask shapes with fully fixed ends: never rank-deficient; kept for symmetry)
+        flag_structurally_singular(m->items[i].plan, ctx->stream, ctx->d_status, nullptr, m->items[i].batch);
     }
     MTG_HIP_TRY(ctx, hipGetLastError());
   }

@@ -261,6 +261,8 @@ struct MtgLane {
   double g[C::KREG][C::D][C::H];  // g_v = Dtilde_v^-1 rtilde_v
   double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
   double rc[C::D][C::H];          // its right-hand side
+  double dg[C::H];                // diagonal of the previous segment's end/end block at the carried vertex: with this step's
+                                  // start/start diagonal it is R_PP's ORIGINAL diagonal entry, the scale of the pivot threshold
   double T[C::KCS];               // static mode: this lane's segment times, chain order
   double fx[C::D][C::NC];         // static mode: this lane's fixed values (columns colBegin..colEnd)
   int flags;
@@ -336,15 +338,32 @@ MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, cons
   }
 }
 
+// Pivot threshold of the LDL^T sweep, relative to R_PP's own diagonal.  The reference factorises R_PP with Eigen's rank-revealing
+// SparseQR (impl/polynomial_optimization_linear_impl.h:365-367), which treats a pivot as zero when it is at most
+// 20 (rows + cols) eps x (largest column norm) (SparseQR::factorize, default threshold).  The sweep's analogue: pivot j of the
+// n_free x n_free system counts as zero when d_j <= tau * R_PP[j][j], tau = 20 (n_free + n_free) eps -- the pivot has lost every
+// digit of the diagonal entry it started from.  (Rounds 1-4 tested the SIGN of d_j: on a rank-deficient system d_j is pure
+// round-off, and whether it came out negative depended on the association of the Schur update.)  The scale is per VARIABLE, not
+// the global column norm: derivative slots differ by powers of the segment times (T^(1 - 2d + 2p)), and a global scale would
+// declare the slots of a long segment next to a short one rank-deficient.  A well-posed problem has d_j / R_PP[j][j] >= 1 / cond
+// >= 1e-8, a rank-deficient one ~1e-16: tau ~ 1e-13 separates them under every association.
+template <class C>
+MTG_HD double mtg_pivot_tau(const MtgParams& P) {
+  int nfree;
+  if constexpr (C::kCT) nfree = (C::H - mtg_popc(C::MS)) + (mtg_nseg<C>(P) - 1) * (C::H - mtg_popc(C::MI)) + (C::H - mtg_popc(C::ME));
+  else nfree = P.offP[P.K + 1];
+  return 40.0 * 2.220446049250313e-16 * (double)nfree;
+}
+
 // in-place LDL^T on the index set {p : bit p of `fixed` clear}; A lower triangle in, L (strict
-// lower) out, dinv = 1/d.
+// lower) out, dinv = 1/d.  thr[j]: pivot threshold of variable j (above).
 template <int H>
-MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, int& flags) {
+MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, const double (&thr)[H], int& flags) {
 #pragma unroll
   for (int j = 0; j < H; ++j) {
     if ((fixed >> j) & 1) continue;
     const double dj = A[j][j];
-    if (!(dj > 0.0)) flags |= MTG_FLAG_SINGULAR;
+    if (!(dj > thr[j])) flags |= MTG_FLAG_SINGULAR;
     const double r = mtg_rcp(dj);
     dinv[j] = r;
     double l[H];
@@ -517,12 +536,15 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   }
 
   // Dtilde_l = Sc + a_ll (free x free, lower), U = a_lr (free_l x free_r)
-  double A[H][H], U[H][H], dinv[H];
+  double A[H][H], U[H][H], dinv[H], thr[H];
   {
     const double* hc = mtg_h1<C>(P);
+    const double tau = mtg_pivot_tau<C>(P);
 #pragma unroll
     for (int p = 0; p < H; ++p) {
       dinv[p] = 0.0;
+      // pivot threshold: tau x (this segment's start/start diagonal + the previous segment's end/end diagonal) = tau x R_PP[p][p]
+      thr[p] = ((ml >> p) & 1) ? 0.0 : mtg_mul(tau, mtg_fma(mtg_mul(bs[p], s[p]), hc[p * N + p], ln.dg[p]));
 #pragma unroll
       for (int q = 0; q < H; ++q) {
         A[p][q] = 0.0;
@@ -534,9 +556,11 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       }
     }
   }
-  mtg_ldl<H>(A, dinv, ml, ln.flags);
+  mtg_ldl<H>(A, dinv, ml, thr, ln.flags);
 
   const double* hrr = mtg_h1<C>(P);
+#pragma unroll
+  for (int p = 0; p < H; ++p) ln.dg[p] = ((mr >> p) & 1) ? 0.0 : mtg_mul(mtg_mul(bs[p], s[p]), hrr[(H + p) * N + H + p]);
   if constexpr ((C::kFS && MTG_FS_PARTIAL != 0) || MTG_PARTIAL_ALL != 0) {
     // Factor store, partial elimination: nothing in the FORWARD sweep needs G = Dtilde^-1 U itself.  With W = L^-1 U and
     // z = L^-1 rv (forward substitution only), U^T G = W^T D^-1 W and U^T g = W^T D^-1 z: the carried Schur complement is what
@@ -910,7 +934,16 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
       ++slot;
     }
   }
-  mtg_ldl<H>(A, dinv, mm, ln.flags);
+  // pivot thresholds at the middle vertex: R_PP's diagonal there is the sum of the two half-chains' last end/end diagonals; each
+  // direction scales with its own (the exchange carries the Schur complements only) and both solve the same block bit for bit, so
+  // the trajectory is flagged when d_j <= tau x the larger of the two -- within a factor two of tau x their sum.
+  double thr[H];
+  {
+    const double tau = mtg_pivot_tau<C>(P);
+#pragma unroll
+    for (int p = 0; p < H; ++p) thr[p] = mtg_mul(tau, ln.dg[p]);
+  }
+  mtg_ldl<H>(A, dinv, mm, thr, ln.flags);
   {
     double X[H][D];
 #pragma unroll
@@ -1325,6 +1358,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
 #endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
+    ln.dg[p] = 0.0;
 #pragma unroll
     for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
   }

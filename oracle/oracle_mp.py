@@ -52,6 +52,52 @@ def cost_matrix(n: int, d: int, t) -> mp.matrix:
     return q
 
 
+def _banded_ldl(a, n):
+    """LDL^T of a symmetric positive definite banded mp.matrix without pivoting (exact enough at 50 digits: the pivots of an SPD
+    matrix are bounded below by its smallest eigenvalue).  Returns (l rows as dicts, d, bandwidth) or None when a pivot is not
+    positive (rank-deficient system: the caller falls back to the dense pivoted LU)."""
+    bw = 0
+    for i in range(n):
+        for j in range(max(0, i - 64), i):
+            if a[i, j] != 0:
+                bw = max(bw, i - j)
+        for j in range(0, max(0, i - 64)):
+            if a[i, j] != 0:
+                return None          # not banded the way a chain is
+    low = [[a[i, j] for j in range(max(0, i - bw), i + 1)] for i in range(n)]    # low[i][j - (i - bw)] for j in [i - bw, i]
+    dd = [mp.mpf(0)] * n
+    for j in range(n):
+        j0 = max(0, j - bw)
+        acc = low[j][j - j0]
+        for k in range(j0, j):
+            acc -= low[j][k - j0] ** 2 * dd[k]
+        if not acc > 0:
+            return None
+        dd[j] = acc
+        for i in range(j + 1, min(n, j + bw + 1)):
+            i0 = max(0, i - bw)
+            v = low[i][j - i0]
+            for k in range(max(i0, j0), j):
+                v -= low[i][k - i0] * low[j][k - j0] * dd[k]
+            low[i][j - i0] = v / acc
+    return low, dd, bw
+
+
+def _banded_solve(fac, rhs, n):
+    low, dd, bw = fac
+    y = [rhs[i] for i in range(n)]
+    for i in range(n):
+        i0 = max(0, i - bw)
+        for k in range(i0, i):
+            y[i] -= low[i][k - i0] * y[k]
+    for i in range(n):
+        y[i] /= dd[i]
+    for i in range(n - 1, -1, -1):
+        for k in range(i + 1, min(n, i + bw + 1)):
+            y[i] -= low[k][i - max(0, k - bw)] * y[k]
+    return mp.matrix(y)
+
+
 def solve(n_coeffs: int, derivative: int, fixed_mask: Sequence[int], times, d_fixed):
     """One trajectory.  times [K] (float64 values taken exactly), d_fixed [D][n_fixed]
     ordered by (vertex, derivative) over fixed slots (LINH:288-295).
@@ -86,18 +132,25 @@ def solve(n_coeffs: int, derivative: int, fixed_mask: Sequence[int], times, d_fi
     coeffs = np.zeros((k, dim, n))
     d_free = np.zeros((dim, npf))
     cost = mp.mpf(0)
+    banded = None
     if npf:
         rpf = r_full[nf:, :nf]
         rpp = r_full[nf:, nf:]
-        lu = mp.matrix(rpp)     # one factorisation for all dimensions (as the reference shares its QR, LIN:365-375)
-        lu_a, lu_p = mp.mp.LU_decomp(lu)
+        if npf > 48:
+            banded = _banded_ldl(rpp, npf)      # long chains: R_PP is block tridiagonal (bandwidth < 2h), dense LU is O(n^3) at 50 digits
+        if banded is None:
+            lu = mp.matrix(rpp)     # one factorisation for all dimensions (as the reference shares its QR, LIN:365-375)
+            lu_a, lu_p = mp.mp.LU_decomp(lu)
     for d in range(dim):
         df = mp.matrix([mp.mpf(float(x)) for x in d_fixed[d]])
         if npf:
             rhs = -(rpf * df)
-            # forward / backward substitution with the shared LU factors (mpmath's own helpers)
-            y = mp.mp.L_solve(lu_a, rhs, lu_p)
-            dp = mp.mp.U_solve(lu_a, y)
+            if banded is not None:
+                dp = _banded_solve(banded, rhs, npf)
+            else:
+                # forward / backward substitution with the shared LU factors (mpmath's own helpers)
+                y = mp.mp.L_solve(lu_a, rhs, lu_p)
+                dp = mp.mp.U_solve(lu_a, y)
             d_all = list(df) + list(dp)
             d_free[d] = [float(x) for x in dp]
         else:

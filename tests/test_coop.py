@@ -122,12 +122,20 @@ def test_gpu_cooperative_form_vs_other_forms(ctx, n, k, bsz, layout):
         e_coop = helpers.poly_relerr(co[w:w + 1].cpu().numpy(), truth)
         e_other = helpers.poly_relerr(ref[w:w + 1].cpu().numpy(), truth)
         assert e_coop <= max(2.0 * e_other, 1e-11 if n <= 10 else 1e-9), (w, e_coop, e_other)
-    nb = min(bsz, 4)
-    th = (t[:, :nb].t() if layout == "soa" else t[:nb]).contiguous().cpu().numpy()
-    fh = (f[:, :, :nb].permute(2, 0, 1) if layout == "soa" else f[:nb]).contiguous().cpu().numpy()
-    from oracle import oracle_np as onp
-    c_lit, _, _ = onp.solve_batch(n, d, masks, th, fh)
-    assert helpers.poly_relerr(co[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
+    # ... and the WHOLE batch against the reference's own code (oracle/_ref, LIN:339-379): 1e-9 for N <= 10, the arbitration rule
+    # of tests/test_gpu_vs_reference.py for N = 12 (round 4 compared four trajectories with the numpy restatement)
+    th = (t.t() if layout == "soa" else t).contiguous().cpu().numpy()
+    fh = (f.permute(2, 0, 1) if layout == "soa" else f).contiguous().cpu().numpy()
+    from oracle import ref_linear
+    if ref_linear.available():
+        from test_gpu_vs_reference import assert_close_to_reference
+        ref_c = ref_linear.solve_batch(n, d, masks, th, fh, nthreads=ref_linear.hardware_threads())[0]
+        assert_close_to_reference(n, d, masks, th, fh, co[:bsz].cpu().numpy(), ref_c)
+    else:
+        from oracle import oracle_np as onp
+        nb = min(bsz, 4)
+        c_lit, _, _ = onp.solve_batch(n, d, masks, th[:nb], fh[:nb])
+        assert helpers.poly_relerr(co[:nb].cpu().numpy(), c_lit) < (1e-9 if n <= 10 else 5e-7)
     plan.close()
 
 
@@ -153,9 +161,16 @@ def test_gpu_cooperative_form_default_range(ctx):
         co, _, _ = plan.solve(t, f)                       # default choice: the cooperative form
         assert plan.launch_form(500, "aos") == "coop"
         c.sync()
-        from oracle import oracle_np as onp
-        c_lit, _, _ = onp.solve_batch(12, 5, masks, t[:6].cpu().numpy(), f[:6].cpu().numpy())
-        assert helpers.poly_relerr(co[:6].cpu().numpy(), c_lit) < 5e-7
+        from oracle import ref_linear
+        from test_gpu_vs_reference import assert_close_to_reference
+        th, fh = t.cpu().numpy(), f.cpu().numpy()
+        if ref_linear.available():
+            ref_c = ref_linear.solve_batch(12, 5, masks, th, fh, nthreads=ref_linear.hardware_threads())[0]
+            assert_close_to_reference(12, 5, masks, th, fh, co.cpu().numpy(), ref_c)
+        else:
+            from oracle import oracle_np as onp
+            c_lit, _, _ = onp.solve_batch(12, 5, masks, th[:6], fh[:6])
+            assert helpers.poly_relerr(co[:6].cpu().numpy(), c_lit) < 5e-7
         plan.close()
     finally:
         c.close()

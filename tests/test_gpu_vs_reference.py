@@ -217,7 +217,16 @@ def assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c):
     5e-8 of the truth or within twice the reference's own distance to it (i.e. never the side that is clearly off)."""
     per_traj = np.array([helpers.poly_relerr(co[b:b + 1], ref_c[b:b + 1]) for b in range(co.shape[0])])
     if n <= 10:
-        assert per_traj.max() < 1e-9
+        # EVERY trajectory above the north-star tolerance is arbitrated by the 50-digit solve (seen on long chains, K = 100: one
+        # of 1000 at 1.1e-9): accepted only when the HIP result is within 1e-9 of the truth, i.e. the reference is the side
+        # that is off -- and only a few of them
+        over = np.nonzero(~(per_traj < 1e-9))[0]
+        assert len(over) <= max(3, co.shape[0] // 200), (len(over), per_traj.max())
+        from oracle import oracle_mp
+        for b in over:
+            truth = np.asarray(oracle_mp.solve(n, d, masks, times[b], d_fixed[b])[0], dtype=np.float64)[None]
+            e_hip, e_ref = helpers.poly_relerr(co[b:b + 1], truth), helpers.poly_relerr(ref_c[b:b + 1], truth)
+            assert e_hip < 1e-9 and per_traj[b] < 1e-8, (int(b), per_traj[b], e_hip, e_ref)
         return
     assert np.median(per_traj) < 1e-8 and per_traj.max() < 1e-5
     from oracle import oracle_mp
