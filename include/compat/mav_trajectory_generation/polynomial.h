@@ -32,6 +32,16 @@ class Polynomial {
   bool operator==(const Polynomial& rhs) const { return coefficients_ == rhs.coefficients_; }
   bool operator!=(const Polynomial& rhs) const { return !(*this == rhs); }
 
+  // The derivative-coefficient table as the reference publishes it (polynomial.h:50: a static kMaxConvolutionSize-square
+  // matrix, row n = coefficients of the n-th derivative of sum t^i); the veneer's own code calls baseCoefficient() below.
+  struct BaseCoefficientTable : Eigen::MatrixXd {
+    BaseCoefficientTable() : Eigen::MatrixXd(kMaxConvolutionSize, kMaxConvolutionSize) {
+      for (int n = 0; n < kMaxConvolutionSize; ++n)
+        for (int i = 0; i < kMaxConvolutionSize; ++i) (*this)(n, i) = baseCoefficient(n, i);
+    }
+  };
+  static inline const BaseCoefficientTable base_coefficients_{};
+
   // base(n, i) = i * (i-1) * ... * (i-n+1): coefficient of t^(i-n) in the n-th derivative of t^i.
   static double baseCoefficient(int derivative, int i) {
     if (i < derivative) return 0.0;
@@ -84,26 +94,23 @@ class Polynomial {
     return out;
   }
   static inline int getConvolutionLength(int data_size, int kernel_size) { return data_size + kernel_size - 1; }
+  // product of two polynomials (reference: polynomial.h:91-95, operator*)
+  Polynomial operator*(const Polynomial& rhs) const { return Polynomial(convolve(coefficients_, rhs.coefficients_)); }
 
-  // All real roots of sum c[i] t^i inside [a, b].  Same method as the device code (csrc/mtg_extrema_lane.h): map
-  // [a, b] to tau in [0, 1], then walk the derivative chain upwards -- between two consecutive roots of the
-  // (k+1)-th derivative the k-th derivative is monotone, so every sign change brackets exactly one root, found by
-  // bisection-safeguarded Newton.  Only exactly-zero leading coefficients are stripped (the reference strips
+  // All real roots of sum c[i] t^i inside [a, b].  Same method as the device code (csrc/mtg_extrema_lane.h): walk the
+  // derivative chain upwards -- between two consecutive roots of the (k+1)-th derivative the k-th derivative is monotone, so
+  // every sign change brackets exactly one root, found by bisection-safeguarded Newton.  The chain is walked in t itself:
+  // the device maps a segment's [0, T] to [0, 1], a pure scaling, but a general interval [a, b] with a != 0 would need a
+  // Taylor shift of the monomial coefficients, which cancels catastrophically for |a| >> 1 (degree 11 on [-100, 100]:
+  // shifted coefficients ~1e26 for values ~1e2 -- found by the reference's own test/test_polynomial.cpp:FindMinMax run
+  // against this header, tests/ref_tests).  Only exactly-zero leading coefficients are stripped (the reference strips
   // |c| < DBL_MIN, rpoly_ak1.cpp:57-68); identically zero polynomials have no isolated roots.
   static void realRootsInInterval(std::vector<double> c, double a, double b, std::vector<double>* roots) {
     roots->clear();
     while (!c.empty() && c.back() == 0.0) c.pop_back();
     if (c.size() < 2 || !(a <= b)) return;
     const int m = (int)c.size() - 1;
-    const double w = b - a;
-    if (w == 0.0) return;
-    // q(tau) = p(a + w tau): Taylor shift by a (repeated synthetic division), then scale coefficient j by w^j
-    std::vector<double> q(c);
-    if (a != 0.0)
-      for (int i = 0; i < m; ++i)
-        for (int j = m - 1; j >= i; --j) q[j] += a * q[j + 1];
-    double wp = 1.0;
-    for (int j = 0; j <= m; ++j) { q[j] *= wp; wp *= w; }
+    if (b - a == 0.0) return;
     auto horner = [](const std::vector<double>& p, double x) {
       double r = 0.0;
       for (size_t i = p.size(); i-- > 0;) r = r * x + p[i];
@@ -124,7 +131,7 @@ class Polynomial {
         const bool slow = std::abs(2.0 * f) > std::abs(dxold * df);
         dxold = dx;
         if (leaves || slow || !(df != 0.0)) { dx = 0.5 * (xh - xl); x = xl + dx; } else { dx = f / df; x -= dx; }
-        if (std::abs(dx) < 4e-15) break;
+        if (std::abs(dx) < 4e-15 * std::max(1.0, std::abs(x))) break;
         eval2(x, &f, &df);
         if (f < 0.0) xl = x; else xh = x;
       }
@@ -132,18 +139,18 @@ class Polynomial {
     };
     std::vector<double> part, next, lvl;
     for (int k = 1; k <= m; ++k) {
-      // (m-k)-th divided derivative: lvl[j] = q[j+s] * C(j+s, s), s = m - k
+      // (m-k)-th divided derivative of the polynomial: lvl[j] = c[j+s] * C(j+s, s), s = m - k
       const int s = m - k;
       lvl.assign(k + 1, 0.0);
       double binom = 1.0;
       for (int j = 0; j <= k; ++j) {
         if (j > 0) binom = binom * (double)(j + s) / (double)j;
-        lvl[j] = q[j + s] * binom;
+        lvl[j] = c[j + s] * binom;
       }
       next.clear();
-      double lo = 0.0, flo = lvl[0];
+      double lo = a, flo = horner(lvl, a);
       for (size_t i = 0; i <= part.size(); ++i) {
-        const double hi = i < part.size() ? part[i] : 1.0;
+        const double hi = i < part.size() ? part[i] : b;
         const double fhi = horner(lvl, hi);
         if ((flo < 0.0) != (fhi < 0.0)) next.push_back(bracketed(lvl, lo, hi, flo, fhi));
         lo = hi;
@@ -151,7 +158,7 @@ class Polynomial {
       }
       part.swap(next);
     }
-    for (double r : part) roots->push_back(a + w * r);
+    for (double r : part) roots->push_back(r);
   }
 
   // Candidates for the extrema of the derivative-th derivative on [t_start, t_end]: both interval ends plus the real

@@ -96,5 +96,25 @@ class Segment {
   int N_, D_;
 };
 
+// Text form of a segment (reference: segment.h:133-138): its time and, per dimension, the coefficients of the given derivative.
+inline void printSegment(std::ostream& stream, const Segment& s, int derivative) {
+  CHECK(derivative >= 0 && derivative < s.N());
+  stream << "t: " << s.getTime() << std::endl << " coefficients for " << positionDerivativeToString(derivative) << ": " << std::endl;
+  for (int d = 0; d < s.D(); ++d) {
+    const Eigen::VectorXd c = s[d].getCoefficients(derivative);
+    stream << "dim " << d << ": " << std::endl;
+    for (int i = 0; i < (int)c.size(); ++i) stream << (i ? " " : "") << c[i];
+    stream << std::endl;
+  }
+}
+inline std::ostream& operator<<(std::ostream& stream, const Segment& s) {
+  printSegment(stream, s, derivative_order::POSITION);
+  return stream;
+}
+inline std::ostream& operator<<(std::ostream& stream, const std::vector<Segment>& segments) {
+  for (const Segment& s : segments) stream << s << std::endl;
+  return stream;
+}
+
 }  // namespace mav_trajectory_generation
 #endif

@@ -54,6 +54,9 @@ class Vertex {
 };
 
 // Uniform waypoints in a box, consecutive spacing > 0.2, one std::mt19937(seed), ends at rest.
+// highest derivative a vertex of a polynomial with N coefficients can constrain (reference: vertex.h:147)
+inline int getHighestDerivativeFromN(int N) { return N / 2 - 1; }
+
 inline Vertex::Vector createRandomVertices(int maximum_derivative, size_t n_segments, const Eigen::VectorXd& pos_min,
                                            const Eigen::VectorXd& pos_max, size_t seed = 0) {
   CHECK_GE((int)n_segments, 1);

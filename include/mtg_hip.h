@@ -148,13 +148,16 @@ int mtg_plan_get_info(const mtg_plan* plan, mtg_plan_info* out);
 /* The context a plan was created on (its stream, status word and error text): host objects that hold a plan and may be
  * used from another thread than their creator synchronise THIS context, not their own thread's.                     */
 mtg_context* mtg_plan_context(const mtg_plan* plan);
+/* (N, D, K, d) of the description the plan was created from (any out-pointer may be NULL).                                  */
+int mtg_plan_get_shape(const mtg_plan* plan, int32_t* n_coeffs, int32_t* dimension, int32_t* n_segments, int32_t* derivative_to_optimize);
 /* STRUCTURAL rank deficiency of the plan's free system R_PP (0: regular).  The cost's null space is the polynomials of degree
  * < derivative_to_optimize over the whole trajectory; what the fixed slots leave of it is a property of the constraint pattern,
  * not of a batch's values (under-constrained problems: fewer than d independent position / velocity / ... constraints in the
  * whole trajectory).  Every trajectory of such a plan is flagged MTG_ERR_SINGULAR (bit 1 of the per-trajectory status) by every
  * solve -- the reference's rank-revealing SparseQR returns a basic solution there (LIN:365-378): ask for it with
- * MTG_FLAG_BASIC_SOLUTION.  On regular plans the kernels' own pivot test (d_j <= 20 (n_free + n_free) eps R_PP[j][j], the form
- * of SparseQR's default threshold relative to the variable's own diagonal) flags trajectories whose pivots lost every digit.  */
+ * MTG_FLAG_BASIC_SOLUTION -- such a plan is then solved through its "shadow" (the same pattern with that many more slots
+ * fixed to zero: a regular system, on the device like any other; free variables beyond the rank come back as exact zeros).
+ * On regular plans the kernels flag a trajectory only when the factorisation breaks down (a non-positive or NaN pivot).     */
 int mtg_plan_rank_deficiency(const mtg_plan* plan);
 /* The same number from the description alone (host arithmetic only: no context, no device): fixed_mask[n_segments + 1] as in
  * mtg_plan_desc.  Negative: mtg_status.                                                                                      */
@@ -376,6 +379,33 @@ int mtg_device_group_solve_linear(mtg_device_group* group, int64_t batch, int32_
 int mtg_device_group_sync(mtg_device_group* group);
 int mtg_device_group_gather_coeffs(mtg_device_group* group, int64_t batch, const double* const* coeffs, int32_t root,
                                    double* dst);
+
+/* ---- one PROCESS per GPU: the final gather over RCCL / xGMI (csrc/mtg_comm.hip) ----------------------------------------
+ * north_star: batches shard across the GPUs of a node "with RCCL over xGMI only for the final gather".  Rank r of `world`
+ * processes owns the slice mtg_shard_range(B, world, r), solves it with its own context / plan (no communication), and -- when
+ * one consumer needs every shard on every device -- gathers the coefficient shards through a communicator:
+ *   rank 0: mtg_comm_unique_id(id); ships the MTG_COMM_UNIQUE_ID_BYTES bytes to the other ranks (file, socket, MPI ...);
+ *   every rank: mtg_comm_create(ctx, rank, world, id, &comm)   -- collective (ncclCommInitRank on the context's device);
+ *   mtg_comm_all_gather(comm, local, n, gathered)              -- gathered[r][n] <- rank r's local[n] (equal n on every rank);
+ *   mtg_comm_solve_all_gather(...)                             -- the batch in n_chunks pieces, chunk i's gather (on the
+ *       communicator's own stream) under chunk i + 1's solve (on the context's stream): at 240 MB per rank the gather takes
+ *       ~10x the solve (7 xGMI links x ~153 GB/s per GPU), so the solve hides behind it, not the other way round.
+ *       gathered is chunk-major: [n_chunks][world][batch / n_chunks][K][D][N]; batch equal on every rank, a multiple of n_chunks.
+ * Everything is asynchronous (ordered after the context's stream, which in turn waits for the last gather); mtg_comm_sync waits
+ * for both streams and reports the context's status.  librccl.so is opened on first use (dlopen) -- a single-GPU consumer neither
+ * links nor loads it; MTG_ERR_UNSUPPORTED where it is absent.  No RCCL types cross the boundary.                              */
+typedef struct mtg_comm mtg_comm;
+#define MTG_COMM_UNIQUE_ID_BYTES 128
+int mtg_comm_unique_id(void* out_id /* MTG_COMM_UNIQUE_ID_BYTES bytes */);
+int mtg_comm_create(mtg_context* ctx, int32_t rank, int32_t world, const void* unique_id, mtg_comm** out);
+int mtg_comm_destroy(mtg_comm* comm);
+int mtg_comm_rank(const mtg_comm* comm);
+int mtg_comm_world(const mtg_comm* comm);
+const char* mtg_comm_last_error(const mtg_comm* comm);
+int mtg_comm_all_gather(mtg_comm* comm, const double* local, int64_t n_doubles, double* gathered);
+int mtg_comm_solve_all_gather(mtg_comm* comm, mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
+                              const double* d_fixed, double* local_coeffs, double* gathered, int32_t n_chunks, uint32_t flags);
+int mtg_comm_sync(mtg_comm* comm);
 
 /* ---- measurement hooks (bench.py / tests) --------------------------------------------- */
 /* Re-runs the last mtg_solve_linear launch of this plan `iters` times back-to-back on the

@@ -45,6 +45,17 @@ EXPORTS = {
     "mtg_plan_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]),
     "mtg_plan_context": (ctypes.c_void_p, [ctypes.c_void_p]),
     "mtg_plan_rank_deficiency": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "mtg_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_comm_rank": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_comm_world": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_comm_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "mtg_comm_all_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "mtg_comm_solve_all_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32]),
+    "mtg_comm_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtg_plan_get_shape": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 4),
     "mtg_structural_rank_deficiency": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32)]),
     "mtg_plan_launch_form": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout), ctypes.c_uint32]),
     "mtg_layout_aos": (None, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Layout)]),

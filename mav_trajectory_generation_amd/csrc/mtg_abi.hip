@@ -184,6 +184,15 @@ struct mtg_plan {
   // MTG_FLAG_BASIC_SOLUTION with device pointers: [status word (8 bytes) | per-trajectory status int32 [batch]] of the call itself
   double* basic_status = nullptr;
   size_t basic_status_bytes = 0;
+  // Structurally rank-deficient plans: the SHADOW plan = this pattern with null_dim additional slots fixed (to zero), chosen so
+  // that the fixed functionals span the cost's null space -- a regular system whose solution is a basic solution of this one
+  // (MTG_FLAG_BASIC_SOLUTION).  shadow_fixed_src[j]: column of this plan's d_fixed behind the shadow's fixed column j (-1: a
+  // pinned slot, value 0); free_in_shadow[j]: the shadow's free column of this plan's free column j (-1: pinned, value 0).
+  mtg_plan* shadow = nullptr;
+  std::vector<int> shadow_fixed_src, free_in_shadow;
+  int* d_shadow_maps = nullptr;      // device copy: shadow_fixed_src | free_in_shadow
+  double* shadow_buf = nullptr;      // [batch][D][n_fixed of the shadow] | [batch][D][n_free of the shadow]
+  size_t shadow_buf_bytes = 0;
   std::vector<LaunchRecord> last;
 };
 
@@ -417,48 +426,66 @@ int mtg_context_sync(mtg_context* ctx) {
 // zero pivot as round-off x the conditioning of everything eliminated before it -- on chains of free vertices that is anything
 // between 1e-12 and 1e0 of the diagonal, of either sign (tests/test_pivot_threshold.py), overlapping the legitimate pivots of
 // regular ill-conditioned problems (1e-7 of the diagonal).  No pivot threshold separates the two; the structure does.
-static int structural_null_dim(int H, int K, int d, const std::vector<int>& mask) {
+// pins (optional): null_dim free slots (vertex, derivative), lowest vertices / derivatives first, whose functionals complete the
+// fixed ones to a basis of P_(d-1)'s dual -- fixing them (to zero) makes the system regular without changing the minimum cost
+// (any minimiser differs from one that satisfies them by an element of the null space).
+static int structural_null_dim(int H, int K, int d, const std::vector<int>& mask, std::vector<std::pair<int, int>>* pins = nullptr) {
+  if (pins) pins->clear();
   if (d <= 0) return 0;
   int best_rank = 0;
   for (int trial = 0; trial < 2 && best_rank < d; ++trial) {
-    std::vector<long double> rows;     // [nrows][d]
-    long double t = 0.0L;
-    for (int v = 0; v <= K; ++v) {
-      // generic instants in [0, 1]: increments from a fixed irrational rotation (no two trials share a ratio)
+    // generic vertex instants in [0, 1]: increments from a fixed irrational rotation (the two trials share no ratio)
+    std::vector<long double> tv((size_t)K + 1, 0.0L);
+    for (int v = 1; v <= K; ++v) {
       const long double u = (v + 1) * (trial == 0 ? 0.6180339887498948482L : 0.4142135623730950488L);
-      if (v > 0) t += (0.35L + (u - (long long)u)) / (long double)K;
-      for (int q = 0; q < H && q < d; ++q) {
-        if (!((mask[v] >> q) & 1)) continue;
-        for (int m = 0; m < d; ++m) {
-          long double c = 0.0L;
-          if (m >= q) {
-            c = 1.0L;
-            for (int i = 0; i < q; ++i) c *= (long double)(m - i);
-            for (int i = 0; i < m - q; ++i) c *= t;
+      tv[v] = tv[v - 1] + (0.35L + (u - (long long)u)) / (long double)K;
+    }
+    auto functional = [&](int v, int q, std::vector<long double>& row) {      // p -> p^(q)(t_v) on the monomials 1, t, ..., t^(d-1)
+      row.assign((size_t)d, 0.0L);
+      for (int m = q; m < d; ++m) {
+        long double c = 1.0L;
+        for (int i = 0; i < q; ++i) c *= (long double)(m - i);
+        for (int i = 0; i < m - q; ++i) c *= tv[v];
+        row[m] = c;
+      }
+    };
+    // incremental echelon basis: basis[i] has its pivot (largest entry at insertion) in column piv[i]
+    std::vector<std::vector<long double>> basis;
+    std::vector<int> piv;
+    auto add_if_independent = [&](std::vector<long double> row) -> bool {
+      long double scale = 0.0L;
+      for (long double x : row) scale = std::max(scale, std::fabs(x));
+      if (scale == 0.0L) return false;
+      for (size_t i = 0; i < basis.size(); ++i) {
+        const long double f = row[piv[i]] / basis[i][piv[i]];
+        if (f != 0.0L) for (int c = 0; c < d; ++c) row[c] -= f * basis[i][c];
+        row[piv[i]] = 0.0L;
+      }
+      int pc = -1;
+      long double big = 1e-9L * scale;
+      for (int c = 0; c < d; ++c) if (std::fabs(row[c]) > big) { big = std::fabs(row[c]); pc = c; }
+      if (pc < 0) return false;
+      basis.push_back(row);
+      piv.push_back(pc);
+      return true;
+    };
+    std::vector<long double> row;
+    for (int v = 0; v <= K; ++v)
+      for (int q = 0; q < H && q < d; ++q)
+        if ((mask[v] >> q) & 1) { functional(v, q, row); add_if_independent(row); }
+    const int rank = (int)basis.size();
+    if (rank > best_rank) {
+      best_rank = rank;
+      if (pins) {
+        pins->clear();
+        for (int v = 0; v <= K && (int)basis.size() < d; ++v)
+          for (int q = 0; q < H && q < d && (int)basis.size() < d; ++q) {
+            if ((mask[v] >> q) & 1) continue;
+            functional(v, q, row);
+            if (add_if_independent(row)) pins->push_back({v, q});
           }
-          rows.push_back(c);
-        }
       }
     }
-    const int nr = (int)(rows.size() / (size_t)d);
-    int rank = 0;
-    std::vector<char> used((size_t)nr, 0);
-    for (int col = 0; col < d; ++col) {          // Gaussian elimination, largest remaining entry of the column as pivot
-      int piv = -1;
-      long double big = 1e-9L;                   // entries are O(1) .. O(d!) on [0, 1]
-      for (int r = 0; r < nr; ++r)
-        if (!used[r] && std::fabs(rows[(size_t)r * d + col]) > big) { big = std::fabs(rows[(size_t)r * d + col]); piv = r; }
-      if (piv < 0) continue;
-      used[piv] = 1;
-      ++rank;
-      for (int r = 0; r < nr; ++r) {
-        if (r == piv) continue;
-        const long double f = rows[(size_t)r * d + col] / rows[(size_t)piv * d + col];
-        if (f == 0.0L) continue;
-        for (int c = 0; c < d; ++c) rows[(size_t)r * d + c] -= f * rows[(size_t)piv * d + c];
-      }
-    }
-    best_rank = std::max(best_rank, rank);
   }
   return d - best_rank;
 }
@@ -470,6 +497,28 @@ __global__ void mtg_flag_all_kernel(int* status, int* tstatus, long long B, int 
   const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0 && status) atomicOr(status, flag);
   if (tstatus && b < B) atomicOr(tstatus + b, flag);
+}
+// shadow d_fixed [B][D][nfs] from the caller's (any strides): column j <- source column src[j], or 0 for a pinned slot
+__global__ void mtg_pin_gather_kernel(const double* __restrict__ src, long long fs_b, long long fs_d, long long fs_c, const int* __restrict__ map,
+                                      double* __restrict__ dst, long long B, int D, int nfs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D * nfs) return;
+  const int j = (int)(i % nfs);
+  const int dm = (int)((i / nfs) % D);
+  const long long b = i / ((long long)nfs * D);
+  const int c = map[j];
+  dst[i] = c >= 0 ? src[b * fs_b + dm * fs_d + c * fs_c] : 0.0;
+}
+// the caller's d_free (any strides) from the shadow's [B][D][nps]: free column j <- shadow column map[j], or 0 for a pinned slot
+__global__ void mtg_pin_scatter_kernel(const double* __restrict__ src, const int* __restrict__ map, double* __restrict__ dst, long long ps_b,
+                                       long long ps_d, long long ps_c, long long B, int D, int np, int nps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D * np) return;
+  const int j = (int)(i % np);
+  const int dm = (int)((i / np) % D);
+  const long long b = i / ((long long)np * D);
+  const int c = map[j];
+  dst[b * ps_b + dm * ps_d + j * ps_c] = c >= 0 ? src[(b * D + dm) * (long long)nps + c] : 0.0;
 }
 }  // namespace
 static void flag_structurally_singular(const mtg_plan* p, hipStream_t st, int* status, int* tstatus, int64_t batch) {
@@ -516,7 +565,8 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
   }
   p->n_fixed = p->offF[K + 1];
   p->n_free = p->offP[K + 1];
-  p->null_dim = p->n_free > 0 ? structural_null_dim(p->H, K, d, p->mask) : 0;
+  std::vector<std::pair<int, int>> pins;
+  p->null_dim = p->n_free > 0 ? structural_null_dim(p->H, K, d, p->mask, &pins) : 0;
   p->fast = mtg_find_static(p->H, D, K, d, p->mask.data());
   for (int dg = 1; dg < D && !p->fast_split; ++dg) {
     if (D % dg == 0) p->fast_split = mtg_find_static(p->H, dg, K, d, p->mask.data());
@@ -533,6 +583,35 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
     delete p;
     return set_err(ctx, MTG_ERR_DEVICE, "plan table upload failed");
   }
+  if (p->null_dim > 0 && (int)pins.size() == p->null_dim) {
+    // the shadow plan: the same problem with the pinned slots fixed (a regular pattern: its own null_dim is 0, no recursion)
+    std::vector<uint32_t> smask((size_t)K + 1);
+    for (int v = 0; v <= K; ++v) smask[v] = (uint32_t)p->mask[v];
+    for (auto& pq : pins) smask[pq.first] |= 1u << pq.second;
+    mtg_plan_desc sd{N, D, K, d, smask.data()};
+    const int rs = mtg_plan_create(ctx, &sd, &p->shadow);
+    if (rs != MTG_OK || p->shadow->null_dim != 0) {
+      if (p->shadow) mtg_plan_destroy(p->shadow);
+      p->shadow = nullptr;       // (the per-trajectory pivoted QR of mtg_basic.cpp stays as the way to a basic solution)
+    } else {
+      int src = 0, sfree = 0;
+      for (int v = 0; v <= K; ++v)
+        for (int q = 0; q < p->H; ++q) {
+          const bool fixed = (p->mask[v] >> q) & 1, sfixed = (smask[v] >> q) & 1;
+          if (sfixed) p->shadow_fixed_src.push_back(fixed ? src : -1);
+          if (fixed) ++src;
+          if (!fixed) p->free_in_shadow.push_back(sfixed ? -1 : sfree);
+          if (!sfixed) ++sfree;
+        }
+      std::vector<int> maps(p->shadow_fixed_src);
+      maps.insert(maps.end(), p->free_in_shadow.begin(), p->free_in_shadow.end());
+      if (hipMalloc((void**)&p->d_shadow_maps, maps.size() * sizeof(int)) != hipSuccess ||
+          hipMemcpy(p->d_shadow_maps, maps.data(), maps.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        mtg_plan_destroy(p);
+        return set_err(ctx, MTG_ERR_DEVICE, "plan table upload failed");
+      }
+    }
+  }
   *out = p;
   return MTG_OK;
 }
@@ -546,11 +625,23 @@ int mtg_plan_destroy(mtg_plan* p) {
   if (p->pert_cost) hipFree(p->pert_cost);
   if (p->stage) hipFree(p->stage);
   if (p->basic_status) hipFree(p->basic_status);
+  if (p->d_shadow_maps) hipFree(p->d_shadow_maps);
+  if (p->shadow_buf) hipFree(p->shadow_buf);
+  if (p->shadow) mtg_plan_destroy(p->shadow);
   delete p;
   return MTG_OK;
 }
 
 mtg_context* mtg_plan_context(const mtg_plan* p) { return p ? p->ctx : nullptr; }
+
+int mtg_plan_get_shape(const mtg_plan* p, int32_t* n_coeffs, int32_t* dimension, int32_t* n_segments, int32_t* derivative_to_optimize) {
+  if (!p) return MTG_ERR_INVALID_ARGUMENT;
+  if (n_coeffs) *n_coeffs = p->N;
+  if (dimension) *dimension = p->D;
+  if (n_segments) *n_segments = p->K;
+  if (derivative_to_optimize) *derivative_to_optimize = p->deriv;
+  return MTG_OK;
+}
 
 int mtg_plan_get_info(const mtg_plan* p, mtg_plan_info* out) {
   if (!p || !out) return MTG_ERR_INVALID_ARGUMENT;
@@ -1206,34 +1297,95 @@ static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layou
   std::vector<int32_t> ts((size_t)batch, 0);
   int32_t* dev_ts = nullptr;           // device-pointer calls: the per-trajectory status the kernels write
   int rc;
+  // A structurally rank-deficient plan is solved through its SHADOW (the same problem with null_dim more slots fixed to zero:
+  // a regular system, the LDL^T kernels at full speed and accuracy -- cost within 1e-11 of the reference's on 50-segment
+  // chains of free vertices where the dense pivoted QR is at 1e-5): shadow d_fixed gathered from the caller's, coefficients and
+  // cost written straight to the caller's buffers, d_free scattered back with zeros at the pinned slots.
+  const bool use_shadow = p->shadow != nullptr;
+  mtg_plan* q = use_shadow ? p->shadow : p;
+  const int Dd = p->D, nfs = q->n_fixed, nps = q->n_free;
+  mtg_layout SL = *L;
+  if (use_shadow) {
+    SL.fixed_stride_b = (int64_t)Dd * nfs; SL.fixed_stride_d = nfs; SL.fixed_stride_c = 1;
+    SL.free_stride_b = (int64_t)Dd * nps; SL.free_stride_d = nps; SL.free_stride_c = 1;
+  }
+  const mtg_layout* QL = use_shadow ? &SL : L;
   if (host) {
-    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, ts.data());
-    if (traj_status) std::memcpy(traj_status, ts.data(), (size_t)batch * sizeof(int32_t));
+    std::vector<double> sfx, sfr;
+    const double* q_fixed = d_fixed;
+    double* q_free = d_free;
+    if (use_shadow) {
+      sfx.assign((size_t)batch * Dd * std::max(nfs, 1), 0.0);
+      sfr.assign((size_t)batch * Dd * std::max(nps, 1), 0.0);
+      for (int64_t b = 0; b < batch; ++b)
+        for (int dm = 0; dm < Dd; ++dm)
+          for (int j = 0; j < nfs; ++j) {
+            const int c = p->shadow_fixed_src[j];
+            if (c >= 0) sfx[((size_t)b * Dd + dm) * nfs + j] = d_fixed[b * L->fixed_stride_b + dm * L->fixed_stride_d + c * L->fixed_stride_c];
+          }
+      q_fixed = sfx.data();
+      q_free = sfr.data();
+    }
+    rc = solve_impl(q, batch, QL, times, q_fixed, coeffs, q_free, cost, inner, false, ts.data());
+    if (use_shadow && d_free && (rc == MTG_OK || rc == MTG_ERR_SINGULAR || rc == MTG_ERR_BAD_SEGMENT_TIME))
+      for (int64_t b = 0; b < batch; ++b)
+        for (int dm = 0; dm < Dd; ++dm)
+          for (int j = 0; j < p->n_free; ++j) {
+            const int c = p->free_in_shadow[j];
+            d_free[b * L->free_stride_b + dm * L->free_stride_d + j * L->free_stride_c] = c >= 0 ? sfr[((size_t)b * Dd + dm) * nps + c] : 0.0;
+          }
+    // (bit 1 of the reported per-trajectory status: WHICH trajectories got a basic solution -- all of a deficient plan)
+    if (traj_status) for (int64_t b = 0; b < batch; ++b) traj_status[b] = ts[b] | (use_shadow ? (int32_t)MTG_FLAG_SINGULAR : 0);
     if (rc != MTG_ERR_SINGULAR && rc != MTG_ERR_BAD_SEGMENT_TIME) return rc;
   } else {
-    // The call has its OWN device status word and (when the caller passes none) per-trajectory status, in a buffer of the plan:
-    // it neither reads nor clears the context's word, so SINGULAR / BAD_TIME flags left by earlier asynchronous launches of
-    // this context are still there for the caller's next mtg_context_sync (round 4 went through mtg_context_sync and lost them).
+    // The call has its OWN device status word and per-trajectory status, in a buffer of the plan: it neither reads nor clears
+    // the context's word, so SINGULAR / BAD_TIME flags left by earlier asynchronous launches of this context are still there
+    // for the caller's next mtg_context_sync (round 4 went through mtg_context_sync and lost them).
     int* own_word = nullptr;
+    const double* q_fixed = d_fixed;
+    double* q_free = d_free;
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
       MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
       const int rb = ensure_buffer(ctx, &p->basic_status, &p->basic_status_bytes, sizeof(double) + (size_t)batch * sizeof(int32_t));
       if (rb != MTG_OK) return rb;
       own_word = reinterpret_cast<int*>(p->basic_status);
-      dev_ts = traj_status ? traj_status : reinterpret_cast<int32_t*>(p->basic_status + 1);
+      dev_ts = (traj_status && !use_shadow) ? traj_status : reinterpret_cast<int32_t*>(p->basic_status + 1);
+      if (use_shadow) {
+        const size_t n_fx = (size_t)batch * Dd * std::max(nfs, 1), n_fr = (size_t)batch * Dd * std::max(nps, 1);
+        const int rs = ensure_buffer(ctx, &p->shadow_buf, &p->shadow_buf_bytes, (n_fx + n_fr) * sizeof(double));
+        if (rs != MTG_OK) return rs;
+        double* sfx = p->shadow_buf;
+        q_fixed = sfx;
+        q_free = p->shadow_buf + n_fx;
+        const long long n = (long long)batch * Dd * nfs;
+        if (n > 0)
+          hipLaunchKernelGGL(mtg_pin_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_fixed, (long long)L->fixed_stride_b,
+                             (long long)L->fixed_stride_d, (long long)L->fixed_stride_c, (const int*)p->d_shadow_maps, sfx, (long long)batch, Dd, nfs);
+      }
     }
-    rc = solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, dev_ts, nullptr, nullptr, own_word);
+    rc = solve_impl(q, batch, QL, times, q_fixed, coeffs, q_free, cost, inner, false, dev_ts, nullptr, nullptr, own_word);
     if (rc != MTG_OK) return rc;
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
       MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+      if (use_shadow && d_free && p->n_free > 0) {
+        const long long n = (long long)batch * Dd * p->n_free;
+        hipLaunchKernelGGL(mtg_pin_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)q_free,
+                           (const int*)(p->d_shadow_maps + nfs), d_free, (long long)L->free_stride_b, (long long)L->free_stride_d,
+                           (long long)L->free_stride_c, (long long)batch, Dd, p->n_free, nps);
+      }
       int word = 0;
       MTG_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, own_word, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       MTG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       word = *ctx->h_status;
+      if (word != 0) MTG_HIP_TRY(ctx, hipMemcpy(ts.data(), dev_ts, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (use_shadow && traj_status) {
+        std::vector<int32_t> rep(ts);
+        for (auto& x : rep) x |= (int32_t)MTG_FLAG_SINGULAR;
+        MTG_HIP_TRY(ctx, hipMemcpy(traj_status, rep.data(), (size_t)batch * sizeof(int32_t), hipMemcpyHostToDevice));
+      }
       if (word == 0) return MTG_OK;
-      MTG_HIP_TRY(ctx, hipMemcpy(ts.data(), dev_ts, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
   }
   // one flagged trajectory after the other: gather its inputs (any strides), solve, recover, scatter

@@ -71,7 +71,6 @@ __device__ __forceinline__ void mtg_lane_forward_rt(const MtgParams& P, long lon
 #pragma unroll
   for (int p = 0; p < H; ++p) {
     ln.rc[0][p] = 0.0;
-    ln.dg[p] = 0.0;
 #pragma unroll
     for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
   }

@@ -87,6 +87,7 @@ constexpr int mtg_ainv_offset(int n) {
 // (inside the box-to-box spread), and it exposed that a rank-deficient system is recognised by the SIGN of a pivot that is pure
 // round-off (mtg_ldl: !(d > 0)): with this association the under-constrained case of tests/cpp/test_veneer.cpp:424 gets a tiny
 // positive pivot and is not flagged.  Off until the pivot test is a relative threshold.
+// (Round 5: rank deficiency is structural now -- see mtg_ldl -- so the association no longer decides what is flagged.)
 #define MTG_PARTIAL_ALL 0
 #endif
 #ifndef MTG_FS_PARTIAL
@@ -131,6 +132,8 @@ struct MtgCfg {
   // constant table and the segment time (mtg_bwd_backsub_fs): ~2 f^2 more FP64 operations per step and dimension lane, on a
   // kernel whose time is the workspace round trip -- 14 -> 10 rows per step for N = 12, 10 -> 8 for N = 10, 6 -> 5 for N = 8.
   static constexpr bool kFS = MTG_FACTOR_STORE != 0 && DLW_ > 0 && ((kStatic && WS_ > 0) || kRolled);
+  // (factor-store entries are standard shapes: with fully fixed trajectory ends R_PP is positive definite for every T > 0)
+  static_assert(!kFS || (MS_ == (1 << H_) - 1 && ME_ == (1 << H_) - 1), "factor-store kernels: trajectory ends fully fixed");
   static constexpr int FCNT = kFS ? FMAXW * (FMAXW + 1) / 2 : FMAXW * FMAXW;   // kept numbers per step besides g
   static constexpr int WSE = DLW > 0 ? (FCNT + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
@@ -261,8 +264,6 @@ struct MtgLane {
   double g[C::KREG][C::D][C::H];  // g_v = Dtilde_v^-1 rtilde_v
   double Sc[C::H][C::H];          // Schur complement carried onto the next vertex (lower tri)
   double rc[C::D][C::H];          // its right-hand side
-  double dg[C::H];                // diagonal of the previous segment's end/end block at the carried vertex: with this step's
-                                  // start/start diagonal it is R_PP's ORIGINAL diagonal entry, the scale of the pivot threshold
   double T[C::KCS];               // static mode: this lane's segment times, chain order
   double fx[C::D][C::NC];         // static mode: this lane's fixed values (columns colBegin..colEnd)
   int flags;
@@ -338,32 +339,26 @@ MTG_HD void mtg_load_vals(const MtgParams& P, long long b, int v, int mask, cons
   }
 }
 
-// Pivot threshold of the LDL^T sweep, relative to R_PP's own diagonal.  The reference factorises R_PP with Eigen's rank-revealing
-// SparseQR (impl/polynomial_optimization_linear_impl.h:365-367), which treats a pivot as zero when it is at most
-// 20 (rows + cols) eps x (largest column norm) (SparseQR::factorize, default threshold).  The sweep's analogue: pivot j of the
-// n_free x n_free system counts as zero when d_j <= tau * R_PP[j][j], tau = 20 (n_free + n_free) eps -- the pivot has lost every
-// digit of the diagonal entry it started from.  (Rounds 1-4 tested the SIGN of d_j: on a rank-deficient system d_j is pure
-// round-off, and whether it came out negative depended on the association of the Schur update.)  The scale is per VARIABLE, not
-// the global column norm: derivative slots differ by powers of the segment times (T^(1 - 2d + 2p)), and a global scale would
-// declare the slots of a long segment next to a short one rank-deficient.  A well-posed problem has d_j / R_PP[j][j] >= 1 / cond
-// >= 1e-8, a rank-deficient one ~1e-16: tau ~ 1e-13 separates them under every association.
-template <class C>
-MTG_HD double mtg_pivot_tau(const MtgParams& P) {
-  int nfree;
-  if constexpr (C::kCT) nfree = (C::H - mtg_popc(C::MS)) + (mtg_nseg<C>(P) - 1) * (C::H - mtg_popc(C::MI)) + (C::H - mtg_popc(C::ME));
-  else nfree = P.offP[P.K + 1];
-  return 40.0 * 2.220446049250313e-16 * (double)nfree;
-}
-
 // in-place LDL^T on the index set {p : bit p of `fixed` clear}; A lower triangle in, L (strict
-// lower) out, dinv = 1/d.  thr[j]: pivot threshold of variable j (above).
+// lower) out, dinv = 1/d.
+// The pivot test `!(d > 0)` is a BREAKDOWN guard (the matrix is numerically not positive definite: NaN inputs, problems beyond
+// float64 such as N = 12 chains with segment-time ratios of 400), not the rank decision.  Whether the free system is
+// rank-deficient -- where the reference's rank-revealing SparseQR returns a basic solution, LIN:365-378 -- is a property of
+// the constraint PATTERN and is decided once per plan on the host (mtg_abi.hip: structural_null_dim; every trajectory of such
+// a plan is flagged, and MTG_FLAG_BASIC_SOLUTION solves it through the plan's pinned shadow).  Round 5 built and measured the
+// alternative the round-4 review asked for, a relative threshold d_j <= 20 (n_free + n_free) eps R_PP[j][j] (SparseQR's default
+// form, the diagonal carried through the chain: +2 % on small launches), and took it out again: on chains of free vertices
+// the structurally zero pivot comes out at 1e-12 ... 1e0 of its diagonal, of either sign (false negatives: profiles/
+// r05_pivot_ratio_study.txt), and a REGULAR 50-segment chain of free vertices has legitimate pivots 1e-12 of their diagonal
+// while its solution is good to 6e-13 (false positive: the case of tests/test_pivot_threshold.py::
+// test_rank_deficient_long_chains_through_every_launch_route[...-10-50], trajectory 2).  No pivot threshold separates the two.
 template <int H>
-MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, const double (&thr)[H], int& flags) {
+MTG_HD void mtg_ldl(double (&A)[H][H], double (&dinv)[H], int fixed, int& flags) {
 #pragma unroll
   for (int j = 0; j < H; ++j) {
     if ((fixed >> j) & 1) continue;
     const double dj = A[j][j];
-    if (!(dj > thr[j])) flags |= MTG_FLAG_SINGULAR;
+    if (!(dj > 0.0)) flags |= MTG_FLAG_SINGULAR;
     const double r = mtg_rcp(dj);
     dinv[j] = r;
     double l[H];
@@ -536,15 +531,12 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   }
 
   // Dtilde_l = Sc + a_ll (free x free, lower), U = a_lr (free_l x free_r)
-  double A[H][H], U[H][H], dinv[H], thr[H];
+  double A[H][H], U[H][H], dinv[H];
   {
     const double* hc = mtg_h1<C>(P);
-    const double tau = mtg_pivot_tau<C>(P);
 #pragma unroll
     for (int p = 0; p < H; ++p) {
       dinv[p] = 0.0;
-      // pivot threshold: tau x (this segment's start/start diagonal + the previous segment's end/end diagonal) = tau x R_PP[p][p]
-      thr[p] = ((ml >> p) & 1) ? 0.0 : mtg_mul(tau, mtg_fma(mtg_mul(bs[p], s[p]), hc[p * N + p], ln.dg[p]));
 #pragma unroll
       for (int q = 0; q < H; ++q) {
         A[p][q] = 0.0;
@@ -556,11 +548,9 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       }
     }
   }
-  mtg_ldl<H>(A, dinv, ml, thr, ln.flags);
+  mtg_ldl<H>(A, dinv, ml, ln.flags);
 
   const double* hrr = mtg_h1<C>(P);
-#pragma unroll
-  for (int p = 0; p < H; ++p) ln.dg[p] = ((mr >> p) & 1) ? 0.0 : mtg_mul(mtg_mul(bs[p], s[p]), hrr[(H + p) * N + H + p]);
   if constexpr ((C::kFS && MTG_FS_PARTIAL != 0) || MTG_PARTIAL_ALL != 0) {
     // Factor store, partial elimination: nothing in the FORWARD sweep needs G = Dtilde^-1 U itself.  With W = L^-1 U and
     // z = L^-1 rv (forward substitution only), U^T G = W^T D^-1 W and U^T g = W^T D^-1 z: the carried Schur complement is what
@@ -934,16 +924,7 @@ MTG_HD void mtg_solve_mid(const MtgParams& P, long long b, MtgLane<C>& ln, int v
       ++slot;
     }
   }
-  // pivot thresholds at the middle vertex: R_PP's diagonal there is the sum of the two half-chains' last end/end diagonals; each
-  // direction scales with its own (the exchange carries the Schur complements only) and both solve the same block bit for bit, so
-  // the trajectory is flagged when d_j <= tau x the larger of the two -- within a factor two of tau x their sum.
-  double thr[H];
-  {
-    const double tau = mtg_pivot_tau<C>(P);
-#pragma unroll
-    for (int p = 0; p < H; ++p) thr[p] = mtg_mul(tau, ln.dg[p]);
-  }
-  mtg_ldl<H>(A, dinv, mm, thr, ln.flags);
+  mtg_ldl<H>(A, dinv, mm, ln.flags);
   {
     double X[H][D];
 #pragma unroll
@@ -1358,7 +1339,6 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
 #endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
-    ln.dg[p] = 0.0;
 #pragma unroll
     for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
   }

@@ -106,3 +106,83 @@ class ChunkedSolveGather:
         if gather and self.backend == "nccl":
             torch.cuda.current_stream().wait_stream(self.comm)
         return self.gathered
+
+
+class Communicator:
+    """The C ABI's own RCCL communicator (mtg_comm_*, csrc/mtg_comm.hip): what a one-process-per-GPU C++ consumer of
+    libmtg_hip.so calls -- no torch.distributed involved.  `unique_id`: bytes from Communicator.unique_id() on rank 0, shipped
+    to the other ranks by the caller (here typically through torch.distributed's store or a file)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from . import _lib as L
+        lib = L.load()
+        buf = ctypes.create_string_buffer(128)
+        rc = lib.mtg_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"mtg_comm_unique_id: {lib.mtg_status_string(rc).decode()}")
+        return buf.raw
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+        import ctypes
+        self.ctx, self.lib = ctx, ctx.lib
+        assert len(unique_id) == 128
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        rc = self.lib.mtg_comm_create(ctx.handle, rank, world, buf, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"mtg_comm_create: {self.lib.mtg_status_string(rc).decode()}")
+        self.handle, self.rank, self.world = h, rank, world
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"mtg_comm: {self.lib.mtg_status_string(rc).decode()} ({self.lib.mtg_comm_last_error(self.handle).decode()})")
+
+    def all_gather(self, local, gathered=None):
+        """gathered [world][...local.shape] <- every rank's `local` (float64 CUDA tensor, same shape on every rank)."""
+        import ctypes
+        import torch
+        assert local.is_cuda and local.dtype == torch.float64 and local.is_contiguous()
+        if gathered is None:
+            gathered = torch.empty((self.world,) + tuple(local.shape), dtype=torch.float64, device=local.device)
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_comm_all_gather(self.handle, ctypes.c_void_p(local.data_ptr()), local.numel(), ctypes.c_void_p(gathered.data_ptr()))
+        self.ctx._leave(cur)
+        self._check(rc)
+        return gathered
+
+    def solve_all_gather(self, plan, times, d_fixed, layout: str = "soa", n_chunks: int = 4, local=None, gathered=None):
+        """This rank's batch solved in chunks, every chunk all-gathered under the next chunk's solve (mtg_comm_solve_all_gather).
+        Returns (local [B][K][D][N], gathered [n_chunks][world][B / n_chunks][K][D][N])."""
+        import ctypes
+        import torch
+        batch = times.shape[0] if layout == "aos" else times.shape[1]
+        while n_chunks > 1 and batch % n_chunks:
+            n_chunks -= 1
+        if local is None:
+            local = torch.empty((batch, plan.K, plan.D, plan.N), dtype=torch.float64, device=times.device)
+        if gathered is None:
+            gathered = torch.empty((n_chunks, self.world, batch // n_chunks, plan.K, plan.D, plan.N), dtype=torch.float64, device=times.device)
+        lay = plan.layout(batch, layout)
+        cur = self.ctx._enter()
+        rc = self.lib.mtg_comm_solve_all_gather(self.handle, plan.handle, batch, ctypes.byref(lay), ctypes.c_void_p(times.data_ptr()),
+                                                ctypes.c_void_p(d_fixed.data_ptr()), ctypes.c_void_p(local.data_ptr()),
+                                                ctypes.c_void_p(gathered.data_ptr()), n_chunks, 0)
+        self.ctx._leave(cur)
+        self._check(rc)
+        return local, gathered
+
+    def sync(self):
+        self._check(self.lib.mtg_comm_sync(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mtg_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -53,12 +53,15 @@ class Matrix;
 template <class T>
 class View;
 
+enum { StreamPrecision = -1, FullPrecision = -2 };   // (IOFormat precisions: the stream's own / every significant digit)
 struct IOFormat {
   IOFormat(int precision = 6, int = 0, const std::string& coeff_sep = " ", const std::string& row_sep = "\n",
-           const std::string& row_prefix = "", const std::string& row_suffix = "")
-      : precision(precision), coeff_sep(coeff_sep), row_sep(row_sep), row_prefix(row_prefix), row_suffix(row_suffix) {}
+           const std::string& row_prefix = "", const std::string& row_suffix = "", const std::string& mat_prefix = "",
+           const std::string& mat_suffix = "")
+      : precision(precision), coeff_sep(coeff_sep), row_sep(row_sep), row_prefix(row_prefix), row_suffix(row_suffix),
+        mat_prefix(mat_prefix), mat_suffix(mat_suffix) {}
   int precision;
-  std::string coeff_sep, row_sep, row_prefix, row_suffix;
+  std::string coeff_sep, row_sep, row_prefix, row_suffix, mat_prefix, mat_suffix;
 };
 
 namespace internal {
@@ -188,6 +191,30 @@ class DenseBase {
   Dyn inverse() const {
     const Index n = rows();
     assert(n == cols());
+#if defined(MINI_EIGEN_REFINED_INVERSE)
+    // tests/ref_tests only (NOT the oracle/_ref build, whose inverse() follows Eigen's algorithm and nothing more): the
+    // reference's AMatrixInversion test (TOPT:731-741) uses `A.inverse()` as the trusted value at 1e-10 absolute on entries up
+    // to 1e2 -- one Newton-Schulz step in extended precision, X <- X + X (I - A X), makes it one (the plain LU's own error is
+    // 1.4e-10 on the entry -126 of A(1)^-1, which is an exact integer).
+    if constexpr (std::is_same<T, double>::value) {
+      Dyn x = n <= 4 ? inverse_cofactors() : inverse_partial_piv_lu();
+      std::vector<long double> r((size_t)(n * n));
+      for (Index i = 0; i < n; ++i)
+        for (Index j = 0; j < n; ++j) {
+          long double acc = i == j ? 1.0L : 0.0L;
+          for (Index k = 0; k < n; ++k) acc -= (long double)coeff(i, k) * (long double)x(k, j);
+          r[(size_t)(i * n + j)] = acc;
+        }
+      Dyn y(n, n);
+      for (Index i = 0; i < n; ++i)
+        for (Index j = 0; j < n; ++j) {
+          long double acc = (long double)x(i, j);
+          for (Index k = 0; k < n; ++k) acc += (long double)x(i, k) * r[(size_t)(k * n + j)];
+          y(i, j) = (double)acc;
+        }
+      return y;
+    }
+#endif
     return n <= 4 ? inverse_cofactors() : inverse_partial_piv_lu();
   }
   // determinant of the sub-matrix without row `skip_r` and column `skip_c` (sizes 0 .. 3: closed forms)
@@ -248,7 +275,9 @@ class DenseBase {
   }
   std::string format(const IOFormat& f) const {
     std::ostringstream s;
-    s << std::setprecision(f.precision);
+    if (f.precision == FullPrecision) s << std::setprecision(std::numeric_limits<Real>::max_digits10);
+    else if (f.precision != StreamPrecision) s << std::setprecision(f.precision);
+    s << f.mat_prefix;
     for (Index r = 0; r < rows(); ++r) {
       if (r) s << f.row_sep;
       s << f.row_prefix;
@@ -258,6 +287,7 @@ class DenseBase {
       }
       s << f.row_suffix;
     }
+    s << f.mat_suffix;
     return s.str();
   }
   // read-only sub-views (copies; the writable versions live in Matrix / View)
@@ -274,9 +304,14 @@ class DenseBase {
   Dyn row(Index r) const { return block(r, 0, 1, cols()); }
   Dyn col(Index c) const { return block(0, c, rows(), 1); }
   Dyn segment(Index i, Index n) const { return cols() == 1 ? block(i, 0, n, 1) : block(0, i, 1, n); }
+  template <int NN>
+  Dyn segment(Index i) const { return segment(i, NN); }
   Dyn head(Index n) const { return segment(0, n); }
   Dyn tail(Index n) const { return segment(size() - n, n); }
 };
+// (Eigen's one-parameter base class name, as generic code spells it: test_utils.h:38)
+template <class Derived>
+using MatrixBase = DenseBase<Derived, double>;
 
 template <class D, class T>
 std::ostream& operator<<(std::ostream& s, const DenseBase<D, T>& m) {

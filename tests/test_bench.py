@@ -105,7 +105,7 @@ def test_single_gpu_bench_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out
-    assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["config"]["buffer_sets"] == 16
+    assert out["n_gpus"] == 1 and out["dtype"] == "f64" and out["config"]["buffer_sets"] >= 25   # (>= steps + warmup sets and >= 1.25 GiB: the timed steps touch no set the warm-up used)
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     # HBM bytes per launch from the committed PMC profile of this very command (null only when none is committed)

@@ -559,7 +559,8 @@ def test_dimlane_extra_outputs(ctx, shape, bsz, layout):
     assert rel < tol
     # (N = 12 long chains: factor-store back-substitution here, G in the fused kernel; the cost is second order in the
     # coefficients but N = 12's are themselves only good to ~1e-8 -- measured 1.2e-9 at N = 12 / K = 32, 1.3e-11 at N = 10 / K = 32)
-    assert torch.allclose(cost, jf, rtol=(1e-11 if k < 32 else 5e-11) if n <= 10 else (1e-9 if k < 16 else 3e-8), atol=0)
+    crel = float(((cost - jf).abs() / jf.abs()).max())
+    assert crel <= ((1e-11 if k < 32 else 5e-11) if n <= 10 else (1e-9 if k < 16 else 3e-8)), crel
     scale = ff.abs().amax().clamp_min(1e-300)
     assert float((fr - ff).abs().amax() / scale) < tol
     nb = min(bsz, 4)

@@ -1,7 +1,8 @@
 /* Plain C consumer of libmtg_hip.so (no HIP headers, no tensor library): generate a random-waypoint batch on the device,
  * solve it with the default kernel choice and with the generic kernel, compare the two results on the device, time the
  * default launch; then a QUEUE of four independent batches in one call (mtg_solve_linear_sequence: one persistent launch) against
- * the same batches solved one by one.  What a cgo / JNI / FFI binding of include/mtg_hip.h does, as one file.
+ * the same batches solved one by one; an under-constrained batch with MTG_FLAG_BASIC_SOLUTION; the chunked solve + RCCL all-gather
+ * of a one-process-per-GPU job (mtg_comm_*).  What a cgo / JNI / FFI binding of include/mtg_hip.h does, as one file.
  * build: gcc -std=c11 -O2 -Iinclude tools/c/roundtrip.c -Lmav_trajectory_generation_amd/csrc -lmtg_hip \
  *            -Wl,-rpath,'$ORIGIN/../../mav_trajectory_generation_amd/csrc' -o tools/c/roundtrip
  * usage: roundtrip [batch = 100000] [segments = 8]                                                                   */
@@ -114,9 +115,37 @@ int main(int argc, char** argv) {
            rc_plain, mtg_status_string(rc_plain), worst, j2[0] + j2[1] + j2[2]);
     mtg_plan_destroy(p2);
   }
+  /* the final gather of a one-process-per-GPU job through the C ABI's own RCCL communicator (here: the one-rank job this
+   * process is -- rank 0 makes the id, every rank would create its communicator from it): the batch solved in four chunks,
+   * each chunk all-gathered on the communicator's stream under the next chunk's solve; gathered = [chunks][world][B / chunks]... */
+  int gather_ok = 0;
+  {
+    char id[MTG_COMM_UNIQUE_ID_BYTES];
+    mtg_comm* comm = NULL;
+    const int rc_id = mtg_comm_unique_id(id);
+    if (rc_id == MTG_ERR_UNSUPPORTED) {
+      printf("RCCL gather: librccl.so not present, skipped\n");
+      gather_ok = 1;
+    } else {
+      CHECK(rc_id);
+      CHECK(mtg_comm_create(ctx, 0, 1, id, &comm));
+      const int chunks = batch % 4 == 0 ? 4 : 1;
+      void* gathered = NULL;
+      CHECK(mtg_device_malloc(ctx, ncoef * sizeof(double), &gathered));
+      CHECK(mtg_comm_solve_all_gather(comm, plan, batch, &lay, (const double*)times, (const double*)dfix, (double*)cb, (double*)gathered, chunks, 0));
+      CHECK(mtg_comm_sync(comm));
+      double r = 1.0, a = 1.0;
+      CHECK(mtg_compare_coefficients(ctx, (const double*)gathered, (const double*)ca, (int64_t)batch * K * D, N, &r, &a));
+      gather_ok = r == 0.0 && mtg_comm_world(comm) == 1;
+      printf("RCCL gather through mtg_comm_solve_all_gather (%d chunks, world %d): gathered vs single solve rel diff %.3e\n", chunks,
+             mtg_comm_world(comm), r);
+      mtg_device_free(ctx, gathered);
+      mtg_comm_destroy(comm);
+    }
+  }
   mtg_device_free(ctx, times); mtg_device_free(ctx, dfix); mtg_device_free(ctx, ca); mtg_device_free(ctx, cb);
   mtg_plan_destroy(plan);
   mtg_context_destroy(ctx);
   free(mask);
-  return (rel < 1e-10 && rel_q < 1e-10 && basic_ok) ? 0 : 3;
+  return (rel < 1e-10 && rel_q < 1e-10 && basic_ok && gather_ok) ? 0 : 3;
 }
