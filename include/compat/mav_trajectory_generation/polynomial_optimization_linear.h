@@ -321,7 +321,64 @@ class PolynomialOptimization {
     }
   }
   // Inverse of the block matrix [[diag, 0], [C, D]]: [[diag^-1, 0], [-D^-1 C diag^-1, D^-1]].
+  // A(T)^-1 through the time-scaling identity the kernels use (csrc/mtg_lane.h): with tau = t / T the mapping factorises as
+  // A(T) = S^-1 A(1) diag(T^i), S = diag(T^0 .. T^(h-1), T^0 .. T^(h-1)), hence A(T)^-1[i][j] = T^-i A(1)^-1[i][j] T^(j mod h).
+  // A(1)^-1 is computed once per N in extended precision and rounded (its entries are integers and simple fractions), so the
+  // result is good to an ulp or two for every T -- the reference's Schur-complement route with a numeric h x h inverse
+  // (LIN:143-179) loses cond(A) ~ 1e7 .. 1e17 of it.  T is read off the matrix (row h is [1, T, T^2, ...]); anything that is not a
+  // mapping matrix of a positive time goes through the generic elimination below.  Found wanting by the reference's own
+  // AMatrixInversion test (TOPT:731-741, 1e-10 absolute) run against this header: the Gauss-Jordan version of rounds 1-4 was
+  // 2.9e-10 off on the entry 420 of A(1)^-1.
   static void invertMappingMatrix(const SquareMatrix& A, SquareMatrix* Ai) {
+    constexpr int h = N / 2;
+    const double T = A(h, 1);
+    if (T > 0.0 && A(h, 0) == 1.0) {
+      static const UnitInverse unit;
+      double tp[h], tn[N];
+      tp[0] = 1.0;
+      for (int k = 1; k < h; ++k) tp[k] = tp[k - 1] * T;
+      tn[0] = 1.0;
+      for (int i = 1; i < N; ++i) tn[i] = tn[i - 1] / T;
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) (*Ai)(i, j) = tn[i] * unit.v[i][j] * tp[j % h];
+      return;
+    }
+    invertGeneric(A, Ai);
+  }
+
+ private:
+  struct UnitInverse {          // A(1)^-1, Gauss-Jordan with partial pivoting in long double, rounded once
+    double v[N][N];
+    UnitInverse() {
+      constexpr int h = N / 2;
+      long double w[N][2 * N];
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < 2 * N; ++j) w[i][j] = 0.0L;
+      for (int k = 0; k < h; ++k) {
+        w[k][k] = (long double)Polynomial::baseCoefficient(k, k);
+        for (int j = k; j < N; ++j) w[h + k][j] = (long double)Polynomial::baseCoefficient(k, j);
+      }
+      for (int i = 0; i < N; ++i) w[i][N + i] = 1.0L;
+      for (int c = 0; c < N; ++c) {
+        int p = c;
+        for (int r = c + 1; r < N; ++r)
+          if (std::abs(w[r][c]) > std::abs(w[p][c])) p = r;
+        if (p != c)
+          for (int j = 0; j < 2 * N; ++j) std::swap(w[c][j], w[p][j]);
+        const long double s = 1.0L / w[c][c];
+        for (int j = 0; j < 2 * N; ++j) w[c][j] *= s;
+        for (int r = 0; r < N; ++r) {
+          if (r == c) continue;
+          const long double f = w[r][c];
+          if (f != 0.0L)
+            for (int j = 0; j < 2 * N; ++j) w[r][j] -= f * w[c][j];
+        }
+      }
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) v[i][j] = (double)w[i][N + j];
+    }
+  };
+  static void invertGeneric(const SquareMatrix& A, SquareMatrix* Ai) {
     constexpr int h = N / 2;
     double Dinv[h][h], W[h][2 * h];
     for (int i = 0; i < h; ++i) for (int j = 0; j < h; ++j) { W[i][j] = A(h + i, h + j); W[i][h + j] = (i == j); }
@@ -349,6 +406,8 @@ class PolynomialOptimization {
       }
     }
   }
+
+ public:
   // Q(r, c) = base(d, r) base(d, c) t^(r+c-2d+1) * 2 / (r+c-2d+1) so that 0.5 c^T Q c = int_0^t (p^(d))^2
   static void computeQuadraticCostJacobian(int derivative, double t, SquareMatrix* cost_jacobian) {
     CHECK_LT(derivative, N);

@@ -126,63 +126,65 @@ class Trajectory {
     return true;
   }
 
-  // src/trajectory.cpp:343-361
+  // Largest velocity and acceleration magnitude over the whole trajectory, all dimensions (reference API: trajectory.h:118).
   bool computeMaxVelocityAndAcceleration(double* v_max, double* a_max) const {
     CHECK_NOTNULL(v_max);
     CHECK_NOTNULL(a_max);
-    std::vector<int> dimensions(D_);
-    std::iota(dimensions.begin(), dimensions.end(), 0);
-    Extremum v_min_traj, v_max_traj, a_min_traj, a_max_traj;
-    bool success = computeMinMaxMagnitude(derivative_order::VELOCITY, dimensions, &v_min_traj, &v_max_traj);
-    success &= computeMinMaxMagnitude(derivative_order::ACCELERATION, dimensions, &a_min_traj, &a_max_traj);
-    *v_max = v_max_traj.value;
-    *a_max = a_max_traj.value;
-    return success;
+    std::vector<int> all_dimensions(D_);
+    std::iota(all_dimensions.begin(), all_dimensions.end(), 0);
+    bool ok = true;
+    auto peak = [&](int derivative) {
+      Extremum lowest, highest;
+      ok = computeMinMaxMagnitude(derivative, all_dimensions, &lowest, &highest) && ok;
+      return highest.value;
+    };
+    *v_max = peak(derivative_order::VELOCITY);
+    *a_max = peak(derivative_order::ACCELERATION);
+    return ok;
   }
 
-  // src/trajectory.cpp:363-381
-  bool scaleSegmentTimes(double scaling) {
-    if (scaling < 1.0e-6) return false;
-    double new_max_time = 0.0;
-    const double scaling_inverse = 1.0 / scaling;
-    for (Segment& s : segments_) {
-      const double new_time = s.getTime() * scaling;
-      for (int d = 0; d < s.D(); ++d) s[d].scalePolynomialInTime(scaling_inverse);
-      s.setTime(new_time);
-      new_max_time += new_time;
-    }
-    max_time_ = new_max_time;
+  // Every segment time multiplied by `factor`, the polynomials re-parametrised so that the path stays the same
+  // (p_new(t) = p(t / factor); reference API: trajectory.h:123).
+  bool scaleSegmentTimes(double factor) {
+    if (factor < 1.0e-6) return false;
+    stretch(factor);
     return true;
   }
 
-  // src/trajectory.cpp:385-429: stretches all segment times by max(1, v/v_max, sqrt(a/a_max)) until both bounds
-  // hold within 1e-3 relative (at most 20 rounds; one is enough, the second only verifies).
+  // Stretches the trajectory in time until |v| <= v_max and |a| <= a_max hold to 1e-3 relative, at most 20 check / stretch rounds
+  // (the reference's contract, trajectory.h:128-131).  Same scheme as the device path (csrc/mtg_extrema.hip, mtg_scale_loop): a
+  // stretch by s re-parametrises p(t / s), so the maxima of the next round are exactly v / s and a / s^2 -- ONE root search, the
+  // rounds carried out on those two numbers, the accumulated factor applied once.  (The reference searches the roots again in
+  // every round and reproduces the same numbers up to round-off.)
   bool scaleSegmentTimesToMeetConstraints(double v_max, double a_max) {
-    constexpr size_t kMaxCounter = 20;
-    constexpr double kTolerance = 1e-3;
-    bool within_range = false;
-    for (size_t i = 0; i < kMaxCounter; ++i) {
-      double v_max_actual, a_max_actual;
-      computeMaxVelocityAndAcceleration(&v_max_actual, &a_max_actual);
-      const double velocity_violation = v_max_actual / v_max;
-      const double acceleration_violation = a_max_actual / a_max;
-      within_range = velocity_violation <= 1.0 + kTolerance && acceleration_violation <= 1.0 + kTolerance;
-      if (within_range) break;
-      const double violation_scaling = std::max(1.0, std::max(velocity_violation, std::sqrt(acceleration_violation)));
-      const double violation_scaling_inverse = 1.0 / violation_scaling;
-      double new_max_time = 0.0;
-      for (Segment& s : segments_) {
-        const double new_time = s.getTime() * violation_scaling;
-        for (int d = 0; d < s.D(); ++d) s[d].scalePolynomialInTime(violation_scaling_inverse);
-        s.setTime(new_time);
-        new_max_time += new_time;
-      }
-      max_time_ = new_max_time;
+    double v = 0.0, a = 0.0;
+    computeMaxVelocityAndAcceleration(&v, &a);
+    double total = 1.0;
+    bool feasible = false;
+    for (int round = 0; round < 20 && !feasible; ++round) {
+      const double over_v = v / v_max, over_a = a / a_max;
+      feasible = over_v <= 1.0 + 1e-3 && over_a <= 1.0 + 1e-3;
+      if (feasible) break;
+      const double s = std::max(1.0, std::max(over_v, std::sqrt(over_a)));
+      total *= s;
+      v /= s;
+      a /= s * s;
     }
-    return within_range;
+    if (total != 1.0) stretch(total);
+    return feasible;
   }
 
  private:
+  void stretch(double factor) {
+    const double inverse = 1.0 / factor;
+    max_time_ = 0.0;
+    for (Segment& segment : segments_) {
+      for (int d = 0; d < segment.D(); ++d) segment[d].scalePolynomialInTime(inverse);
+      segment.setTime(segment.getTime() * factor);
+      max_time_ += segment.getTime();
+    }
+  }
+
   int D_, N_;
   double max_time_;
   Segment::Vector segments_;

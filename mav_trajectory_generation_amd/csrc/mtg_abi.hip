@@ -138,6 +138,23 @@ struct mtg_context {
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
   std::vector<hipEvent_t> join_events;
+  // Cross-structure requests (mtg_multi_create -> mtg_solve_dl_any_kernel) are typically rebuilt with the SAME structure and new
+  // buffers (a planner's mixed request per cycle; bench.py --config 4 rebuilds its 240-item request per timed region): the
+  // per-workgroup unit lists depend only on the (kernel body, tile count) sequence of the items, so they are computed and
+  // uploaded once per structure and shared read-only by every request of that structure; the workspace is one buffer per
+  // context (requests of one context run in stream order), the small per-request item tables come from a free list.
+  // Round 4: every create paid four hipMalloc, three synchronous copies and a 29k-unit heap schedule: 2.45 ms per 240 items,
+  // three times the launch it prepared.
+  struct DlAnySchedule {
+    std::vector<long long> key;        // grid, schedule kind, then (body index, tiles) per item in launch order
+    int grid = 0, nunits = 0;
+    void* d_units = nullptr;           // MtgDlAnyUnit [nunits]
+    int* d_wg_begin = nullptr;         // [grid + 1]
+  };
+  std::vector<DlAnySchedule> dl_any_schedules;      // never evicted while the context lives (bounded: kMaxDlAnySchedules)
+  double* dl_any_ws = nullptr;
+  size_t dl_any_ws_bytes = 0;
+  std::vector<std::pair<void*, size_t>> dl_any_item_pool;   // free item tables (device)
   std::string last_error;
   std::mutex mu;
 };
@@ -335,6 +352,9 @@ int mtg_context_destroy(mtg_context* ctx) {
   for (hipStream_t q : ctx->side_streams) { hipStreamSynchronize(q); hipStreamDestroy(q); }
   for (hipEvent_t e : ctx->join_events) hipEventDestroy(e);
   if (ctx->fork_event) hipEventDestroy(ctx->fork_event);
+  for (auto& sc : ctx->dl_any_schedules) { if (sc.d_units) hipFree(sc.d_units); if (sc.d_wg_begin) hipFree(sc.d_wg_begin); }
+  if (ctx->dl_any_ws) hipFree(ctx->dl_any_ws);
+  for (auto& pb : ctx->dl_any_item_pool) hipFree(pb.first);
   delete ctx;
   return MTG_OK;
 }
@@ -1628,6 +1648,9 @@ struct MtgDlAnyGroup {                      // cross-structure dimension-in-lane
   int* d_wg_begin = nullptr;                // [grid + 1]: workgroup w runs d_units[d_wg_begin[w] .. d_wg_begin[w + 1])
   double* d_ws = nullptr;
   int nunits = 0, grid = 0;
+  bool shared_schedule = false;             // d_units / d_wg_begin belong to the context's schedule cache
+  size_t d_items_bytes = 0;                 // d_items comes from (and returns to) the context's free list
+  std::vector<MtgDlAnyItem> h_items;        // source of the asynchronous upload
 };
 struct mtg_multi {
   mtg_context* ctx = nullptr;
@@ -1640,20 +1663,29 @@ struct mtg_multi {
   int n_lanes = 0;
 };
 
-int mtg_multi_destroy(mtg_multi* m) {
-  if (!m) return MTG_OK;
+static void multi_free(mtg_multi* m, bool context_locked) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
-  if (m->dl_any.d_items) hipFree(m->dl_any.d_items);
-  if (m->dl_any.d_units) hipFree(m->dl_any.d_units);
-  if (m->dl_any.d_wg_begin) hipFree(m->dl_any.d_wg_begin);
-  if (m->dl_any.d_ws) hipFree(m->dl_any.d_ws);
+  if (m->dl_any.d_items) {
+    std::unique_lock<std::mutex> lock(m->ctx->mu, std::defer_lock);
+    if (!context_locked) lock.lock();
+    m->ctx->dl_any_item_pool.push_back({(void*)m->dl_any.d_items, m->dl_any.d_items_bytes});
+  }
+  if (!m->dl_any.shared_schedule) {
+    if (m->dl_any.d_units) hipFree(m->dl_any.d_units);
+    if (m->dl_any.d_wg_begin) hipFree(m->dl_any.d_wg_begin);
+  }
+  // (dl_any.d_ws is the context's)
   for (MtgMultiGroup& g : m->groups) {
     if (g.d_table) hipFree(g.d_table);
     if (g.d_tiles) hipFree(g.d_tiles);
     if (g.d_ws) hipFree(g.d_ws);
   }
   delete m;
+}
+int mtg_multi_destroy(mtg_multi* m) {
+  if (!m) return MTG_OK;
+  multi_free(m, false);
   return MTG_OK;
 }
 
@@ -1745,53 +1777,106 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
         const int tpw = it.plan->dimlane->tpw;
         table[bi] = MtgDlAnyItem{it.times, it.d_fixed, it.coeffs, (int)it.batch, mtg_dl_any_index(it.plan->dimlane),
                                  dimlane_input_kind(it.plan, &it.layout, it.batch), 0};
-        const int nt = (int)((it.batch + tpw - 1) / tpw);
-        for (int t = 0; t < nt; ++t) units.push_back(MtgDlAnyUnit{(int)bi, t});
+        g.nunits += (int)((it.batch + tpw - 1) / tpw);
       }
-      g.nunits = (int)units.size();
       g.grid = std::min(g.nunits, ctx->n_cu * 2);      // two 2-wave workgroups per CU: one wave per SIMD
-      // Every workgroup gets its own unit list.  Default: greedy longest-processing-time assignment (units in order of
-      // decreasing cost, each to the least-loaded workgroup; ties -> the lowest index, so the first `grid` units land on
-      // workgroups 0, 1, 2, ... and neighbours start with the same configuration).  Cost model from the per-bucket kernel
-      // times (profiles/r03b_configs.jsonl): ~0.03 us x K x (N/2)^2 + ~2.5 us per unit.  MTG_DL_ANY_SCHED=rr: round 2's
-      // schedule (units w, w + grid, ... of the sorted list, every second round reversed).
-      std::vector<std::vector<MtgDlAnyUnit>> lists(g.grid);
-      if (ctx->knob_dl_any_rr) {
-        for (size_t r = 0; r * (size_t)g.grid < units.size(); ++r) {
-          const size_t lo = r * (size_t)g.grid, hi = std::min(units.size(), lo + (size_t)g.grid);
-          const bool rev = (r & 1) && hi - lo == (size_t)g.grid;
-          for (size_t u = lo; u < hi; ++u) lists[rev ? (hi - 1 - u) : (u - lo)].push_back(units[u]);
-        }
+      // the schedule of this STRUCTURE: cached per context (see mtg_context::DlAnySchedule)
+      constexpr size_t kMaxDlAnySchedules = 64;
+      std::vector<long long> key;
+      key.reserve(2 + 2 * cand.size());
+      key.push_back(g.grid);
+      key.push_back(ctx->knob_dl_any_rr ? 1 : 0);
+      for (size_t bi = 0; bi < cand.size(); ++bi) {
+        key.push_back(table[bi].cfg);
+        key.push_back((items[cand[bi]].batch + items[cand[bi]].plan->dimlane->tpw - 1) / items[cand[bi]].plan->dimlane->tpw);
+      }
+      const mtg_context::DlAnySchedule* hit = nullptr;
+      for (const auto& sc : ctx->dl_any_schedules)
+        if (sc.key == key) { hit = &sc; break; }
+      bool ok = true;
+      if (hit) {
+        g.d_units = (MtgDlAnyUnit*)hit->d_units;
+        g.d_wg_begin = hit->d_wg_begin;
+        g.shared_schedule = true;
       } else {
-        auto cost = [&](const MtgDlAnyUnit& u) {
-          const mtg_plan* pl = items[cand[u.item]].plan;
-          return (long long)pl->K * pl->H * pl->H + 90;
-        };
-        typedef std::pair<long long, int> Load;      // (load, workgroup): min-heap
-        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
-        for (int w = 0; w < g.grid; ++w) heap.push(Load(0, w));
-        for (const MtgDlAnyUnit& u : units) {          // `units` is sorted by decreasing work already
-          Load l = heap.top();
-          heap.pop();
-          lists[l.second].push_back(u);
-          heap.push(Load(l.first + cost(u), l.second));
+        // Every workgroup gets its own unit list.  Default: greedy longest-processing-time assignment (units in order of
+        // decreasing cost, each to the least-loaded workgroup; ties -> the lowest index, so the first `grid` units land on
+        // workgroups 0, 1, 2, ... and neighbours start with the same configuration).  Cost model from the per-bucket kernel
+        // times (profiles/r03b_configs.jsonl): ~0.03 us x K x (N/2)^2 + ~2.5 us per unit.  MTG_DL_ANY_SCHED=rr: round 2's
+        // schedule (units w, w + grid, ... of the sorted list, every second round reversed).
+        units.reserve((size_t)g.nunits);
+        for (size_t bi = 0; bi < cand.size(); ++bi) {
+          const int tpw = items[cand[bi]].plan->dimlane->tpw;
+          const int nt = (int)((items[cand[bi]].batch + tpw - 1) / tpw);
+          for (int t = 0; t < nt; ++t) units.push_back(MtgDlAnyUnit{(int)bi, t});
+        }
+        std::vector<std::vector<MtgDlAnyUnit>> lists(g.grid);
+        if (ctx->knob_dl_any_rr) {
+          for (size_t r = 0; r * (size_t)g.grid < units.size(); ++r) {
+            const size_t lo = r * (size_t)g.grid, hi = std::min(units.size(), lo + (size_t)g.grid);
+            const bool rev = (r & 1) && hi - lo == (size_t)g.grid;
+            for (size_t u = lo; u < hi; ++u) lists[rev ? (hi - 1 - u) : (u - lo)].push_back(units[u]);
+          }
+        } else {
+          auto cost = [&](const MtgDlAnyUnit& u) {
+            const mtg_plan* pl = items[cand[u.item]].plan;
+            return (long long)pl->K * pl->H * pl->H + 90;
+          };
+          typedef std::pair<long long, int> Load;      // (load, workgroup): min-heap
+          std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+          for (int w = 0; w < g.grid; ++w) heap.push(Load(0, w));
+          for (const MtgDlAnyUnit& u : units) {          // `units` is sorted by decreasing work already
+            Load l = heap.top();
+            heap.pop();
+            lists[l.second].push_back(u);
+            heap.push(Load(l.first + cost(u), l.second));
+          }
+        }
+        std::vector<int> wg_begin(g.grid + 1, 0);
+        units.clear();
+        for (int w = 0; w < g.grid; ++w) {
+          units.insert(units.end(), lists[w].begin(), lists[w].end());
+          wg_begin[w + 1] = (int)units.size();
+        }
+        ok = hipMalloc((void**)&g.d_units, units.size() * sizeof(MtgDlAnyUnit)) == hipSuccess &&
+             hipMalloc((void**)&g.d_wg_begin, wg_begin.size() * sizeof(int)) == hipSuccess &&
+             hipMemcpy(g.d_wg_begin, wg_begin.data(), wg_begin.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(g.d_units, units.data(), units.size() * sizeof(MtgDlAnyUnit), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && ctx->dl_any_schedules.size() < kMaxDlAnySchedules) {
+          mtg_context::DlAnySchedule sc;
+          sc.key = std::move(key); sc.grid = g.grid; sc.nunits = g.nunits; sc.d_units = g.d_units; sc.d_wg_begin = g.d_wg_begin;
+          ctx->dl_any_schedules.push_back(std::move(sc));
+          g.shared_schedule = true;
         }
       }
-      std::vector<int> wg_begin(g.grid + 1, 0);
-      units.clear();
-      for (int w = 0; w < g.grid; ++w) {
-        units.insert(units.end(), lists[w].begin(), lists[w].end());
-        wg_begin[w + 1] = (int)units.size();
+      // workspace: one buffer per context, sized for the largest grid (requests of a context run in stream order)
+      const size_t ws_bytes = std::max<size_t>(16, mtg_dl_any_ws_per_lane() * (size_t)(ctx->n_cu * 2) * 2 * kWave);
+      if (ok && ctx->dl_any_ws_bytes < ws_bytes) {
+        if (ctx->dl_any_ws) { hipStreamSynchronize(ctx->stream); hipFree(ctx->dl_any_ws); ctx->dl_any_ws = nullptr; ctx->dl_any_ws_bytes = 0; }
+        ok = hipMalloc((void**)&ctx->dl_any_ws, ws_bytes) == hipSuccess;
+        if (ok) ctx->dl_any_ws_bytes = ws_bytes;
       }
-      const size_t ws_bytes = std::max<size_t>(16, mtg_dl_any_ws_per_lane() * (size_t)g.grid * 2 * kWave);
-      if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
-          hipMalloc((void**)&g.d_items, table.size() * sizeof(MtgDlAnyItem)) != hipSuccess ||
-          hipMalloc((void**)&g.d_units, units.size() * sizeof(MtgDlAnyUnit)) != hipSuccess ||
-          hipMemcpy(g.d_items, table.data(), table.size() * sizeof(MtgDlAnyItem), hipMemcpyHostToDevice) != hipSuccess ||
-          hipMalloc((void**)&g.d_wg_begin, wg_begin.size() * sizeof(int)) != hipSuccess ||
-          hipMemcpy(g.d_wg_begin, wg_begin.data(), wg_begin.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(g.d_units, units.data(), units.size() * sizeof(MtgDlAnyUnit), hipMemcpyHostToDevice) != hipSuccess) {
-        mtg_multi_destroy(m);
+      g.d_ws = ctx->dl_any_ws;
+      // item table: a buffer of the free list (or a new one), filled by an asynchronous copy on the context's stream -- the
+      // launch that reads it is enqueued behind it
+      const size_t ib = table.size() * sizeof(MtgDlAnyItem);
+      if (ok) {
+        for (size_t k2 = 0; k2 < ctx->dl_any_item_pool.size(); ++k2)
+          if (ctx->dl_any_item_pool[k2].second >= ib) {
+            g.d_items = (MtgDlAnyItem*)ctx->dl_any_item_pool[k2].first;
+            g.d_items_bytes = ctx->dl_any_item_pool[k2].second;
+            ctx->dl_any_item_pool.erase(ctx->dl_any_item_pool.begin() + (long)k2);
+            break;
+          }
+        if (!g.d_items) {
+          g.d_items_bytes = std::max<size_t>(ib, 4096);
+          ok = hipMalloc((void**)&g.d_items, g.d_items_bytes) == hipSuccess;
+        }
+      }
+      g.h_items = std::move(table);
+      if (ok) ok = hipMemcpyAsync(g.d_items, g.h_items.data(), ib, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+      if (!ok) {
+        multi_free(m, true);
         return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: device allocation failed");
       }
     }
@@ -1900,7 +1985,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
     if (hipMalloc((void**)&g.d_ws, ws_bytes) != hipSuccess ||
         hipMalloc((void**)&g.d_table, table.size() * sizeof(MtgParams)) != hipSuccess ||
         hipMalloc((void**)&g.d_tiles, tiles.size() * sizeof(MtgTileRef)) != hipSuccess) {
-      mtg_multi_destroy(m);
+      multi_free(m, true);
       return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: device allocation failed");
     }
     for (size_t bi = 0; bi < order.size(); ++bi) {
@@ -1915,7 +2000,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
     }
     if (hipMemcpy(g.d_table, table.data(), table.size() * sizeof(MtgParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(g.d_tiles, tiles.data(), tiles.size() * sizeof(MtgTileRef), hipMemcpyHostToDevice) != hipSuccess) {
-      mtg_multi_destroy(m);
+      multi_free(m, true);
       return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: table upload failed");
     }
   }

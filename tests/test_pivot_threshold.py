@@ -156,6 +156,62 @@ def costly_structures(n, k):
     return out
 
 
+def pinned_masks(n, k, d, masks):
+    """Test-side restatement of the library's choice of pinned slots (csrc/mtg_abi.hip, structural_null_dim): the lowest free
+    slots (vertex, derivative < d) whose functionals p -> p^(q)(t_v) complete the fixed ones to a basis on P_(d-1)."""
+    h = n // 2
+    tv = np.cumsum([0.0] + [0.35 + ((v + 1) * 0.6180339887498949) % 1 for v in range(1, k + 1)]) / k
+
+    def row(v, q):
+        r = np.zeros(d)
+        for m in range(q, d):
+            c = 1.0
+            for i in range(q):
+                c *= m - i
+            r[m] = c * tv[v] ** (m - q)
+        return r
+    rows = [row(v, q) for v in range(k + 1) for q in range(min(h, d)) if (masks[v] >> q) & 1]
+    a = np.array(rows) if rows else np.zeros((0, d))
+    rank = np.linalg.matrix_rank(a, tol=1e-9) if len(rows) else 0
+    out = list(masks)
+    for v in range(k + 1):
+        for q in range(min(h, d)):
+            if rank >= d or (masks[v] >> q) & 1:
+                continue
+            a2 = np.vstack([a, row(v, q)])
+            if np.linalg.matrix_rank(a2, tol=1e-9) > rank:
+                a, rank = a2, rank + 1
+                out[v] |= 1 << q
+    return out
+
+
+def assert_cost_matches(n, d, masks, times, d_fixed, cost, cost_ref, tol):
+    """Cost against the reference's; a trajectory beyond the tolerance is arbitrated by the 50-digit solve of the PINNED (regular)
+    system, whose minimum equals the deficient system's: accepted only when the HIP cost is within `tol` of it (seen on
+    50-segment chains of free vertices: the reference's QR 3.5e-8 off on one of 21 trajectories, the HIP path 1e-11)."""
+    rel = np.abs(cost - cost_ref) / np.abs(cost_ref)
+    over = np.nonzero(~(rel <= tol))[0]
+    assert len(over) <= max(2, len(rel) // 10), rel
+    if len(over):
+        from oracle import oracle_mp
+        k = times.shape[1]
+        pm = pinned_masks(n, k, d, masks)
+        h = n // 2
+        cols, src = [], 0
+        for v in range(k + 1):
+            for q in range(h):
+                if (pm[v] >> q) & 1:
+                    cols.append(src if (masks[v] >> q) & 1 else -1)
+                    src += (masks[v] >> q) & 1
+        for b in over:
+            sd = np.zeros((d_fixed.shape[1], len(cols)))
+            for j, c in enumerate(cols):
+                if c >= 0:
+                    sd[:, j] = d_fixed[b][:, c]
+            truth = oracle_mp.solve(n, d, pm, times[b], sd)[2]
+            assert abs(cost[b] - truth) <= tol * abs(truth), (int(b), cost[b], cost_ref[b], truth)
+
+
 @pytest.mark.gpu
 @needs_ref
 @pytest.mark.parametrize("n,k", [(10, 8), (10, 16), (10, 32), (10, 50), (8, 16), (8, 50), (12, 8)])
@@ -218,7 +274,7 @@ def test_rank_deficient_long_chains_through_every_launch_route(ctx, n, k, which)
         co, cost = co.cpu().numpy(), cost.cpu().numpy()
         fr = fr.cpu().numpy() if layout == "aos" else fr.permute(2, 0, 1).cpu().numpy()
         assert np.isfinite(co).all() and helpers.check_path(masks, times, d_fixed, co) < 1e-6
-        assert np.abs(cost - cost_ref).max() <= cost_tol * np.abs(cost_ref).max()
+        assert_cost_matches(n, d, masks, times, d_fixed, cost, cost_ref, cost_tol)
         if deficient:       # basic: (at least) as many free variables as the rank is short are exactly zero
             assert int((fr[0, 0] == 0.0).sum()) >= plan.rank_deficiency
     for hb in (False, True):
@@ -228,7 +284,7 @@ def test_rank_deficient_long_chains_through_every_launch_route(ctx, n, k, which)
             assert e.value.code == -3
         co, fr, cost = plan.solve_host(times, d_fixed, host_backend=hb, basic_solution=True)
         assert helpers.check_path(masks, times, d_fixed, co) < 1e-6
-        assert np.abs(cost - cost_ref).max() <= cost_tol * np.abs(cost_ref).max()
+        assert_cost_matches(n, d, masks, times, d_fixed, cost, cost_ref, cost_tol)
         if deficient:
             assert int((fr[0, 0] == 0.0).sum()) >= plan.rank_deficiency
     plan.close()
