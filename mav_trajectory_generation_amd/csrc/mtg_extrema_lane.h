@@ -70,6 +70,7 @@ constexpr double kRootTol = 1e-12;        // absolute, in tau in [0, 1]: roots o
 constexpr double kPartitionTol = 1e-4;    // roots of the derivative levels only partition [0, 1] for the next level (the last
                                           // Newton step that is smaller than this leaves ~1e-8; a root pair closer than that
                                           // changes no extremum value beyond round-off)
+constexpr double kBisectTol = 1e-7;       // a bracket whose last step was a bisection is refined to at least this
 constexpr int kRootMaxIter = 100;         // pure bisection needs ~48
 #ifndef MTGX_NOISE_ULPS
 #define MTGX_NOISE_ULPS 4.0
@@ -156,7 +157,9 @@ MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fn
   b.dxold = live ? b.dx : b.dxold;
   b.dx = live ? dx : b.dx;
   b.x = live ? x : b.x;
-  b.done = !live || fabs(dx) < tol;
+  // (a NEWTON step smaller than the loose partition tolerance leaves an error ~ its square; a bisection step of that size leaves
+  // the error it has -- those continue to kBisectTol, so that the next level's intervals stay monotone: ADVICE round 4)
+  b.done = !live || fabs(dx) < (bisect ? fmin(tol, kBisectTol) : tol);
 }
 template <int K>
 MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, double tol, double fnoise) {
