@@ -867,6 +867,30 @@ def main():
             gather = {"chunks": runner.n_chunks, "own_slice_matches_local_solve": own_slice_ok, "solve_plus_gather_ms": both * 1e3, "solve_only_ms": solve_only * 1e3,
                       "gather_only_ms": gather_only * 1e3,
                       "gathered_bytes_per_rank": world * B * K * D * N * 8, "backend": args.backend}
+            if args.backend == "nccl":
+                # the same chunked solve + gather through the C ABI's OWN RCCL communicator (mtg_comm_*, csrc/mtg_comm.hip: what a
+                # C++ consumer running one process per GPU calls -- no torch.distributed in the data path; the unique id travels
+                # over the process group that exists anyway).  Never fails the bench: an error is recorded in the line.
+                try:
+                    ids = [mdist.Communicator.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    comm = mdist.Communicator(ctx, rank, world, ids[0])
+                    for _ in range(3):
+                        loc, gat = comm.solve_all_gather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks)
+                    comm.sync()
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        comm.solve_all_gather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks, local=loc, gathered=gat)
+                    comm.sync()
+                    barrier()
+                    via = (time.perf_counter() - t0) / reps
+                    gather["via_mtg_comm"] = {"solve_plus_gather_ms": via * 1e3, "own_slice_matches_local_solve": bool(torch.equal(gat[:, rank].reshape(loc.shape), loc)),
+                                              "matches_torch_distributed_gather": bool(torch.equal(gat, runner.gathered)),
+                                              "is": "mtg_comm_solve_all_gather: ncclAllGather per chunk on the communicator's stream under the next chunk's solve"}
+                    comm.close()
+                except Exception as e:   # noqa: BLE001
+                    gather["via_mtg_comm"] = {"error": repr(e)[:300]}
 
     per_rank = None
     if grouped:

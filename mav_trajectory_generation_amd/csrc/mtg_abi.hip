@@ -1344,7 +1344,7 @@ static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layou
             if (c >= 0) sfx[((size_t)b * Dd + dm) * nfs + j] = d_fixed[b * L->fixed_stride_b + dm * L->fixed_stride_d + c * L->fixed_stride_c];
           }
       q_fixed = sfx.data();
-      q_free = sfr.data();
+      q_free = d_free ? sfr.data() : nullptr;
     }
     rc = solve_impl(q, batch, QL, times, q_fixed, coeffs, q_free, cost, inner, false, ts.data());
     if (use_shadow && d_free && (rc == MTG_OK || rc == MTG_ERR_SINGULAR || rc == MTG_ERR_BAD_SEGMENT_TIME))
@@ -1377,7 +1377,7 @@ static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layou
         if (rs != MTG_OK) return rs;
         double* sfx = p->shadow_buf;
         q_fixed = sfx;
-        q_free = p->shadow_buf + n_fx;
+        q_free = d_free ? p->shadow_buf + n_fx : nullptr;     // (d_P only when the caller asked for it)
         const long long n = (long long)batch * Dd * nfs;
         if (n > 0)
           hipLaunchKernelGGL(mtg_pin_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_fixed, (long long)L->fixed_stride_b,

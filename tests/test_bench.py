@@ -85,6 +85,10 @@ def test_rccl_branches_run_on_a_one_rank_group(launcher):
     assert ce["backend"] == "nccl" and ce["ranks_seen"] == 1 and any("all_gather_into_tensor" in c for c in ce["calls"])
     assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["solve_plus_gather_ms"] > 0
     assert out["gather"]["own_slice_matches_local_solve"] is True
+    # ... and the same chunked solve + gather through the C ABI's own RCCL communicator (mtg_comm_*), bit-identical to it
+    via = out["gather"]["via_mtg_comm"]
+    assert "error" not in via, via
+    assert via["own_slice_matches_local_solve"] is True and via["matches_torch_distributed_gather"] is True and via["solve_plus_gather_ms"] > 0
     assert out["per_rank"][0]["device_us_per_step"] > 0 and out["parity"]["ok"]
 
 
