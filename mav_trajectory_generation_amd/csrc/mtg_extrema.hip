@@ -20,7 +20,7 @@ extern "C" int mtg_context_extrema_split(const mtg_context* ctx);   // measureme
 
 namespace {
 
-constexpr int kThreads = 128;   // per lane in LDS: two root buffers of L - 1 doubles + L + 1 partition-point values: 128 x 65 x 8 B = 66.6 KB at most
+constexpr int kThreads = 128;   // two root buffers of L - 1 doubles per lane in LDS: 128 x 2 x 21 x 8 B = 43 KB at most
 
 struct ExtremaParams {
   const double* coeffs;   // [B][K][D][N]
@@ -171,21 +171,13 @@ void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   constexpr int L = 2 * NMAX - 2;
   const long long total = P.B * P.K;
   const dim3 grid((unsigned)((P.split * total + kThreads - 1) / kThreads), n_slots);
-  // two root buffers + the level's values at its partition points, per search (mtg_extrema_lane.h)
-  const size_t lds = (size_t)(kThreads / P.split) * (3 * (L - 1) + 2) * sizeof(double);
-  auto go = [&](auto kernel) {
-    if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit (N = 12 position magnitudes: L = 22)
-      static bool raised = false;
-      if (!raised) { hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); raised = true; }
-    }
-    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, P);
-  };
+  const size_t lds = (size_t)(kThreads / P.split) * 2 * (L - 1) * sizeof(double);   // two root buffers per search (mtg_extrema_lane.h)
   if (P.split == 2) {
-    if (P.rolled) go(mtg_minmax_seg_kernel<NMAX, 2, true>);
-    else go(mtg_minmax_seg_kernel<NMAX, 2, false>);
+    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, true>), grid, dim3(kThreads), lds, stream, P);
+    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, false>), grid, dim3(kThreads), lds, stream, P);
   } else {
-    if (P.rolled) go(mtg_minmax_seg_kernel<NMAX, 1, true>);
-    else go(mtg_minmax_seg_kernel<NMAX, 1, false>);
+    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, true>), grid, dim3(kThreads), lds, stream, P);
+    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, false>), grid, dim3(kThreads), lds, stream, P);
   }
 }
 

@@ -209,20 +209,19 @@ struct Level {
     for (int j = 0; j <= KH; ++j) anorm += fabs(a[j]);
     const double fnoise = kNoiseUlps * DBL_EPSILON * anorm;
     // partition points P_0 = 0, P_i = roots[SRC + i - 1] (i = 1 .. cnt), P_(cnt+1) = 1; interval i = [P_i, P_(i+1)]
-    // Round 5: the level's VALUES at the partition points are kept (third buffer, roots[FV + i] = value at P_i): phase B used to
-    // evaluate both ends of every bracket again -- four Horner chains per bracket pair, a fifth of a refinement's arithmetic.
-    constexpr int FV = 2 * M;
+    // (Round 5, measured and not adopted: keeping this level's VALUES at the partition points in a third LDS buffer instead of
+    // evaluating both ends of every bracket again in phase B -- a fifth of a refinement's arithmetic on paper -- gave 4 % on the
+    // one-derivative launch (214 -> 205 / 176 -> 170 us per 10k x 8) and LOST 35 % on the velocity + acceleration launch of the
+    // time-scaling path (311 -> 418 us): 48 instead of 30 KB of LDS per 128-lane workgroup, three instead of five workgroups
+    // per CU, a second round of workgroups.  profiles/r05h_extrema_partition_values_in_lds_not_adopted.txt)
     unsigned mask = 0;
     {
       double flo = a[0];   // value at 0
-      roots[FV] = flo;
       for (int i = 0; i <= cnt; i += 2) {
         const double h0 = i < cnt ? roots[SRC + i] : 1.0;
         const double h1 = i + 1 < cnt ? roots[SRC + i + 1] : 1.0;
         double f0, f1;
         horner_pair<KH>(a, h0, h1, f0, f1);
-        roots[FV + i + 1] = f0;
-        if (i + 1 <= cnt) roots[FV + i + 2] = f1;
         if ((flo < 0.0) != (f0 < 0.0)) mask |= 1u << i;
         if (i + 1 <= cnt && (f0 < 0.0) != (f1 < 0.0)) mask |= 1u << (i + 1);
         flo = f1;
@@ -238,7 +237,9 @@ struct Level {
     auto refine = [&](int ia, int ra, int ib, int rb, bool wa, bool wb) {
       const double lo0 = ia > 0 ? roots[SRC + ia - 1] : 0.0, hi0 = ia < cnt ? roots[SRC + ia] : 1.0;
       const double lo1 = ib > 0 ? roots[SRC + ib - 1] : 0.0, hi1 = ib < cnt ? roots[SRC + ib] : 1.0;
-      const double fl0 = roots[FV + ia], fh0 = roots[FV + ia + 1], fl1 = roots[FV + ib], fh1 = roots[FV + ib + 1];
+      double fl0, fh0, fl1, fh1;
+      horner_pair<KH>(a, lo0, hi0, fl0, fh0);
+      horner_pair<KH>(a, lo1, hi1, fl1, fh1);
       Bracket b0, b1;
       bracket_init(b0, lo0, hi0, fl0, fh0);
       bracket_init(b1, lo1, hi1, fl1, fh1);
@@ -284,8 +285,8 @@ struct Level {
   }
 };
 
-// Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 3 * (L - 1) + 2 elements (two
-// buffers of L - 1 roots the levels alternate between, then the current level's L + 1 values at its partition points); returns the count and, in `base`, the offset of the buffer that holds the result.
+// Real roots in [0, 1] of g(tau) = sum_j g[j] tau^j, j < L; ascending.  L >= 2.  `roots` holds 2 * (L - 1) elements (two
+// buffers the levels alternate between); returns the count and, in `base`, the offset of the buffer that holds the result.
 template <int L, class Roots, bool ROLLED = false>
 MTGX_HD int real_roots_unit(const double* g, Roots& roots, int& base, const Share& sh = Share{0, 1, 1}) {
   constexpr int M = L - 1;   // degree

@@ -6,7 +6,7 @@
 
 namespace {
 struct LocalRoots {
-  double v[72];   // two buffers of L - 1 roots (the derivative-chain levels alternate between them) + L + 1 partition-point values, L <= 22
+  double v[48];   // two buffers of L - 1 elements (the derivative-chain levels alternate between them)
   double& operator[](int i) { return v[i]; }
 };
 

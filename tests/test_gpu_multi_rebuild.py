@@ -11,7 +11,7 @@ def test_rebuilt_requests_share_the_cached_schedule():
     import torch
     import mav_trajectory_generation_amd as m
     ctx = m.Context(0)
-    shapes = [(8, 3, 4), (10, 4, 8), (12, 5, 16), (10, 4, 32), (8, 3, 9)]
+    shapes = [(8, 3, 4), (10, 4, 8), (12, 5, 16), (10, 4, 32), (8, 3, 32)]       # config-4 shapes: bodies of the cross-structure kernel
     plans = [m.Plan(ctx, n, 3, k, d, m.ends_full_masks(n, k, 1)) for (n, d, k) in shapes]
 
     def make_set(seed, sizes):
