@@ -224,7 +224,10 @@ int mtg_basic_solution_host(const mtg_plan* plan, const double* times, const dou
  * Because the batches are independent the library overlaps them: plans with a slab-output kernel (the standard shapes)
  * run the whole queue as ONE persistent launch whose workgroups walk the tiles of all batches, batch-major (the pointer
  * triples travel in the kernel arguments, up to 96 batches per launch): no drain / launch gap between batches, the store
- * tail of batch i under the elimination of batch i + 1.  Results are bit-identical to n mtg_solve_linear calls.  Other
+ * tail of batch i under the elimination of batch i + 1.  Results are bit-identical to n mtg_solve_linear calls -- EXCEPT where a
+ * single call of that batch size would take the row-cooperative form by default (mtg_plan_launch_form = 7: N = 12 / K >= 16,
+ * N = 10 / K >= 64, N = 8 / K >= 80 in launches of at most one or two 4-trajectory workgroups per CU): that form eliminates in
+ * another order, and the queue (and mtg_multi_*) agrees with it to round-off x conditioning, not bit for bit.  Other
  * plans, and calls with MTG_FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH, enqueue one launch per batch back to back.           */
 int mtg_solve_linear_sequence(mtg_plan* plan, int32_t n, int64_t batch, const mtg_layout* layout,
                               const double* const* times, const double* const* d_fixed, double* const* coeffs,
