@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the solve + all_gather measurement")
     ap.add_argument("--gather-chunks", type=int, default=4)
+    ap.add_argument("--gather-via-mtg-comm", action="store_true", help="N > 1, nccl: also measure the chunked solve + gather through "
+                    "the C ABI's own RCCL communicator (mtg_comm_*); always done on a one-rank group")
     ap.add_argument("--exercise-collectives", action="store_true",
                     help="run every collective branch of the N > 1 path on a ONE-rank group (RCCL on a 1-GPU box: init, "
                          "all_reduce, all_gather, barrier, the chunked solve + all_gather_into_tensor); extra.collectives_exercised")
@@ -867,7 +869,10 @@ def main():
             gather = {"chunks": runner.n_chunks, "own_slice_matches_local_solve": own_slice_ok, "solve_plus_gather_ms": both * 1e3, "solve_only_ms": solve_only * 1e3,
                       "gather_only_ms": gather_only * 1e3,
                       "gathered_bytes_per_rank": world * B * K * D * N * 8, "backend": args.backend}
-            if args.backend == "nccl":
+            if args.backend == "nccl" and (world == 1 or args.gather_via_mtg_comm):
+                # (default at world == 1 only: a second communicator's ncclCommInitRank is a collective -- a rank that failed
+                # before it would leave the others waiting, and the driver's multi-GPU run must not hang on an extra;
+                # --gather-via-mtg-comm turns it on for N > 1)
                 # the same chunked solve + gather through the C ABI's OWN RCCL communicator (mtg_comm_*, csrc/mtg_comm.hip: what a
                 # C++ consumer running one process per GPU calls -- no torch.distributed in the data path; the unique id travels
                 # over the process group that exists anyway).  Never fails the bench: an error is recorded in the line.
