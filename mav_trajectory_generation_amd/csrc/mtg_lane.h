@@ -90,6 +90,15 @@ constexpr int mtg_ainv_offset(int n) {
 // (Round 5: rank deficiency is structural now -- see mtg_ldl -- so the association no longer decides what is flagged.)
 #define MTG_PARTIAL_ALL 0
 #endif
+#ifndef MTG_LDS_RING
+// 1: long static chains whose workspace steps are split between the wave's LDS and global memory (MtgCfg::LSJ < MtgCfg::WSJ)
+// bring the global steps back THROUGH the LDS step slots during the backward sweep (MtgCfg::kRing).  Built and measured in
+// round 5 (tools/build_ring_ab.sh, tools/ab_lds_ring.py, profiles/r05_lds_ring_ab.txt): bit-identical coefficients, every
+// long-chain parity test green, and NO change in time (N = 12 / K = 32 at 100k: 474.6 us without, 481.3 us with; K = 17 .. 31
+// and N = 10 / K = 50 within +-2 %) -- the memory round trip of the workspace steps is not what these kernels wait for.
+// Off: the direct form needs no hand-counted s_waitcnt.
+#define MTG_LDS_RING 0
+#endif
 #ifndef MTG_FS_PARTIAL
 #define MTG_FS_PARTIAL 1       // (0: factor-store steps still solve for G in the forward sweep -- A/B builds)
 #endif
@@ -137,6 +146,13 @@ struct MtgCfg {
   static constexpr int FCNT = kFS ? FMAXW * (FMAXW + 1) / 2 : FMAXW * FMAXW;   // kept numbers per step besides g
   static constexpr int WSE = DLW > 0 ? (FCNT + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
+  // Ring (round 5; chains with LDS steps AND global steps): the LSJ step slots of the wave's LDS are a ring in the backward
+  // sweep.  As soon as step j has been consumed from its slot, global step j - LSJ is requested INTO that slot by direct-to-LDS
+  // loads (global_load_lds_dwordx4: 16 bytes per lane, one instruction per two workspace rows, no registers), LSJ - 1 steps
+  // before it is needed; the back-substitution then reads every workspace step from the LDS.  (The direct form issues a
+  // global step's loads one step ahead, into registers.)  Same numbers, same order of operations: bit-identical to the
+  // direct form -- and, measured, not faster (see MTG_LDS_RING).
+  static constexpr bool kRing = MTG_LDS_RING != 0 && kStatic && DLW_ > 0 && LS_ >= 2 && WS_ > LS_ && WSE % 2 == 0;
   // RS_ != 0 (with DLW_): the REGISTER steps keep G shared as well -- lane of dimension k holds elements k, DLW + k, ... of
   // G (GROWS doubles instead of up to H * H) and fetches its siblings' elements with ds_bpermute at back-substitution time
   // (the three lanes of a trajectory compute identical G): half the registers per step, i.e. twice the steps on chip.
@@ -1183,6 +1199,41 @@ template <class C>
 __device__ __forceinline__ mtg_lds_double* mtg_lds_step(const MtgParams& P, int j) {
   return (mtg_lds_double*)(size_t)(P.lds_steps + (unsigned)(j - (C::WSJ - C::LSJ)) * (unsigned)(C::WSE * 64 * sizeof(double)));
 }
+// MtgCfg::kRing: byte address of this lane's column in the slot workspace step j uses (any j < WSJ; steps LSJ apart share one)
+template <class C>
+__device__ __forceinline__ unsigned mtg_lds_ring_addr(const MtgParams& P, int j) {
+  constexpr int L = C::LSJ > 0 ? C::LSJ : 1;
+  const int s = (((j - (C::WSJ - C::LSJ)) % L) + L) % L;
+  return P.lds_steps + (unsigned)s * (unsigned)(C::WSE * 64 * sizeof(double));
+}
+// One workspace step, global -> LDS slot, asynchronously.  src: this lane's source address for rows 0 / 1 (lanes 0-31 the
+// first row's 16-byte pieces, lanes 32-63 the second row's); slot: the WAVE's slot address (uniform).  The instruction
+// writes lane l's 16 bytes to M0 + 16 l, i.e. two consecutive 512-byte rows.  The compiler does NOT track these writes
+// (no s_waitcnt before a later ds_read of the slot: checked in the ISA) -- the consumer waits with mtg_wait_vmcnt.
+template <class C>
+__device__ __forceinline__ void mtg_ws_prefetch_lds(const double* src, long long ws_stride, unsigned slot) {
+  typedef __attribute__((address_space(1))) const void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  asm volatile("" ::: "memory");   // after the LDS reads that consumed the slot's previous step
+#pragma unroll
+  for (int q = 0; q < C::WSE / 2; ++q) {
+    __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(size_t)(slot + (unsigned)q * 1024u), 16, 0, 0);
+    src += 2 * ws_stride;
+  }
+  asm volatile("" ::: "memory");
+}
+// s_waitcnt vmcnt(n) as a compiler-level memory barrier; n folds to a constant in the unrolled loops that call it.
+__device__ __forceinline__ void mtg_wait_vmcnt(int n) {
+#define MTG_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    MTG_VMCNT_CASE(1) MTG_VMCNT_CASE(2) MTG_VMCNT_CASE(3) MTG_VMCNT_CASE(4) MTG_VMCNT_CASE(5) MTG_VMCNT_CASE(6)
+    MTG_VMCNT_CASE(7) MTG_VMCNT_CASE(8) MTG_VMCNT_CASE(9) MTG_VMCNT_CASE(10) MTG_VMCNT_CASE(11) MTG_VMCNT_CASE(12)
+    MTG_VMCNT_CASE(13) MTG_VMCNT_CASE(14) MTG_VMCNT_CASE(15) MTG_VMCNT_CASE(16) MTG_VMCNT_CASE(17) MTG_VMCNT_CASE(18)
+    MTG_VMCNT_CASE(19) MTG_VMCNT_CASE(20) MTG_VMCNT_CASE(21) MTG_VMCNT_CASE(22) MTG_VMCNT_CASE(23) MTG_VMCNT_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef MTG_VMCNT_CASE
+}
 #endif
 template <int DL>
 MTG_HD double mtg_pick(int d, const double (&c)[DL]) {
@@ -1460,6 +1511,23 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       for (int k = 0; k < C::DLW; ++k) perm[k] = 4 * ((int)(threadIdx.x & 63) + (int)P.ws_share + k * (64 / C::DLW));
     }
 #endif
+    // MtgCfg::kRing.  JTOP: steps below it come back from the workspace.  ringed(p): global step p is brought into the slot
+    // of step p + LSJ once that step has been consumed (iteration p + LSJ of the loop below), and read from there.
+    [[maybe_unused]] constexpr int JTOP = C::WSJ < KC ? C::WSJ : KC;
+    [[maybe_unused]] constexpr int RG = C::WSE / 2;   // direct-to-LDS instructions per step
+    [[maybe_unused]] auto ringed = [&](int p) {
+      return C::kRing && p >= 0 && p < C::WSJ - C::LSJ && p + C::LSJ < JTOP &&
+             C::popc(mtg_mask<C>(P, mtg_vl<DIR>(C::KT, p))) < H;   // (a step whose left vertex is fixed keeps nothing)
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    [[maybe_unused]] const double* ring_src = nullptr;
+    [[maybe_unused]] unsigned ring_lane8 = 0;
+    if constexpr (C::kRing) {
+      const int lane = (int)(threadIdx.x & 63);
+      ring_src = wsl - lane + 2 * (lane & 31) + (lane >> 5) * P.ws_stride;
+      ring_lane8 = (unsigned)lane * 8u;
+    }
+#endif
     auto request = [&](int j) {
       if constexpr (C::kRegShared) {
         if (j >= C::WSJ) {   // register step: G back from the three dimension lanes' shares (g is per lane)
@@ -1471,7 +1539,19 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
       }
       if constexpr (C::DLW > 0) {
-        if (j >= C::WSJ - C::LSJ) {
+        if (ringed(j)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          // Everything issued before step j's group must have landed: the groups of steps j - 1 .. j - LSJ + 1 (those that
+          // exist) were issued after it -- this call runs in iteration j + 1, after that iteration's group -- and so were
+          // an unknown number of coefficient stores (the counter retires in order, so they only make the bound safer).
+          int later = 0;
+#pragma unroll
+          for (int p = j - 1; p > j - C::LSJ; --p) later += ringed(p) ? RG : 0;
+          mtg_wait_vmcnt(later);
+          mtg_ws_load_shared<C>((mtg_lds_double*)(size_t)mtg_lds_ring_addr<C>(P, j), 64, P.ws_share, Gw, gw,
+                                mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
+#endif
+        } else if (j >= C::WSJ - C::LSJ) {
 #if defined(__HIP_DEVICE_COMPILE__)
           mtg_ws_load_shared<C>(mtg_lds_step<C>(P, j), 64, P.ws_share, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
                                 mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
@@ -1504,6 +1584,13 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
         // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
         // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (C::kRing) {   // step j's slot is free (its reads fed the back-substitution above): refill it
+          if (j < JTOP && ringed(j - C::LSJ))
+            mtg_ws_prefetch_lds<C>(ring_src + (long long)(j - C::LSJ) * C::WSE * P.ws_stride, P.ws_stride,
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(mtg_lds_ring_addr<C>(P, j) - ring_lane8)));
+        }
+#endif
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
       } else {
