@@ -57,7 +57,16 @@ struct MtgParams {
   // tile -> (variant, tile of the real batch); pert_seg is that tile's perturbed segment (-1: none).
   int pert_on, pert_seg, pert_tpv;   // pert_tpv: tiles per variant
   double pert_h, pert_corr, pert_lo;
+#if defined(MTG_LAB_TIMELINE)
+  long long* tl;   // measurement build (tools/lab/long_timeline.hip): this wave's stamp row of the current tile, or null
+#endif
 };
+// measurement build: shader-clock stamp `slot` of the current tile by lane 0 (compiled out of the product)
+#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
+#define MTG_TL(P, slot) do { if ((threadIdx.x & 63) == 0 && (P).tl != nullptr) (P).tl[slot] = clock64(); } while (0)
+#else
+#define MTG_TL(P, slot) do { } while (0)
+#endif
 
 // segment time as the virtual problem sees it (identity unless a perturbed-time launch)
 MTG_HD double mtg_perturb(const MtgParams& P, int seg, double T) {
@@ -1409,6 +1418,9 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
       if (j + 1 < KC) asm("" : "+v"(ln.T[j + 1]) : "v"(ln.Sc[H - 1][H - 1]));
 #endif
       const int ml = mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j));
+#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
+      if (j == 1 || j == 2) { asm volatile("" : "+v"(ln.Sc[H - 1][H - 1])); MTG_TL(P, j == 1 ? 1 : 7); }   // steps 0 / 1 done
+#endif
       if (j < C::WSJ) {
         double G[H][H], g[D][H];
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
@@ -1483,9 +1495,13 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
 
 // `active` = this lane owns a real trajectory (tail tiles run clamped duplicates whose outputs
 // are suppressed; every lane still takes part in the cooperative coefficient flush).
-template <class C, int DIR, int OUT, class IO>
+struct MtgNoHook { MTG_HD void operator()(int) const {} };
+// hook(j): called in back-substitution step j of a static chain, after the next step's data has been requested and before
+// step j's coefficients are recovered and stored (mtg_dimlane.h requests the next tile's first inputs from it)
+template <class C, int DIR, int OUT, class IO, class HK = MtgNoHook>
 MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
-                            const double* other, int stride, IO& io, bool active, double* cost_out = nullptr) {
+                            const double* other, int stride, IO& io, bool active, double* cost_out = nullptr,
+                            const HK& hook = HK()) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
@@ -1499,6 +1515,10 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
 #endif
   if (DIR > 0) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
+#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(xr[0][0]));
+  MTG_TL(P, 6);   // middle vertex solved
+#endif
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
     // steps below C::WSJ: (G, g) come back from the workspace, requested one step ahead -- right after the previous
@@ -1592,8 +1612,10 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
 #endif
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
+        hook(j);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
       } else {
+        hook(j);
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);
       }
 #if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
