@@ -98,125 +98,6 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
   }
 }
 
-// Early inputs (round 5).  A persistent wave needs the next tile's inputs the moment the current tile ends, and their registers
-// (T, fx) are live until then: the loads were issued after the last coefficient drain and the end-of-tile barrier then sat
-// through their whole latency (and, because the compiler put s_waitcnt vmcnt(0) in front of that barrier, through the
-// acknowledgement of the tile's last coefficient stores as well): 3.4-4.6k of a tile's 35-90k cycles in the long chains
-// (tools/lab/long_timeline.hip, profiles/r05_long_timeline.txt).  Now the inputs of the next tile's first E forward steps
-// (E segment times, the fixed values of the end vertex and of E more vertices) are loaded into registers of their own while
-// the back-substitution still has MTG_DL_EARLY_AT steps to go (the times / fixed values of the steps already recovered are
-// dead by then), the rest after the last drain, and the barrier waits for the LDS only.
-#ifndef MTG_DL_EARLY
-#define MTG_DL_EARLY 0          // E (0: off -- everything after the last drain)
-#endif
-#ifndef MTG_DL_WARM
-#define MTG_DL_WARM 0           // 1: instead, touch every line of the next tile's inputs from the same place (L2 warm-up, 4 registers)
-#endif
-#ifndef MTG_DL_END_LDS_BARRIER
-#define MTG_DL_END_LDS_BARRIER 0   // 1: the end-of-tile barrier waits for the LDS only (0: __syncthreads, as before)
-#endif
-#ifndef MTG_DL_EARLY_AT
-#define MTG_DL_EARLY_AT 2       // issued in back-substitution step min(this, steps - 1) of the current tile
-#endif
-#ifndef MTG_DL_EARLY_MIN_K
-#define MTG_DL_EARLY_MIN_K 16   // chains of at least this many segments
-#endif
-template <class C, int DIR>
-struct MtgDlEarly {
-  static constexpr int KC = DIR > 0 ? C::KA : C::KB;
-  static constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
-  static constexpr int E = MTG_DL_EARLY < KC - 1 ? MTG_DL_EARLY : (KC - 1 > 0 ? KC - 1 : 0);
-  static constexpr int NE0 = C::popc(DIR > 0 ? C::MS : C::ME) + E * C::popc(C::MI);
-  static constexpr int NE = NE0 < nc ? NE0 : nc;          // fixed values of the end vertex and the next E vertices ...
-  static constexpr int c_lo = DIR > 0 ? 0 : nc - NE;      // ... are columns [c_lo, c_lo + NE) of this direction's range
-};
-template <class C>
-struct MtgDlEarlyCfg {
-  static constexpr bool on = MTG_DL_EARLY > 0 && C::KT >= MTG_DL_EARLY_MIN_K && C::KB >= 2;
-  static constexpr int E = on ? (MtgDlEarly<C, 1>::E > MtgDlEarly<C, -1>::E ? MtgDlEarly<C, 1>::E : MtgDlEarly<C, -1>::E) : 1;
-  static constexpr int NE = on ? (MtgDlEarly<C, 1>::NE > MtgDlEarly<C, -1>::NE ? MtgDlEarly<C, 1>::NE : MtgDlEarly<C, -1>::NE) : 1;
-  static constexpr int AT = MTG_DL_EARLY_AT < C::KB - 1 ? MTG_DL_EARLY_AT : C::KB - 1;
-  static constexpr bool warm = MTG_DL_WARM != 0 && !on && C::KT >= MTG_DL_EARLY_MIN_K && C::KB >= 2;
-  static constexpr bool lds_barrier = MTG_DL_END_LDS_BARRIER != 0 && C::KT >= MTG_DL_EARLY_MIN_K;
-};
-// MTG_DL_WARM: one dword of each 128-byte line of the next tile's input row pieces (canonical / padded SoA: a row piece is the
-// TPW trajectories' 8 * TPW consecutive bytes of one times / d_fixed row).  Lane i touches piece i and piece i + 64 of this
-// direction's KC + nc * DL pieces, first and second line each; the values are only kept alive until the tile ends.
-template <class C, int DIR, int DL>
-__device__ __forceinline__ void mtg_dl_warm(const double* __restrict__ times, const double* __restrict__ dfix, unsigned B,
-                                            unsigned b0, int lane, unsigned (&sink)[4]) {
-  constexpr int KC = DIR > 0 ? C::KA : C::KB;
-  constexpr int nc = DIR > 0 ? C::NCA : C::NCB;
-  constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
-  constexpr int k0 = DIR > 0 ? 0 : C::KT - KC;     // first segment of this direction's range
-  constexpr int NPIECE = KC + nc * DL;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    int i = lane + 64 * r;
-    if (i >= NPIECE) i = NPIECE - 1;
-    const bool is_t = i < KC;
-    const int f = i - KC, dd = f / nc, cc = f - dd * nc;
-    const unsigned row = is_t ? (unsigned)(k0 + i) : (unsigned)(dd * C::offFEnd + c0 + cc);
-    const unsigned b1 = b0 + 16u < B ? b0 + 16u : B - 1u;   // (second line of the piece; never past the row)
-    const char* base = reinterpret_cast<const char*>(is_t ? times : dfix);
-    sink[2 * r] = *reinterpret_cast<const unsigned*>(base + (row * B + b0) * 8u);
-    sink[2 * r + 1] = *reinterpret_cast<const unsigned*>(base + (row * B + b1) * 8u);
-  }
-}
-
-// mtg_dl_preload in two parts.  PART 1: the early part -> (eT, efx); PART 2: the rest -> (T, fx), the early elements copied in
-// from (eT, efx).  Same addresses, same element order as mtg_dl_preload.
-template <class C, int DIR, int PART>
-__device__ __forceinline__ void mtg_dl_preload_part(const double* __restrict__ times, const double* __restrict__ dfix,
-                                                    unsigned B, unsigned b, unsigned d, unsigned dl, int aos,
-                                                    double (&T)[C::KCS], double (&fx)[1][C::NC],
-                                                    double (&eT)[MtgDlEarlyCfg<C>::E], double (&efx)[MtgDlEarlyCfg<C>::NE]) {
-  using EA = MtgDlEarly<C, DIR>;
-  constexpr int KC = EA::KC, nc = EA::nc;
-  constexpr int c0 = DIR > 0 ? C::colBeginA : C::colBeginB;
-  constexpr unsigned k0 = DIR > 0 ? 0u : (unsigned)(C::KT - 1);
-  if constexpr (PART == 2) {
-    // The early values are pinned BEFORE the loads of the rest are issued: otherwise their wait ends up behind those loads
-    // (it came out as s_waitcnt vmcnt(0) after them -- the whole latency again).  Both directions then write EVERY element of
-    // T and fx in the same order (see mtg_dl_preload).
-#pragma unroll
-    for (int j = 0; j < MtgDlEarlyCfg<C>::E; ++j) asm volatile("" : "+v"(eT[j]) : : "memory");
-#pragma unroll
-    for (int c = 0; c < MtgDlEarlyCfg<C>::NE; ++c) asm volatile("" : "+v"(efx[c]) : : "memory");
-  }
-  const unsigned step = aos ? 8u : B * 8u;
-  unsigned ot = aos ? (b * (unsigned)C::KT + k0) * 8u : (k0 * B + b) * 8u;
-#pragma unroll
-  for (int j = 0; j < C::KCS; ++j) {
-    const bool early = j < EA::E;
-    if (j < KC) {
-      if (PART == 1 && early) eT[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(times) + ot);
-      if (PART == 2) T[j] = early ? eT[j] : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(times) + ot);
-      ot = DIR > 0 ? ot + step : ot - step;
-    } else if (PART == 2) {
-      T[j] = 0.0;
-    }
-  }
-  if constexpr (PART == 1) {   // (every element of the early arrays is written by both directions)
-#pragma unroll
-    for (int j = EA::E; j < MtgDlEarlyCfg<C>::E; ++j) eT[j] = 0.0;
-#pragma unroll
-    for (int c = EA::NE; c < MtgDlEarlyCfg<C>::NE; ++c) efx[c] = 0.0;
-  }
-  unsigned of = aos ? ((b * dl + d) * (unsigned)C::offFEnd + (unsigned)c0) * 8u : ((d * (unsigned)C::offFEnd + (unsigned)c0) * B + b) * 8u;
-#pragma unroll
-  for (int c = 0; c < C::NC; ++c) {
-    const bool early = c >= EA::c_lo && c < EA::c_lo + EA::NE;
-    if (c < nc) {
-      if (PART == 1 && early) efx[c - EA::c_lo] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(dfix) + of);
-      if (PART == 2) fx[0][c] = early ? efx[c - EA::c_lo] : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(dfix) + of);
-      of += step;
-    } else if (PART == 2) {
-      fx[0][c] = 0.0;
-    }
-  }
-}
-
 #if defined(MTG_LAB_TIMELINE)   // per-tile stamps of the first MTG_LAB_TIMELINE tiles of every wave (tools/lab/long_timeline.hip)
 #define MTG_DL_STAMP(slot) MTG_TL(P, slot)
 #elif defined(MTG_LAB_TIMING)
@@ -326,20 +207,6 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if (dir == 0) mtg_dl_preload<C, 1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
     else mtg_dl_preload<C, -1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, T_, fx_);
   };
-  using EC = MtgDlEarlyCfg<C>;
-  [[maybe_unused]] double eT[EC::E], efx[EC::NE];
-  [[maybe_unused]] auto fetch_early = [&](const Where& w) {
-    unsigned bb = (unsigned)w.local * TPW + t;
-    if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload_part<C, 1, 1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx, eT, efx);
-    else mtg_dl_preload_part<C, -1, 1>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx, eT, efx);
-  };
-  [[maybe_unused]] auto fetch_rest = [&](const Where& w) {
-    unsigned bb = (unsigned)w.local * TPW + t;
-    if (bb >= (unsigned)B) bb = B - 1;
-    if (dir == 0) mtg_dl_preload_part<C, 1, 2>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx, eT, efx);
-    else mtg_dl_preload_part<C, -1, 2>(w.t, w.f, Bs, bb, (unsigned)d, (unsigned)DL, aos, ln.T, ln.fx, eT, efx);
-  };
   Where cur{0, 0, times, dfix, coeffs};
   int tile_prev = 0;
   if ((int)blockIdx.x < nunits) {
@@ -405,25 +272,12 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     __syncthreads();
     MTG_DL_STAMP(3);
     [[maybe_unused]] double part = 0.0;
-    // (early inputs of the next tile: requested from inside the back-substitution, see MTG_DL_EARLY)
-    [[maybe_unused]] unsigned warm_sink[4] = {0u, 0u, 0u, 0u};
-    auto early_hook = [&](int j) {
-      if constexpr (EC::on) {
-        if (j == EC::AT && has_next) fetch_early(nxt);
-      } else if constexpr (EC::warm) {
-        if (j == EC::AT && has_next && !aos) {   // (SoA layouts; AoS tiles keep the plain path)
-          const unsigned nb0 = (unsigned)nxt.local * TPW;
-          if (dir == 0) mtg_dl_warm<C, 1, DL>(nxt.t, nxt.f, Bs, nb0, lane, warm_sink);
-          else mtg_dl_warm<C, -1, DL>(nxt.t, nxt.f, Bs, nb0, lane, warm_sink);
-        }
-      }
-    };
     if (dir == 0) {
       ioA.begin_tile(cur.c, b0, B);
-      mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active, (OUT & 1) ? &part : nullptr, early_hook);
+      mtg_lane_finish<C, 1, OUT>(P, b, ln, wsl, other, kWave, ioA, active, (OUT & 1) ? &part : nullptr);
     } else {
       ioB.begin_tile(cur.c, b0, B);
-      mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active, (OUT & 1) ? &part : nullptr, early_hook);
+      mtg_lane_finish<C, -1, OUT>(P, b, ln, wsl, other, kWave, ioB, active, (OUT & 1) ? &part : nullptr);
     }
     if constexpr ((OUT & 1) != 0) {
       // cost of this half-chain: the DL dimension lanes of a trajectory summed in a fixed order by the dimension-0 lane,
@@ -443,18 +297,15 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if (lane == 0 && first) { tdbg[5] = clock64(); tdbg[15] = wall_clock64(); }
 #endif
     if (has_next) {
-      if constexpr (EC::on) fetch_rest(nxt);
-      else fetch(nxt, ln.T, ln.fx);
+      fetch(nxt, ln.T, ln.fx);
       cur = nxt;
     }
-    // The barrier orders the reuse of the pair's LDS (slabs, exchange buffer, step slots) -- nothing in global memory is
-    // shared between the two waves.  __syncthreads() came out as s_waitcnt vmcnt(0) + s_barrier here: the full latency of the
-    // loads just issued and of the last coefficient stores' acknowledgements, once per tile.
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (EC::warm) asm volatile("" : : "v"(warm_sink[0]), "v"(warm_sink[1]), "v"(warm_sink[2]), "v"(warm_sink[3]));
-    if constexpr (EC::lds_barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else __syncthreads();
-#endif
+    // (This barrier comes out as s_waitcnt vmcnt(0) + s_barrier -- it sits through the loads just issued and the last coefficient
+    // stores' acknowledgements.  Round 5 measured three hand-overs that avoid that -- an LDS-only barrier, an L2 warm-up of the
+    // next tile's inputs and the first steps' inputs loaded early into registers of their own (commit 31baf6e) -- and none moves
+    // the launch time: what the end of a tile waits for is the other direction's wave, whose back-substitution finishes up to
+    // 20 % apart -- profiles/r05_long_timeline.txt.)
+    __syncthreads();
 #if defined(MTG_LAB_TIMELINE)
     MTG_DL_STAMP(5);
 #endif

@@ -1495,13 +1495,9 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
 
 // `active` = this lane owns a real trajectory (tail tiles run clamped duplicates whose outputs
 // are suppressed; every lane still takes part in the cooperative coefficient flush).
-struct MtgNoHook { MTG_HD void operator()(int) const {} };
-// hook(j): called in back-substitution step j of a static chain, after the next step's data has been requested and before
-// step j's coefficients are recovered and stored (mtg_dimlane.h requests the next tile's first inputs from it)
-template <class C, int DIR, int OUT, class IO, class HK = MtgNoHook>
+template <class C, int DIR, int OUT, class IO>
 MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, const double* wsl,
-                            const double* other, int stride, IO& io, bool active, double* cost_out = nullptr,
-                            const HK& hook = HK()) {
+                            const double* other, int stride, IO& io, bool active, double* cost_out = nullptr) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int vm = (K + 1) / 2;
@@ -1612,10 +1608,8 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
 #endif
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
-        hook(j);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
       } else {
-        hook(j);
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);
       }
 #if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
