@@ -34,6 +34,19 @@
 extern "C" {
 #endif
 int mtg_context_set_option(mtg_context* ctx, const char* name, int value);
+
+/* EVIDENCE variant of one step of the path (SURVEY.md section 7 "K1-alt"; the MFMA clause of BASELINE.json's north_star) -- no
+ * solve entry point goes through it.  The per-segment cost matrices  H_k = A_k^-T Q_k A_k^-1  of
+ * impl/polynomial_optimization_linear_impl.h:318 (A: LIN:112-121, its inverse LIN:143-179, Q: LIN:568-583) for `n_segments`
+ * segment times, h_out [n_segments][n_coeffs][n_coeffs] row-major:
+ *   variant 1   LITERALLY: both N x N x N products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, N <= 12 padded to one
+ *               16 x 16 tile), one wavefront per segment, A^-1 and Q assembled per segment;
+ *   variant 0   by the unit-time scaling identity the solve kernels use (H(T) = T^(1-2d) S H(1) S, constant table).
+ * n_coeffs even in 2..12, 0 <= derivative < n_coeffs / 2; device pointers; asynchronous on the context's stream.
+ * Measured: the literal form is 4.9x slower and reaches 5.5 % of the FP64 MFMA peak (profiles/r01_literal_h_mfma.txt);
+ * checked against the 50-digit oracle in tests/test_gpu_literal_mfma.py.                                              */
+int mtg_lab_segment_cost_matrices(mtg_context* ctx, int32_t n_coeffs, int32_t derivative, int64_t n_segments,
+                                  const double* times, double* h_out, int32_t variant);
 #ifdef __cplusplus
 }
 #endif

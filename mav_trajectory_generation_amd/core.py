@@ -61,6 +61,20 @@ class Context:
         """A measurement knob of this context by name (include/mtg_hip_lab.h: A/B runs and form-forcing tests)."""
         _check(self.lib, self.lib.mtg_context_set_option(self.handle, name.encode(), int(value)), self.handle)
 
+    def lab_segment_cost_matrices(self, n_coeffs: int, derivative: int, times, variant: int):
+        """EVIDENCE variant (include/mtg_hip_lab.h: mtg_lab_segment_cost_matrices): H_k = A_k^-T Q_k A_k^-1 (LIN:318) of the
+        given segment times, [n][N][N]; variant 1 = literally on the FP64 matrix cores, 0 = the scaling identity."""
+        import torch
+        t = times.contiguous()
+        out = torch.empty((t.numel(), n_coeffs, n_coeffs), dtype=torch.float64, device=t.device)
+        cur = self._enter()
+        try:
+            _check(self.lib, self.lib.mtg_lab_segment_cost_matrices(self.handle, n_coeffs, derivative, t.numel(), t.data_ptr(),
+                                                                    out.data_ptr(), variant), self.handle)
+        finally:
+            self._leave(cur)
+        return out
+
     def _enter(self):
         """Order the library's stream after torch's current stream (no-op when they are the same)."""
         import torch
