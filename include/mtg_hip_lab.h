@@ -21,8 +21,8 @@
  *   "rolled_wg_per_cu" >= 1 (default 4)            persistent workgroups per CU of the rolled kernels
  *   "dl_max_units"     -1 default, >= 0            upper limit of the dimension-in-lane default range (x CUs)
  *   "coop"             -1 default, 0 never, 1 always   row-cooperative form where eligible
- *   "extrema_split"    -1 default; bits 0-1: lanes that share one root search of the extrema kernels (1 / 2, 0 = by launch
- *                      size); bit 2: one code body for all levels of the derivative chain instead of one per level
+ *   "extrema_split"    -1 default; bits 0-1: lanes that share one root search of the extrema kernels (1, 2, 3 = four; 0 = by
+ *                      launch size, the default); bit 2: one code body for all levels of the derivative chain
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
  *   "dl_stagger"       >= 0 (default 0)            every second workgroup of a single dimension-in-lane launch starts
  *                                                  value x 2048 shader cycles late (phase-lock experiment: no effect)

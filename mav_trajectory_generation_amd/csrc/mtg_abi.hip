@@ -131,7 +131,7 @@ struct mtg_context {
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
   int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
-  int knob_extrema_split = -1;       // MTG_EXTREMA_SPLIT: lanes per root search of the extrema kernels (1 / 2; -1: by launch size)
+  int knob_extrema_split = -1;       // MTG_EXTREMA_SPLIT: lanes per root search of the extrema kernels (include/mtg_hip_lab.h; -1: default)
   int knob_coop = -1;                // MTG_COOP: 1 always / 0 never take the row-cooperative form where eligible (default: by size)
   int knob_dl_stagger = 0;           // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events

@@ -33,7 +33,7 @@ struct ExtremaParams {
   int N, K, D;
   unsigned mask;
   int der[2];
-  int split;              // lanes that share one root search (launch_seg): 1, or 2 for small launches
+  int split;              // lanes that share one root search (launch_seg): 1, 2 or 4
   int rolled;             // one code body for all levels of the derivative chain (mtg_extrema_lane.h, Level) or one per level
 };
 
@@ -43,9 +43,11 @@ struct LdsRoots {
   __device__ double& operator[](int i) { return p[i * COLS]; }
 };
 
-// SPLIT lanes share one (trajectory, segment) root search (mtg_extrema_lane.h, Share): small launches are bound by the latency
-// of one lane's chain of refinements -- 10k x 8 segments are 1250 wavefronts, ~1.2 per SIMD -- and two lanes halve it.  The
-// lanes of a search are neighbours in one wavefront and address the same LDS column; lane `part` 0 writes the result.
+// SPLIT lanes share one (trajectory, segment) root search (mtg_extrema_lane.h, Share): a launch with about one wavefront per SIMD
+// or fewer is bound by the LATENCY of a lane's chain of refinements (a lone wavefront of one-lane searches takes ~150 us whatever
+// the batch), and two / four lanes shorten that chain.  The lanes of a search are neighbours in one wavefront and address the same
+// LDS column; lane `part` 0 writes the result.  Results do not depend on SPLIT (bit-identical by construction: a bracket's
+// refinement does not depend on which lane refines it; tests/test_extrema.py).
 template <int NMAX, int SPLIT, bool ROLLED>
 __global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
   extern __shared__ double lds[];
@@ -172,28 +174,35 @@ void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   const long long total = P.B * P.K;
   const dim3 grid((unsigned)((P.split * total + kThreads - 1) / kThreads), n_slots);
   const size_t lds = (size_t)(kThreads / P.split) * 2 * (L - 1) * sizeof(double);   // two root buffers per search (mtg_extrema_lane.h)
-  if (P.split == 2) {
-    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, true>), grid, dim3(kThreads), lds, stream, P);
-    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 2, false>), grid, dim3(kThreads), lds, stream, P);
-  } else {
-    if (P.rolled) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, true>), grid, dim3(kThreads), lds, stream, P);
-    else hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, 1, false>), grid, dim3(kThreads), lds, stream, P);
-  }
+#define MTG_XL(S, R) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, S, R>), grid, dim3(kThreads), lds, stream, P)
+  if (P.rolled) {   // (measurement knob: one or two lanes)
+    if (P.split == 2) MTG_XL(2, true); else MTG_XL(1, true);
+  } else if (P.split == 4) MTG_XL(4, false);
+  else if (P.split == 2) MTG_XL(2, false);
+  else MTG_XL(1, false);
+#undef MTG_XL
 }
 
-// Two lanes per search (mtg_extrema_lane.h, Share) were built to halve the latency of a lane's refinement chain in small launches.
-// Measured (profiles/r04f_extrema_variants.jsonl, r04_next_rows_pmc.json): 10k x 8 segments 177 vs 181 us, 2 500 x 8 134 vs
-// 134 us -- for 39 % more VALU instructions (phase A is repeated by both lanes).  Not the default: selectable (measurement knob
-// "extrema_split"), bit-identical results (tests/test_extrema.py).
-constexpr long long kSplitMaxSearches = 0;
+// Lanes per search by launch size (round 5; profiles/r05_extrema_lanes_per_search.jsonl, N = 10 / K = 8 / D = 3, velocity search, us):
+//   wavefronts at one lane per search      313     625    1024    1250    1500    2048
+//   one lane                               149     185     188     193     197     215
+//   two lanes                              136     138     140     183     222     244
+//   four lanes                             112     145     178     209     237     316
+// A wavefront costs the same whatever its number of live lanes, so more lanes per search cost instructions (two: +39 %) and pay
+// only while the chip has SIMDs to spare -- up to one one-lane wavefront per SIMD (1024).  At 1250 (10k x 8 segments) two lanes
+// measured 179 vs 194 us in one process and 224 vs 207 us inside bench.py: not a default there.  (Also measured and dropped: the
+// whole rounds of wavefronts at one lane per search and only the SURPLUS searches on four lanes, in one launch -- 186 us at 1250.)
+constexpr long long kFourLanesMaxWaves = 400, kTwoLanesMaxWaves = 1100;
 int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int option) {
-  // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1 / 2, 0 = by size); bit 2: ONE code body
-  // for all levels of the derivative chain.  Measured (profiles/r04f_extrema_variants.jsonl, 10k x 8 segments): per-level
-  // bodies 181 / 177 us (one / two lanes per search), one body 221 / 211 us -- the 60 KB of straight-line code are NOT what
-  // bounds the kernel (its zero-padded chains cost more than the instruction fetches they save): per-level bodies stay.
+  // option (measurement knob "extrema_split"): -1 default; bits 0-1: lanes per search (1, 2, 3 = four; 0 = by launch size); bit 2:
+  // ONE code body for all levels of the derivative chain.  Measured (profiles/r04f_extrema_variants.jsonl, 10k x 8 segments):
+  // per-level bodies 181 / 177 us (one / two lanes per search), one body 221 / 211 us -- the 60 KB of straight-line code are NOT
+  // what bounds the kernel (its zero-padded chains cost more than the instruction fetches they save): per-level bodies stay.
   const int split_option = option < 0 ? 0 : (option & 3);
   P.rolled = option < 0 ? 0 : ((option & 4) ? 1 : 0);
-  P.split = split_option == 1 || split_option == 2 ? split_option : (P.B * P.K * n_slots <= kSplitMaxSearches ? 2 : 1);
+  const long long waves = (P.B * P.K + 63) / 64 * n_slots;   // at one lane per search, all derivative slots of the launch
+  P.split = split_option == 3 ? 4 : (split_option != 0 ? split_option : (waves <= kFourLanesMaxWaves ? 4 : (waves <= kTwoLanesMaxWaves ? 2 : 1)));
+  if (P.rolled && P.split == 4) P.split = 2;
   int n_d = 0;
   for (int s = 0; s < n_slots; ++s) {
     const int nd = P.N - P.der[s];

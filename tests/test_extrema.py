@@ -307,8 +307,8 @@ def test_gpu_extrema_argument_errors(ctx):
 
 @pytest.mark.gpu
 def test_gpu_shared_root_search_is_bit_identical(ctx):
-    """Two lanes per root search (a selectable variant: 3 % faster for 39 % more instructions) against one lane per search: the same bits,
-    for the extrema tables and for the time scaling built on them."""
+    """One, two and four lanes per root search (the default picks by launch size): the same bits, for the extrema tables and for
+    the time scaling built on them."""
     import torch
     import mav_trajectory_generation_amd as m
     n, k, dim, bsz = 10, 8, 3, 3000
@@ -319,8 +319,8 @@ def test_gpu_shared_root_search_is_bit_identical(ctx):
     ctx.sync()
     res = {}
     try:
-        for split in (1, 2):
-            ctx.set_option("extrema_split", split)      # (bits 0-1: lanes per search)
+        for split in (1, 2, 3, 0):
+            ctx.set_option("extrema_split", split)      # (bits 0-1: lanes per search: 1, 2, 3 = four; 0 = by launch size)
             seg_v, traj_v, idx_v = m.minmax_magnitude(ctx, co, t, 1)
             seg_a, traj_a, _ = m.minmax_magnitude(ctx, co, t, 2, dimensions=[0, 2])
             c2, t2 = co.clone(), t.clone()
@@ -329,6 +329,7 @@ def test_gpu_shared_root_search_is_bit_identical(ctx):
             res[split] = (seg_v, traj_v, idx_v, seg_a, traj_a, c2, t2, sc, within)
     finally:
         ctx.set_option("extrema_split", -1)
-    for a, b in zip(res[1], res[2]):
-        assert torch.equal(a, b)
+    for other in (2, 3, 0):
+        for a, b in zip(res[1], res[other]):
+            assert torch.equal(a, b), other
     plan.close()
