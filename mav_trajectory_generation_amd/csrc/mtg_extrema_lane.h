@@ -93,34 +93,43 @@ MTGX_HD double fast_rcp(double x) {
 #endif
 }
 
-// Two chains at once: a lane alone on its SIMD pays ~8 cycles per DEPENDENT FP64 operation and 4 per independent one, and the
+// Several chains at once: a lane alone on its SIMD pays ~8 cycles per DEPENDENT FP64 operation and 4 per independent one, and the
 // extrema kernels run at about one wave per SIMD at the sizes that matter (10k trajectories x 8 segments = 1250 waves) -- the
 // round-3 form (one Horner chain after the other) was bound by exactly that latency.
-template <int K>
-MTGX_HD void horner_pair(const double* a, double x0, double x1, double& f0, double& f1) {
-  f0 = a[K];
-  f1 = a[K];
+// NCH chains at once (MTGX_CHAINS); x / f / d are arrays with compile-time indices
+template <int K, int NCH>
+MTGX_HD void horner_multi(const double* a, const double (&x)[NCH], double (&f)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) f[c] = a[K];
 #pragma unroll
   for (int j = K - 1; j >= 0; --j) {
-    f0 = fma(f0, x0, a[j]);
-    f1 = fma(f1, x1, a[j]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) f[c] = fma(f[c], x[c], a[j]);
   }
 }
-template <int K>
-MTGX_HD void horner2_pair(const double* a, double x0, double x1, double& f0, double& d0, double& f1, double& d1) {
-  f0 = a[K]; f1 = a[K];
-  d0 = 0.0; d1 = 0.0;
+template <int K, int NCH>
+MTGX_HD void horner2_multi(const double* a, const double (&x)[NCH], double (&f)[NCH], double (&d)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { f[c] = a[K]; d[c] = 0.0; }
 #pragma unroll
   for (int j = K - 1; j >= 0; --j) {
-    d0 = fma(d0, x0, f0);
-    d1 = fma(d1, x1, f1);
-    f0 = fma(f0, x0, a[j]);
-    f1 = fma(f1, x1, a[j]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) d[c] = fma(d[c], x[c], f[c]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) f[c] = fma(f[c], x[c], a[j]);
   }
 }
+#ifndef MTGX_CHAINS
+// brackets a lane refines at once (and partition points it evaluates at once).  2: with value and derivative that is four
+// independent FMAs per Horner step -- the 4-cycle issue already covers the 8-cycle dependent latency.  4 measured 20 % SLOWER at
+// every launch size (round 5, profiles/r05_extrema_lanes_per_search.jsonl: 10k x 8 segments 237 vs 192 us): most levels have one
+// or two brackets per lane, the idle chains are pure instructions.
+#define MTGX_CHAINS 2
+#endif
+constexpr int kChains = MTGX_CHAINS;
 
-// Bisection-safeguarded Newton on TWO brackets at once (each: f of opposite sign at its ends, monotone inside); a bracket that
-// has converged keeps its x while the other one finishes.  Same step rule as the one-bracket form of round 3.
+// Bisection-safeguarded Newton on kChains brackets at once (each: f of opposite sign at its ends, monotone inside); a bracket that
+// has converged keeps its x while the others finish.  Same step rule as the one-bracket form of round 3.
 struct Bracket {
   double xl, xh, x, dx, dxold;
   bool done;
@@ -161,21 +170,27 @@ MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fn
   // the error it has -- those continue to kBisectTol, so that the next level's intervals stay monotone: ADVICE round 4)
   b.done = !live || fabs(dx) < (bisect ? fmin(tol, kBisectTol) : tol);
 }
-template <int K>
-MTGX_HD void bracketed_root_pair(const double* a, Bracket& b0, Bracket& b1, double tol, double fnoise) {
+template <int K, int NCH>
+MTGX_HD void bracketed_root_multi(const double* a, Bracket (&b)[NCH], double tol, double fnoise) {
 #if defined(MTGX_COUNT_ITERATIONS)
   const long long before = mtgx_iteration_count;
   struct Rec { long long b; ~Rec() { if (mtgx_trace_slot < 16) mtgx_trace[K][mtgx_trace_slot++] = (int)(mtgx_iteration_count - b); } } rec{before};
 #endif
   for (int it = 0; it < kRootMaxIter; ++it) {
-    double f0, d0, f1, d1;
-    horner2_pair<K>(a, b0.x, b1.x, f0, d0, f1, d1);
+    double x[NCH], f[NCH], d[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) x[c] = b[c].x;
+    horner2_multi<K, NCH>(a, x, f, d);
 #if defined(MTGX_COUNT_ITERATIONS)
     ++mtgx_iteration_count;
 #endif
-    bracket_step(b0, f0, d0, tol, fnoise);
-    bracket_step(b1, f1, d1, tol, fnoise);
-    if (b0.done && b1.done) break;
+    bool all_done = true;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      bracket_step(b[c], f[c], d[c], tol, fnoise);
+      all_done = all_done && b[c].done;
+    }
+    if (all_done) break;
   }
 }
 
@@ -217,50 +232,57 @@ struct Level {
     unsigned mask = 0;
     {
       double flo = a[0];   // value at 0
-      for (int i = 0; i <= cnt; i += 2) {
-        const double h0 = i < cnt ? roots[SRC + i] : 1.0;
-        const double h1 = i + 1 < cnt ? roots[SRC + i + 1] : 1.0;
-        double f0, f1;
-        horner_pair<KH>(a, h0, h1, f0, f1);
-        if ((flo < 0.0) != (f0 < 0.0)) mask |= 1u << i;
-        if (i + 1 <= cnt && (f0 < 0.0) != (f1 < 0.0)) mask |= 1u << (i + 1);
-        flo = f1;
+      for (int i = 0; i <= cnt; i += kChains) {
+        double h[kChains], f[kChains];
+#pragma unroll
+        for (int c = 0; c < kChains; ++c) h[c] = i + c < cnt ? roots[SRC + i + c] : 1.0;
+        horner_multi<KH, kChains>(a, h, f);
+#pragma unroll
+        for (int c = 0; c < kChains; ++c) {
+          if (i + c <= cnt && (flo < 0.0) != (f[c] < 0.0)) mask |= 1u << (i + c);
+          flo = f[c];
+        }
       }
     }
 #if defined(MTGX_COUNT_ITERATIONS)
     mtgx_trace_slot = 0;
 #endif
-    // The brackets are taken in GROUPS of 2 x nparts consecutive ranks: every lane of a shared search pops the same bits in the
-    // same iteration (uniform control flow -- the lanes are neighbours in one wavefront) and picks its own two, ranks
-    // part and part + nparts of the group; all of them then refine at once.
+    // The brackets are taken in GROUPS of kChains x nparts consecutive ranks: every lane of a shared search pops the same bits in
+    // the same iteration (uniform control flow -- the lanes are neighbours in one wavefront) and picks its own kChains, ranks
+    // part, part + nparts, ... of the group; all of them then refine at once.
     int rank = 0;
-    auto refine = [&](int ia, int ra, int ib, int rb, bool wa, bool wb) {
-      const double lo0 = ia > 0 ? roots[SRC + ia - 1] : 0.0, hi0 = ia < cnt ? roots[SRC + ia] : 1.0;
-      const double lo1 = ib > 0 ? roots[SRC + ib - 1] : 0.0, hi1 = ib < cnt ? roots[SRC + ib] : 1.0;
-      double fl0, fh0, fl1, fh1;
-      horner_pair<KH>(a, lo0, hi0, fl0, fh0);
-      horner_pair<KH>(a, lo1, hi1, fl1, fh1);
-      Bracket b0, b1;
-      bracket_init(b0, lo0, hi0, fl0, fh0);
-      bracket_init(b1, lo1, hi1, fl1, fh1);
-      bracketed_root_pair<KH>(a, b0, b1, tol, fnoise);
-      if (wa) roots[DST + ra] = b0.x;
-      if (wb) roots[DST + rb] = b1.x;
-    };
     while (mask != 0u) {
-      int idx[8], n_in_group = 0;
+      int idx[4 * kChains], n_in_group = 0;
       const int base = rank;
-      for (int u = 0; u < 2 * sh.nparts && u < 8 && mask != 0u; ++u) {
+      for (int u = 0; u < kChains * sh.nparts && u < 4 * kChains && mask != 0u; ++u) {
         idx[u] = __builtin_ctz(mask);
         mask &= mask - 1u;
         ++n_in_group;
         ++rank;
       }
       for (int part = sh.part_begin; part < sh.part_end; ++part) {
-        const bool wa = part < n_in_group, wb = part + sh.nparts < n_in_group;
-        // (a lane without a bracket of its own in this group runs along on the group's first one and writes nothing)
-        const int ua = wa ? part : 0, ub = wb ? part + sh.nparts : ua;
-        refine(idx[ua], base + ua, idx[ub], base + ub, wa, wb);
+        // (a chain without a bracket of its own in this group runs along on the lane's first one -- or the group's -- and writes nothing)
+        int u[kChains];
+        bool w[kChains];
+        double lo[kChains], hi[kChains], ends[2 * kChains], fe[2 * kChains];
+#pragma unroll
+        for (int c = 0; c < kChains; ++c) {
+          w[c] = part + c * sh.nparts < n_in_group;
+          u[c] = w[c] ? part + c * sh.nparts : (c > 0 ? u[0] : 0);
+          const int ia = idx[u[c]];
+          lo[c] = ia > 0 ? roots[SRC + ia - 1] : 0.0;
+          hi[c] = ia < cnt ? roots[SRC + ia] : 1.0;
+          ends[2 * c] = lo[c];
+          ends[2 * c + 1] = hi[c];
+        }
+        horner_multi<KH, 2 * kChains>(a, ends, fe);
+        Bracket b[kChains];
+#pragma unroll
+        for (int c = 0; c < kChains; ++c) bracket_init(b[c], lo[c], hi[c], fe[2 * c], fe[2 * c + 1]);
+        bracketed_root_multi<KH, kChains>(a, b, tol, fnoise);
+#pragma unroll
+        for (int c = 0; c < kChains; ++c)
+          if (w[c]) roots[DST + base + u[c]] = b[c].x;
       }
     }
     const int cnt_new = rank;
