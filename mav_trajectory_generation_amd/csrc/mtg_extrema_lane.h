@@ -149,11 +149,14 @@ MTGX_HD void bracket_init(Bracket& b, double lo, double hi, double flo, double f
 // a 7-fold root of g at the trajectory end -- is resolvable only to ~eps^(1/m); bisecting such a cluster down to `tol` cost ~45
 // rounds per bracket and level, and it was the slowest lane of every wave: 250 us per 10k x 8 segments in round 3).
 MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fnoise) {
-  // branch-free (selects only): the two brackets of a pair interleave, and a finished bracket costs no exec-mask detour
-  const bool live = !b.done && !(fabs(f) <= fnoise);
+  // branch-free (selects only): the brackets of a lane interleave, and a finished bracket costs no exec-mask detour.  Only x is
+  // guarded: once a bracket has stopped (`done` is sticky) its other fields are never looked at again, so they may drift --
+  // guarding all five cost 6 of the step's 16 v_cndmask, in a loop whose bookkeeping outweighs its Horner chains up to degree ~20
+  // (85 of the 98 + 4 K instructions of a level-K iteration of two brackets).
+  const bool stop = b.done || fabs(f) <= fnoise;
   const bool neg = f < 0.0;
-  const double xl = (live && neg) ? b.x : b.xl;
-  const double xh = (live && !neg) ? b.x : b.xh;
+  const double xl = neg ? b.x : b.xl;
+  const double xh = neg ? b.xh : b.x;
   const bool newton_leaves = ((b.x - xh) * df - f) * ((b.x - xl) * df - f) > 0.0;
   const bool newton_slow = fabs(2.0 * f) > fabs(b.dxold * df);
   const bool bisect = newton_leaves || newton_slow || !(df != 0.0);
@@ -163,12 +166,12 @@ MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fn
   const double x = bisect ? xl + dx_b : b.x - dx_n;
   b.xl = xl;
   b.xh = xh;
-  b.dxold = live ? b.dx : b.dxold;
-  b.dx = live ? dx : b.dx;
-  b.x = live ? x : b.x;
+  b.dxold = b.dx;
+  b.dx = dx;
+  b.x = stop ? b.x : x;
   // (a NEWTON step smaller than the loose partition tolerance leaves an error ~ its square; a bisection step of that size leaves
   // the error it has -- those continue to kBisectTol, so that the next level's intervals stay monotone: ADVICE round 4)
-  b.done = !live || fabs(dx) < (bisect ? fmin(tol, kBisectTol) : tol);
+  b.done = stop || fabs(dx) < (bisect ? fmin(tol, kBisectTol) : tol);
 }
 template <int K, int NCH>
 MTGX_HD void bracketed_root_multi(const double* a, Bracket (&b)[NCH], double tol, double fnoise) {
