@@ -109,10 +109,15 @@ MTGX_HD void horner_multi(const double* a, const double (&x)[NCH], double (&f)[N
 }
 template <int K, int NCH>
 MTGX_HD void horner2_multi(const double* a, const double (&x)[NCH], double (&f)[NCH], double (&d)[NCH]) {
+  // (the first derivative step of the textbook loop is fma(0, x, a[K]) = a[K]: written out, one FMA per chain and call less)
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) { f[c] = a[K]; d[c] = 0.0; }
+  for (int c = 0; c < NCH; ++c) { f[c] = a[K]; d[c] = K >= 1 ? a[K] : 0.0; }
+  if (K >= 1) {
 #pragma unroll
-  for (int j = K - 1; j >= 0; --j) {
+    for (int c = 0; c < NCH; ++c) f[c] = fma(f[c], x[c], a[K - 1]);
+  }
+#pragma unroll
+  for (int j = K - 2; j >= 0; --j) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) d[c] = fma(d[c], x[c], f[c]);
 #pragma unroll
