@@ -49,8 +49,7 @@ struct LdsRoots {
 // LDS column; lane `part` 0 writes the result.  Results do not depend on SPLIT (bit-identical by construction: a bracket's
 // refinement does not depend on which lane refines it; tests/test_extrema.py).
 template <int NMAX, int SPLIT, bool ROLLED>
-__global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void mtg_minmax_seg_body(const ExtremaParams& P, double* lds) {
   constexpr int COLS = kThreads / SPLIT;
   const long long total = P.B * P.K;
   const long long idx = ((long long)blockIdx.x * kThreads + threadIdx.x) / SPLIT;
@@ -67,6 +66,20 @@ __global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams 
   double* o = P.seg_out + ((long long)slot * total + idx) * 4;
   reinterpret_cast<double2*>(o)[0] = make_double2(mm.t_min, mm.v_min);
   reinterpret_cast<double2*>(o)[1] = make_double2(mm.t_max, mm.v_max);
+}
+
+// NMAX0 / NMAX1: compile-time bound on the derivative polynomial's coefficient count of derivative slot 0 / slot 1 (blockIdx.y).
+// The time-scaling path searches velocity and acceleration in one launch: with one bound for both, the acceleration slot walked
+// the velocity's two extra (identically zero) levels of the derivative chain.
+template <int NMAX0, int NMAX1, int SPLIT, bool ROLLED>
+__global__ __launch_bounds__(kThreads) void mtg_minmax_seg_kernel(ExtremaParams P) {
+  extern __shared__ double lds[];
+  if constexpr (NMAX1 == NMAX0) {
+    mtg_minmax_seg_body<NMAX0, SPLIT, ROLLED>(P, lds);
+  } else {
+    if (blockIdx.y == 0) mtg_minmax_seg_body<NMAX0, SPLIT, ROLLED>(P, lds);
+    else mtg_minmax_seg_body<NMAX1, SPLIT, ROLLED>(P, lds);
+  }
 }
 
 // Trajectory::computeMinMaxMagnitude's outer loop (trajectory.cpp:199-225): first segment with a strictly
@@ -168,14 +181,14 @@ __global__ void mtg_scale_finish_kernel(ScaleParams P) {
   }
 }
 
-template <int NMAX>
+template <int NMAX, int NMAX1 = NMAX>
 void launch_seg(const ExtremaParams& P, int n_slots, hipStream_t stream) {
   constexpr int L = 2 * NMAX - 2;
   const long long total = P.B * P.K;
   const dim3 grid((unsigned)((P.split * total + kThreads - 1) / kThreads), n_slots);
   const size_t lds = (size_t)(kThreads / P.split) * 2 * (L - 1) * sizeof(double);   // two root buffers per search (mtg_extrema_lane.h)
-#define MTG_XL(S, R) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, S, R>), grid, dim3(kThreads), lds, stream, P)
-  if (P.rolled) {   // (measurement knob: one or two lanes)
+#define MTG_XL(S, R) hipLaunchKernelGGL((mtg_minmax_seg_kernel<NMAX, R ? NMAX : NMAX1, S, R>), grid, dim3(kThreads), lds, stream, P)
+  if (P.rolled) {   // (measurement knob: one or two lanes, one bound for all slots)
     if (P.split == 2) MTG_XL(2, true); else MTG_XL(1, true);
   } else if (P.split == 4) MTG_XL(4, false);
   else if (P.split == 2) MTG_XL(2, false);
@@ -208,11 +221,13 @@ int launch_minmax(ExtremaParams& P, int n_slots, hipStream_t stream, int option)
     const int nd = P.N - P.der[s];
     if (nd > n_d) n_d = nd;
   }
+  // (velocity + acceleration of the time-scaling path: slot 1's polynomial is one coefficient shorter)
+  const bool shorter1 = n_slots == 2 && P.N - P.der[0] == n_d && P.N - P.der[1] == n_d - 1;
   if (n_d <= 7) launch_seg<7>(P, n_slots, stream);
-  else if (n_d <= 8) launch_seg<8>(P, n_slots, stream);
-  else if (n_d <= 9) launch_seg<9>(P, n_slots, stream);
-  else if (n_d <= 10) launch_seg<10>(P, n_slots, stream);
-  else if (n_d <= 11) launch_seg<11>(P, n_slots, stream);
+  else if (n_d <= 8) { if (shorter1) launch_seg<8, 7>(P, n_slots, stream); else launch_seg<8>(P, n_slots, stream); }
+  else if (n_d <= 9) { if (shorter1) launch_seg<9, 8>(P, n_slots, stream); else launch_seg<9>(P, n_slots, stream); }
+  else if (n_d <= 10) { if (shorter1) launch_seg<10, 9>(P, n_slots, stream); else launch_seg<10>(P, n_slots, stream); }
+  else if (n_d <= 11) { if (shorter1) launch_seg<11, 10>(P, n_slots, stream); else launch_seg<11>(P, n_slots, stream); }
   else launch_seg<12>(P, n_slots, stream);
   if (P.traj_out)
     hipLaunchKernelGGL(mtg_minmax_traj_kernel, dim3((unsigned)((P.B + 255) / 256), n_slots), dim3(256), 0, stream, P);
