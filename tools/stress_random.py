@@ -66,3 +66,15 @@ while time.time() - t0 < budget:
     plan.close()
     cases += 1
 print("cases", cases, {k_: float("%.2e" % v) for k_, v in worst.items()})
+# the worst solve case, arbitrated: its worst trajectory against the 50-digit solution (oracle/oracle_mp.py)
+if os.path.exists("gpurun_out/stress_worst.npz"):
+    from oracle import oracle_mp
+    w = np.load("gpurun_out/stress_worst.npz")
+    hip, ref = w["hip"], w["ref"]
+    num = np.abs(hip - ref).max(axis=-1); den = np.maximum(np.abs(ref).max(axis=-1), 1e-300)
+    b = int(np.unravel_index(np.argmax(num / den), num.shape)[0])
+    exact = np.array(oracle_mp.solve(int(w["n"]), int(w["d"]), [int(x) for x in w["masks"]], w["times"][b], w["d_fixed"][b])[0], dtype=float)
+    exact = exact.reshape(hip[b].shape)
+    print("worst solve case: N %d K %d D %d masks %s batch %d, trajectory %d: HIP vs reference %.2e, HIP vs 50-digit %.2e, reference vs 50-digit %.2e"
+          % (int(w["n"]), hip.shape[1], hip.shape[2], [int(x) for x in w["masks"]], hip.shape[0], b,
+             helpers.poly_relerr(hip[b:b + 1], ref[b:b + 1]), helpers.poly_relerr(hip[b:b + 1], exact[None]), helpers.poly_relerr(ref[b:b + 1], exact[None])))
