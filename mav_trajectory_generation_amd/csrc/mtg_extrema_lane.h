@@ -164,7 +164,9 @@ MTGX_HD void bracket_step(Bracket& b, double f, double df, double tol, double fn
   const double xh = neg ? b.xh : b.x;
   const bool newton_leaves = ((b.x - xh) * df - f) * ((b.x - xl) * df - f) > 0.0;
   const bool newton_slow = fabs(2.0 * f) > fabs(b.dxold * df);
-  const bool bisect = newton_leaves || newton_slow || !(df != 0.0);
+  // (df == 0 needs no test of its own: then newton_leaves is f * f > 0, and newton_slow is |2 f| > 0 should f * f underflow;
+  // f == 0 has stopped the bracket above)
+  const bool bisect = newton_leaves || newton_slow;
   const double dx_b = 0.5 * (xh - xl);
   const double dx_n = f * fast_rcp(df);
   const double dx = bisect ? dx_b : dx_n;
