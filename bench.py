@@ -433,7 +433,7 @@ class MixedLoop:
             for i in range(steps):
                 self.reqs[(first + i) % n].solve()
         else:
-            req.solve()
+            req.solve(ordered=False)   # (events are recorded on ctx.stream around the call; the bench syncs explicitly)
         if stop_event is not None:
             stop_event.record(stream)
 

@@ -462,8 +462,17 @@ class PackedMultiSolve:
         self.launch_count = self.lib.mtg_multi_launch_count(h)
         ctx._plans.add(self)
 
-    def solve(self):
-        _check(self.lib, self.lib.mtg_multi_solve(self.handle), self.ctx.handle)
+    def solve(self, ordered: bool = True):
+        """Enqueue the request on the context's stream (asynchronous).  ordered: the library's stream waits for torch's current
+        stream before the launch and torch's current stream for the launch afterwards, as every other wrapper does
+        (ordered=False: the caller orders the streams itself -- bench.py records its events on ctx.stream and syncs)."""
+        cur = self.ctx._enter() if ordered else None
+        try:
+            rc = self.lib.mtg_multi_solve(self.handle)
+        finally:
+            if ordered:
+                self.ctx._leave(cur)
+        _check(self.lib, rc, self.ctx.handle)
 
     def close(self):
         if getattr(self, "handle", None):

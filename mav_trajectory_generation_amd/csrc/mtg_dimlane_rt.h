@@ -46,7 +46,7 @@ struct MtgRtStore {
   __device__ __forceinline__ mtg_lds_double* lds_ptr(int j) const {
     return (mtg_lds_double*)(size_t)(lds_col + (unsigned)(j - (nh - L)) * (unsigned)mtg_rt_step_bytes<C>());
   }
-  __device__ __forceinline__ double* ws_ptr(int j) const { return wsl + (long long)(j - 1) * C::WSE * ws_stride; }
+  __device__ __forceinline__ mtg_glb_double* ws_ptr(int j) const { return mtg_glb(wsl + (long long)(j - 1) * C::WSE * ws_stride); }   // (global address space: see mtg_glb)
 };
 
 // The trajectory index with an opaque zero added that "depends" on `dep`: a load addressed through it cannot be issued before
@@ -185,7 +185,7 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
   auto request_head = [&](int j) {     // j < nh: a head step (rows in LDS / workspace) or step 0 (no rows)
     if (j >= 1) {
       if (st.in_lds(j)) mtg_ws_load_shared<C>(st.lds_ptr(j), 64, st.share, Gw, gw, C::MI, C::MI);
-      else mtg_ws_load_shared<C>((const double*)st.ws_ptr(j), st.ws_stride, st.share, Gw, gw, C::MI, C::MI);
+      else mtg_ws_load_shared<C>((const mtg_glb_double*)st.ws_ptr(j), st.ws_stride, st.share, Gw, gw, C::MI, C::MI);
     }
     request_inputs(j);
   };

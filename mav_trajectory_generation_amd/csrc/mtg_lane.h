@@ -201,6 +201,22 @@ MTG_HD void mtg_store2(double* p, double a, double b) {
 #endif
 }
 
+// Workspace pointers as GLOBAL-address-space pointers.  The kernels re-define their workspace column pointer opaquely per tile (an
+// empty asm, so that the per-step addresses are not hoisted and spilled); a pointer that went through an asm has lost its address
+// space, and every workspace access came out as flat_load / flat_store.  A FLAT access may hit LDS or memory, which return out of
+// order: the compiler has to wait for it with vmcnt(0) lgkmcnt(0) -- i.e. each backward step waited for the acknowledgement of the
+// coefficient stores issued AFTER its workspace loads (found in round 6: the N = 12 / K = 32 kernel had 20 such waits per tile and
+// direction).  As global_load / global_store the waits are counted (vmcnt(n): only what was issued before the loads).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MTG_WS_FLAT)   // (MTG_WS_FLAT: the A/B build of tools/gpu_r06_variants.sh)
+typedef __attribute__((address_space(1))) double mtg_glb_double;
+__device__ __forceinline__ mtg_glb_double* mtg_glb(double* p) { return (mtg_glb_double*)p; }
+__device__ __forceinline__ const mtg_glb_double* mtg_glb(const double* p) { return (const mtg_glb_double*)p; }
+#else
+typedef double mtg_glb_double;
+MTG_HD double* mtg_glb(double* p) { return p; }
+MTG_HD const double* mtg_glb(const double* p) { return p; }
+#endif
+
 MTG_HD int mtg_popc(int x) {
 #if defined(__HIPCC__)
   return __builtin_popcount(x);
@@ -250,13 +266,21 @@ MTG_HD double mtg_rcp(double x) {
 // Table bases.  Static mode: compile-time offset => every entry folds to an immediate (no SGPR
 // pressure, trivially rematerialisable).  Generic mode: runtime offset, laundered (see above).
 template <class C> MTG_HD const double* mtg_h1(const MtgParams& P) {
+#if defined(MTG_TABLE_SLOAD)
+  if constexpr (C::kCT) return kH1 + mtg_launder(C::H1OFF); else return kH1 + mtg_launder(P.h1off);
+#else
   if constexpr (C::kCT) return kH1 + C::H1OFF; else return kH1 + mtg_launder(P.h1off);
+#endif
 }
 template <class C> MTG_HD const double* mtg_q1(const MtgParams& P) {
   if constexpr (C::kCT) return kQ1 + C::H1OFF; else return kQ1 + mtg_launder(P.h1off);
 }
 template <class C> MTG_HD const double* mtg_ainv(const MtgParams& P) {
+#if defined(MTG_TABLE_SLOAD)
+  if constexpr (C::kCT) return kAinvLo + mtg_launder(C::AINVOFF); else return kAinvLo + mtg_launder(P.ainvoff);
+#else
   if constexpr (C::kCT) return kAinvLo + C::AINVOFF; else return kAinvLo + mtg_launder(P.ainvoff);
+#endif
 }
 template <class C> MTG_HD int mtg_deriv(const MtgParams& P) {
   if constexpr (C::kCT) return C::DV; else return P.deriv;
@@ -1156,8 +1180,8 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
 // only free x free entries of G and free entries of g exist; they are packed in traversal order and addressed by
 // walking a pointer (one 64-bit add per element) -- indexed addressing made the compiler keep ~40 hoisted
 // 64-bit slot offsets live across the chain loop (450-900 SGPR spills in the rolled kernels).
-template <class C>
-MTG_HD void mtg_ws_store(double* w, long long stride, const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
+template <class C, class PTR>
+MTG_HD void mtg_ws_store(PTR w, long long stride, const double (&G)[C::H][C::H], const double (&g)[C::D][C::H],
                          int ml, int mr) {
   constexpr int H = C::H, D = C::D;
 #pragma unroll
@@ -1176,8 +1200,8 @@ MTG_HD void mtg_ws_store(double* w, long long stride, const double (&G)[C::H][C:
     }
   }
 }
-template <class C>
-MTG_HD void mtg_ws_load(const double* w, long long stride, double (&G)[C::H][C::H], double (&g)[C::D][C::H], int ml,
+template <class C, class PTR>
+MTG_HD void mtg_ws_load(PTR w, long long stride, double (&G)[C::H][C::H], double (&g)[C::D][C::H], int ml,
                         int mr) {
   constexpr int H = C::H, D = C::D;
 #pragma unroll
@@ -1430,10 +1454,10 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
             mtg_ws_store_shared<C>(mtg_lds_step<C>(P, j), 64, P.dim0, G, g, ml, mr);
 #endif
           } else {
-            mtg_ws_store_shared<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, P.dim0, G, g, ml, mr);
+            mtg_ws_store_shared<C>(mtg_glb(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, P.dim0, G, g, ml, mr);
           }
         } else {
-          mtg_ws_store<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, G, g, ml, mr);
+          mtg_ws_store<C>(mtg_glb(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, G, g, ml, mr);
         }
       } else if constexpr (C::kRegShared) {
         constexpr int JR0 = C::WSJ;
@@ -1469,7 +1493,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
         mtg_load_vals<C, DIR>(P, b, mtg_vr<DIR>(K, jn), C::MI, ln, fn);
         if (j == 0) mtg_fwd_step_core<C, DIR>(P, M0, C::MI, ln, T_cur, fl, fr, G, g);
         else mtg_fwd_step_core<C, DIR>(P, C::MI, C::MI, ln, T_cur, fl, fr, G, g);
-        mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, j == 0 ? M0 : C::MI,
+        mtg_ws_store<C>(mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride), P.ws_stride, G, g, j == 0 ? M0 : C::MI,
                         C::MI);
         T_cur = T_nxt;
 #pragma unroll
@@ -1487,7 +1511,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
         const int ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j));
         const int mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
-        mtg_ws_store<C>(wsl + (long long)j * (H * H + D * H) * P.ws_stride, P.ws_stride, G, g, ml, mr);
+        mtg_ws_store<C>(mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride), P.ws_stride, G, g, ml, mr);
       }
     }
   }
@@ -1573,11 +1597,11 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
                                 mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
 #endif
         } else {
-          mtg_ws_load_shared<C>((const double*)(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, P.ws_share, Gw, gw,
+          mtg_ws_load_shared<C>(mtg_glb(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, P.ws_share, Gw, gw,
                                 mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
         }
       } else
-        mtg_ws_load<C>(wsl + (long long)j * C::WSE * P.ws_stride, P.ws_stride, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
+        mtg_ws_load<C>(mtg_glb(wsl + (long long)j * C::WSE * P.ws_stride), P.ws_stride, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
                        mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
     };
     if ((C::WSJ > 0 && KC <= C::WSJ) || C::kRegShared) request(KC - 1);
@@ -1626,7 +1650,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       double G[H][H], g[D][H], fl[D][H];
       double T_cur = 0.0;
       auto request = [&](int j) {
-        const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
+        const auto w = mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride);
         if (j == 0) {
           mtg_ws_load<C>(w, P.ws_stride, G, g, M0, C::MI);
           mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, j), M0, ln, fl);
@@ -1648,7 +1672,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
     } else {
       for (int j = kc - 1; j >= 0; --j) {
         double G[H][H], g[D][H];
-        const double* w = wsl + (long long)j * (H * H + D * H) * P.ws_stride;
+        const auto w = mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride);
         const int ml = mtg_mask<C>(P, mtg_vl<DIR>(K, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(K, j));
         mtg_ws_load<C>(w, P.ws_stride, G, g, ml, mr);
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, G, g, xr, io, active);

@@ -147,8 +147,10 @@ class Communicator:
         if gathered is None:
             gathered = torch.empty((self.world,) + tuple(local.shape), dtype=torch.float64, device=local.device)
         cur = self.ctx._enter()
-        rc = self.lib.mtg_comm_all_gather(self.handle, ctypes.c_void_p(local.data_ptr()), local.numel(), ctypes.c_void_p(gathered.data_ptr()))
-        self.ctx._leave(cur)
+        try:
+            rc = self.lib.mtg_comm_all_gather(self.handle, ctypes.c_void_p(local.data_ptr()), local.numel(), ctypes.c_void_p(gathered.data_ptr()))
+        finally:
+            self.ctx._leave(cur)
         self._check(rc)
         return gathered
 
@@ -166,10 +168,12 @@ class Communicator:
             gathered = torch.empty((n_chunks, self.world, batch // n_chunks, plan.K, plan.D, plan.N), dtype=torch.float64, device=times.device)
         lay = plan.layout(batch, layout)
         cur = self.ctx._enter()
-        rc = self.lib.mtg_comm_solve_all_gather(self.handle, plan.handle, batch, ctypes.byref(lay), ctypes.c_void_p(times.data_ptr()),
-                                                ctypes.c_void_p(d_fixed.data_ptr()), ctypes.c_void_p(local.data_ptr()),
-                                                ctypes.c_void_p(gathered.data_ptr()), n_chunks, 0)
-        self.ctx._leave(cur)
+        try:
+            rc = self.lib.mtg_comm_solve_all_gather(self.handle, plan.handle, batch, ctypes.byref(lay), ctypes.c_void_p(times.data_ptr()),
+                                                    ctypes.c_void_p(d_fixed.data_ptr()), ctypes.c_void_p(local.data_ptr()),
+                                                    ctypes.c_void_p(gathered.data_ptr()), n_chunks, 0)
+        finally:
+            self.ctx._leave(cur)
         self._check(rc)
         return local, gathered
 
