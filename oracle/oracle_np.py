@@ -455,6 +455,36 @@ def solve_batch(n_coeffs: int, derivative: int, fixed_mask: Sequence[int],
     return coeffs, d_free, cost
 
 
+# --------------------------------------------------------------------------- Mellinger time gradient (next-step row N2)
+K_OPTIMIZATION_TIME_LOWER_BOUND = 0.1    # polynomial_optimization_nonlinear.h: kOptimizationTimeLowerBound
+
+
+def mellinger_cost_gradient(n_coeffs: int, derivative: int, fixed_mask: Sequence[int], times: np.ndarray, d_fixed: np.ndarray):
+    """PolynomialOptimizationNonLinear<N>::getCostAndGradientMellinger (impl/polynomial_optimization_nonlinear_impl.h:287-364),
+    literally: J_d of the given times, and per segment n the forward difference (J_d(T + h e_n - h/(m-1) sum_{i != n} e_i) - J_d) / h
+    with h = 0.1 (:311), every perturbed time clamped from below by kOptimizationTimeLowerBound (:338-340); one segment: zero
+    gradient (:295-302).  Pinned on the reference's own member run in this container (tests/golden/reference_mellinger.npz,
+    tests/test_reference_build.py).  times [B][K], d_fixed [B][D][n_fixed] -> (cost [B], gradient [B][K])."""
+    times = np.asarray(times, dtype=np.float64)
+    bsz, k = times.shape
+    cost, grad = np.zeros(bsz), np.zeros((bsz, k))
+    for b in range(bsz):
+        def cost_of(tt):
+            return solve_batch(n_coeffs, derivative, fixed_mask, tt[None], d_fixed[b][None])[2][0]
+        cost[b] = cost_of(times[b])
+        if k == 1:
+            continue
+        increment_time = 0.1
+        corr = increment_time / (k - 1.0)
+        for s in range(k):
+            bigger = times[b].copy()
+            for i in range(k):
+                bigger[i] += increment_time if i == s else -corr
+            bigger = np.maximum(K_OPTIMIZATION_TIME_LOWER_BOUND, bigger)
+            grad[b, s] = (cost_of(bigger) - cost[b]) / increment_time
+    return cost, grad
+
+
 # --------------------------------------------------------------------------- sampling (next-step row N3)
 def polynomial_evaluate(coeffs: np.ndarray, t: float, derivative: int) -> float:
     """polynomial.h:137-149: Horner on base_coefficients_(derivative, j) * c_j, highest power first."""

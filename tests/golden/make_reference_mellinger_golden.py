@@ -28,7 +28,7 @@ CASES = [  # name, n, d, k, dim, masks, bsz, seed, clamp tweaks
     ("config5_k16_d4", 10, 4, 16, 4, [31] + [7] * 15 + [31], 6, 424242, True),
     ("jerk_k4", 8, 3, 4, 3, None, 6, 424242, True),
     ("one_segment", 10, 4, 1, 3, None, 4, 424242, True),
-    ("n12_k8", 12, 5, 8, 3, None, 6, 424242, True),
+    ("n12_k8", 12, 5, 8, 3, None, 6, 424242, False),   # (no clamp tweak: an N = 12 chain with a 0.05 s segment is beyond float64 on every side)
 ]
 
 

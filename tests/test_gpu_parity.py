@@ -494,10 +494,50 @@ def test_update_from_free_whole_sector_output(ctx, n, d, k, dim, interior, bsz, 
     ctx2.close()
 
 
+MEL = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_mellinger.npz"))
+MEL_NAMES = sorted({k.split("/")[0] for k in MEL.files})
+# Gradient tolerance against the reference's own member, relative to each trajectory's largest gradient component: the
+# gradient is a forward difference (J(T') - J(T)) / 0.1 of two costs that each agree with the reference's to ~1e-10.
+MEL_TOL = 1e-9
+
+
+def mel_err(got, ref):
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-300)
+    return float((np.abs(got - ref) / scale).max())
+
+
+@pytest.mark.parametrize("name", MEL_NAMES)
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_mellinger_entry_vs_the_references_own_member(ctx, name, layout):
+    """mtg_mellinger_cost_gradient against the outputs of the reference's OWN
+    PolynomialOptimizationNonLinear<N>::getCostAndGradientMellinger (NL:287-364) compiled and run in the build container
+    (oracle/ref_nonlinear_wrap.cpp; tests/golden/make_reference_mellinger_golden.py), incl. the lower clamp (NL:338-340), one
+    segment (NL:295-302), ragged masks, config 5's shape and N = 12."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    n, d = int(MEL[f"{name}/n"]), int(MEL[f"{name}/d"])
+    masks = [int(x) for x in MEL[f"{name}/masks"]]
+    times, d_fixed = MEL[f"{name}/times"], MEL[f"{name}/d_fixed"]
+    dim, k = d_fixed.shape[1], times.shape[1]
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = torch.from_numpy(times).cuda(), torch.from_numpy(d_fixed).cuda()
+    if layout == "soa":
+        t, f = t.t().contiguous(), f.permute(1, 2, 0).contiguous()
+    j0, grad = m.mellinger_cost_and_gradient(plan, t, f, layout=layout)
+    ctx.sync()
+    got = grad.cpu().numpy() if layout == "aos" else grad.t().cpu().numpy()
+    tol = MEL_TOL if n <= 10 else 5e-8          # N = 12: the reference's own float64 evaluation (tol_for of test_gpu_vs_reference.py)
+    assert np.abs(j0.cpu().numpy() / MEL[f"{name}/cost_ref"] - 1).max() < tol
+    assert mel_err(got, MEL[f"{name}/grad_ref"]) <= (10 * tol if n > 10 else tol)
+    if k == 1:
+        assert np.all(got == 0.0)
+    plan.close()
+
+
 def test_cost_only_and_mellinger_gradient(ctx):
     """MTG_FLAG_COST_ONLY and the batched Mellinger cost/gradient step (K+1 perturbed-time solves per trajectory in
-    one launch) against a literal restatement of getCostAndGradientMellinger
-    (polynomial_optimization_nonlinear_impl.h:287-364) on the oracle."""
+    one launch) against the REFERENCE's own getCostAndGradientMellinger (polynomial_optimization_nonlinear_impl.h:287-364;
+    tests/golden/reference_mellinger.npz) and its restatement on the oracle."""
     import torch
     import mav_trajectory_generation_amd as m
     bsz, k = 12, 8
@@ -510,21 +550,14 @@ def test_cost_only_and_mellinger_gradient(ctx):
     ctx.sync()
     assert torch.allclose(cost_only, cost_full, rtol=1e-12)
     assert torch.allclose(j0, cost_full, rtol=1e-12)
-    # oracle: the reference's loop, one trajectory at a time
-    want = np.zeros((bsz, k))
-    for b in range(bsz):
-        def cost_of(tt):
-            _, _, j = onp.solve_batch(10, 4, masks, tt[None], d_fixed[b][None])
-            return j[0]
-        jd = cost_of(times[b])
-        for n in range(k):
-            tb = times[b].copy()
-            for i in range(k):
-                tb[i] += 0.1 if i == n else -0.1 / (k - 1.0)
-            tb = np.maximum(0.1, tb)
-            want[b, n] = (cost_of(tb) - jd) / 0.1
+    # the restatement of the reference's loop (pinned on the reference's own member: tests/test_reference_build.py) ...
+    _, want = onp.mellinger_cost_gradient(10, 4, masks, times, d_fixed)
     got = grad.cpu().numpy()
-    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    assert np.abs(got - want).max() <= MEL_TOL * np.abs(want).max()
+    # ... and the reference's own getCostAndGradientMellinger run in the build container on these inputs (fixture snap_k8_d3)
+    assert np.array_equal(MEL["snap_k8_d3/times"], times) and np.array_equal(MEL["snap_k8_d3/d_fixed"], d_fixed)
+    assert np.abs(j0.cpu().numpy() / MEL["snap_k8_d3/cost_ref"] - 1).max() < 1e-9
+    assert mel_err(got, MEL["snap_k8_d3/grad_ref"]) <= MEL_TOL
     plan.close()
 
 
@@ -571,8 +604,9 @@ def test_batched_sampling_vs_oracle(ctx):
     (10, 4, 1, 3, None, 4, "aos"),                               # one segment: zero gradient (impl:295-302)
 ])
 def test_mellinger_cost_gradient_entry(ctx, n, d, k, dim, masks, bsz, layout):
-    """mtg_mellinger_cost_gradient (C ABI; perturbed times formed inside the kernel) against a literal restatement of
-    getCostAndGradientMellinger (polynomial_optimization_nonlinear_impl.h:287-364) on the oracle, incl. the lower clamp."""
+    """mtg_mellinger_cost_gradient (C ABI; perturbed times formed inside the kernel) against the restatement of
+    getCostAndGradientMellinger (polynomial_optimization_nonlinear_impl.h:287-364; pinned on the reference's own member in
+    tests/test_reference_build.py) on the oracle, incl. the lower clamp."""
     import torch
     import mav_trajectory_generation_amd as m
     masks, times, d_fixed = helpers.reference_batch(bsz, k, n, dim, 424242, masks)
@@ -587,23 +621,9 @@ def test_mellinger_cost_gradient_entry(ctx, n, d, k, dim, masks, bsz, layout):
     ctx.sync()
     got = grad.cpu().numpy() if layout == "aos" else grad.t().cpu().numpy()
     nchk = min(bsz, 6)
-    want = np.zeros((nchk, k))
-    jd = np.zeros(nchk)
-    for b in range(nchk):
-        def cost_of(tt):
-            _, _, j = onp.solve_batch(n, d, masks, tt[None], d_fixed[b][None])
-            return j[0]
-        jd[b] = cost_of(times[b])
-        if k == 1:
-            continue
-        for s in range(k):
-            tb = times[b].copy()
-            for i in range(k):
-                tb[i] += 0.1 if i == s else -0.1 / (k - 1.0)
-            want[b, s] = (cost_of(np.maximum(0.1, tb)) - jd[b]) / 0.1
+    jd, want = onp.mellinger_cost_gradient(n, d, masks, times[:nchk], d_fixed[:nchk])
     assert np.allclose(j0.cpu().numpy()[:nchk], jd, rtol=1e-8)
-    scale = max(np.abs(want).max(), 1e-300)
-    assert np.abs(got[:nchk] - want).max() <= 1e-6 * scale
+    assert mel_err(got[:nchk], want) <= MEL_TOL
     if k == 1:
         assert np.all(got == 0.0)
     plan.close()

@@ -280,3 +280,40 @@ def test_real_eigen_build_vs_stand_in(name):
     assert np.allclose(cost, REF[f"{name}/cost_ref"], rtol=1e-8)
     if name == "two_vertices":
         assert np.abs(co[0, 0, 0] - GOLD["two_vertices/matlab_coeffs"]).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ row N2: the Mellinger step
+MEL = np.load(os.path.join(HERE, "golden", "reference_mellinger.npz"))
+MEL_NAMES = sorted({k.split("/")[0] for k in MEL.files})
+live_nl = pytest.mark.skipif(not ref_linear.nonlinear_available(), reason="oracle/_ref/libmtg_ref_nl.so not built (needs /root/reference)")
+
+
+def mel_inputs(name):
+    return (int(MEL[f"{name}/n"]), int(MEL[f"{name}/d"]), [int(m) for m in MEL[f"{name}/masks"]], MEL[f"{name}/times"],
+            MEL[f"{name}/d_fixed"])
+
+
+@pytest.mark.parametrize("name", MEL_NAMES)
+def test_mellinger_restatement_vs_reference_member(name):
+    """oracle_np.mellinger_cost_gradient against the outputs of the reference's OWN getCostAndGradientMellinger (NL:287-364) run
+    in the build container (tests/golden/make_reference_mellinger_golden.py): cost 1e-9, gradient 1e-9 of its scale -- the two
+    evaluate the same float64 formulas; a forward difference of costs that agree to round-off x cond divided by h = 0.1."""
+    n, d, masks, times, d_fixed = mel_inputs(name)
+    nchk = min(len(times), 3)
+    cost, grad = onp.mellinger_cost_gradient(n, d, masks, times[:nchk], d_fixed[:nchk])
+    ref_cost, ref_grad = MEL[f"{name}/cost_ref"][:nchk], MEL[f"{name}/grad_ref"][:nchk]
+    tol = 1e-9 if n <= 10 else 5e-8
+    assert np.abs(cost / ref_cost - 1).max() < tol
+    # per trajectory: gradients of trajectories in one batch differ by orders of magnitude (a clamped 0.05 s segment)
+    scale = np.maximum(np.abs(ref_grad).max(axis=1, keepdims=True), 1e-300)
+    assert (np.abs(grad - ref_grad) / scale).max() < 10 * tol
+    if times.shape[1] == 1:
+        assert np.all(ref_grad == 0.0) and np.all(grad == 0.0)
+
+
+@live_nl
+@pytest.mark.parametrize("name", MEL_NAMES)
+def test_committed_mellinger_fixture_is_what_the_library_produces(name):
+    n, d, masks, times, d_fixed = mel_inputs(name)
+    cost, grad = ref_linear.mellinger_cost_gradient(n, d, masks, times, d_fixed)
+    assert np.array_equal(cost, MEL[f"{name}/cost_ref"]) and np.array_equal(grad, MEL[f"{name}/grad_ref"])
