@@ -51,6 +51,9 @@ CONFIGS = {
 }
 
 
+WATCHDOG = {"hard_exit": False}   # set when a watchdog thread is stuck inside a collective init: leave through os._exit
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,8 +73,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the solve + all_gather measurement")
     ap.add_argument("--gather-chunks", type=int, default=4)
-    ap.add_argument("--gather-via-mtg-comm", action="store_true", help="N > 1, nccl: also measure the chunked solve + gather through "
-                    "the C ABI's own RCCL communicator (mtg_comm_*); always done on a one-rank group")
+    ap.add_argument("--gather-via-mtg-comm", action="store_true", help="(default since round 6; kept for old command lines)")
+    ap.add_argument("--no-gather-via-mtg-comm", action="store_true", help="nccl: do NOT measure the chunked solve + gather through the "
+                    "C ABI's own RCCL communicator (mtg_comm_*, north_star's gather).  Default: measured at every N, its "
+                    "ncclCommInitRank on a watchdog thread (--mtg-comm-init-timeout); a rank that cannot join in time makes ALL "
+                    "ranks fall back to the torch.distributed figure, and the line says so")
+    ap.add_argument("--mtg-comm-init-timeout", type=float, default=90.0, help="seconds the watchdog waits for ncclCommInitRank")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0, help="length of the `sustained` run: continuous queue launches "
+                    "over the HBM-sized rotation with the shader clock probed next to them (0: skip)")
     ap.add_argument("--exercise-collectives", action="store_true",
                     help="run every collective branch of the N > 1 path on a ONE-rank group (RCCL on a 1-GPU box: init, "
                          "all_reduce, all_gather, barrier, the chunked solve + all_gather_into_tensor); extra.collectives_exercised")
@@ -725,6 +734,71 @@ def main():
             assert torch.isfinite(co).all()
 
         extra, fill_us, peer = {}, None, None
+        # ---- `sustained` (round 6, first-class field): the same queue launches, continuously for >= --sustained-seconds over the
+        # same HBM-sized rotation (calls of up to 96 batches, enqueued back to back: no host gap), every rank at once; the shader
+        # clock is probed next to them by a one-wave kernel on its own stream (s_memtime against the 100 MHz s_memrealtime:
+        # include/mtg_hip_lab.h) -- the FP64-heavy kernels run power-limited, which a 90-us burst after a 50-ms settle does not show
+        sustained = None
+        if args.sustained_seconds > 0 and not args.no_extras and not per_batch:
+            chunk = min(96, nsets) if not mixed else min(16, nsets)
+            est_us = max(step_us, 0.5) * chunk
+            calls = max(8, int(args.sustained_seconds * 1e6 / est_us) + 1)
+            loop.prepare(chunk, 0)
+            loop.run(chunk)
+            barrier()
+            probe = None
+            try:
+                probe = ctx.clock_probe_start(min(0.6 * args.sustained_seconds * 1e6, 0.6 * est_us * calls))
+            except Exception:   # noqa: BLE001  (the probe is evidence, not part of the measurement)
+                probe = None
+            t0 = time.perf_counter()
+            e0.record(ctx.stream)
+            for _ in range(calls):
+                loop.run(chunk)
+            e1.record(ctx.stream)
+            finish()
+            wall_s = time.perf_counter() - t0
+            dev_us = e0.elapsed_time(e1) * 1e3 / (calls * chunk)
+            mhz = None
+            if probe is not None:
+                try:
+                    mhz, _ = ctx.clock_probe_finish(probe)
+                except Exception:   # noqa: BLE001
+                    mhz = None
+            if grouped:
+                w = torch.tensor([wall_s, dev_us], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                wall_s, dev_us = float(w[0].item()), float(w[1].item())
+            sustained = {"value": world * traj_per_step * calls * chunk / wall_s, "unit": "trajectories/s", "seconds": wall_s,
+                         "steps": calls * chunk, "calls": calls, "batches_per_call": chunk, "buffer_sets": nsets,
+                         "device_us_per_step": dev_us, "roofline_frac": bytes_per_step / dev_us * 1e-3 / HBM_PEAK_GBS,
+                         "shader_clock_mhz": mhz,
+                         "is": "the queue form run continuously (calls enqueued back to back, max over ranks) over the same rotation as "
+                               "`value`; shader clock = s_memtime / s_memrealtime of a one-wave probe kernel running next to it (this rank)"}
+            ctx.sync()
+        # ---- the queue form on AoS inputs (times[B][K], d_fixed[B][D][n_fixed]: the order a reference-side caller's Vertex::Vector
+        # packs into), same protocol as value_other_form: W warm-up + K timed steps, wall clock
+        aos_peer = None
+        if rank == 0 and not args.no_extras and not mixed and args.layout != "aos":
+            try:
+                aos_sets = []
+                for (t_, f_, co_) in sets:
+                    ta = t_[:, :B].t().contiguous()
+                    fa = f_[:, :, :B].permute(2, 0, 1).contiguous()
+                    aos_sets.append((ta, fa, co_))
+                aos_loop = SolveLoop(plan, aos_sets, "aos", args.dims, per_batch)
+                aos_loop.run(len(aos_sets))
+                torch.cuda.synchronize()
+                us, wall = side_run(aos_loop, args.steps, warm=args.warmup)
+                aos_peer = {"value": world * traj_per_step * args.steps / wall, "unit": "trajectories/s", "device_us_per_step": us,
+                            "roofline_frac": bytes_per_step / us * 1e-3 / HBM_PEAK_GBS, "steps": args.steps, "warmup": args.warmup,
+                            "input_layout": "aos", "launch_form": plan.launch_form(B, "aos"),
+                            "is": "the same steps with AoS inputs (times [B][K], d_fixed [B][D][n_fixed] -- the reference's natural order), "
+                                  "same output buffers, this rank's clock"}
+                ctx.sync()
+                del aos_loop, aos_sets
+            except Exception as e:   # noqa: BLE001
+                aos_peer = {"error": repr(e)[:300]}
         if args.timed_repeats > 0:
             reps_ = []
             for _ in range(args.timed_repeats):
@@ -869,17 +943,41 @@ def main():
             gather = {"chunks": runner.n_chunks, "own_slice_matches_local_solve": own_slice_ok, "solve_plus_gather_ms": both * 1e3, "solve_only_ms": solve_only * 1e3,
                       "gather_only_ms": gather_only * 1e3,
                       "gathered_bytes_per_rank": world * B * K * D * N * 8, "backend": args.backend}
-            if args.backend == "nccl" and (world == 1 or args.gather_via_mtg_comm):
-                # (default at world == 1 only: a second communicator's ncclCommInitRank is a collective -- a rank that failed
-                # before it would leave the others waiting, and the driver's multi-GPU run must not hang on an extra;
-                # --gather-via-mtg-comm turns it on for N > 1)
-                # the same chunked solve + gather through the C ABI's OWN RCCL communicator (mtg_comm_*, csrc/mtg_comm.hip: what a
-                # C++ consumer running one process per GPU calls -- no torch.distributed in the data path; the unique id travels
-                # over the process group that exists anyway).  Never fails the bench: an error is recorded in the line.
+            if args.backend == "nccl" and not args.no_gather_via_mtg_comm:
+                # North_star's gather, at every N (round 6; rounds 4-5: opt-in for N > 1): the same chunked solve + gather through
+                # the C ABI's OWN RCCL communicator (mtg_comm_*, csrc/mtg_comm.hip: what a C++ consumer running one process per GPU
+                # calls -- no torch.distributed in the data path; the unique id travels over the process group that exists anyway).
+                # A second communicator's ncclCommInitRank is a collective: a rank that cannot join would leave the others waiting,
+                # and the driver's scaling run must not hang on an extra.  So the init runs on a WATCHDOG thread; every rank then
+                # reports over torch.distributed whether it joined in time, and only if ALL did is the communicator used.
+                # Otherwise the line carries the torch.distributed figure and says so (`gather.via_mtg_comm.fell_back`), and the
+                # process leaves through os._exit after printing (a thread stuck inside RCCL cannot be joined).
                 try:
+                    import threading
                     ids = [mdist.Communicator.unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(ids, src=0)
-                    comm = mdist.Communicator(ctx, rank, world, ids[0])
+                    box = {}
+
+                    def init_comm():
+                        try:
+                            box["comm"] = mdist.Communicator(ctx, rank, world, ids[0])
+                        except Exception as e_:   # noqa: BLE001
+                            box["error"] = repr(e_)[:300]
+                    th = threading.Thread(target=init_comm, daemon=True)
+                    t_init = time.perf_counter()
+                    th.start()
+                    th.join(args.mtg_comm_init_timeout)
+                    joined = torch.tensor([1.0 if "comm" in box else 0.0], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(joined, op=dist.ReduceOp.MIN)
+                    if float(joined.item()) < 1.0:
+                        stuck = th.is_alive()
+                        if stuck:
+                            WATCHDOG["hard_exit"] = True
+                        raise RuntimeError("mtg_comm init did not complete on every rank within %.0f s (this rank: %s); "
+                                           "gather figures are torch.distributed's" % (args.mtg_comm_init_timeout,
+                                           "timed out" if stuck else box.get("error", "joined")))
+                    comm = box["comm"]
+                    init_s = time.perf_counter() - t_init
                     for _ in range(3):
                         loc, gat = comm.solve_all_gather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks)
                     comm.sync()
@@ -892,10 +990,11 @@ def main():
                     via = (time.perf_counter() - t0) / reps
                     gather["via_mtg_comm"] = {"solve_plus_gather_ms": via * 1e3, "own_slice_matches_local_solve": bool(torch.equal(gat[:, rank].reshape(loc.shape), loc)),
                                               "matches_torch_distributed_gather": bool(torch.equal(gat, runner.gathered)),
+                                              "init_s": init_s, "default": True,
                                               "is": "mtg_comm_solve_all_gather: ncclAllGather per chunk on the communicator's stream under the next chunk's solve"}
                     comm.close()
                 except Exception as e:   # noqa: BLE001
-                    gather["via_mtg_comm"] = {"error": repr(e)[:300]}
+                    gather["via_mtg_comm"] = {"error": repr(e)[:300], "fell_back": "torch.distributed all_gather_into_tensor (the figures above)"}
 
     per_rank = None
     if grouped:
@@ -985,6 +1084,8 @@ def main():
             # the same warm-up + timed region as the first thing a fresh process does (no settle phase in front of it)
             "value_cold": None if cold is None else world * cold["units_per_s_this_rank"],
             "value_other_form": peer,
+            "sustained": sustained,
+            "value_aos_inputs": aos_peer,
         }
         if mixed and not per_batch:
             # the merged request of the timed region is built INSIDE it (MixedLoop.run): `value` pays for it
@@ -1020,8 +1121,11 @@ def main():
             print("bench.py: PARITY FAILED: " + json.dumps(out["parity"]), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if grouped:
         dist.barrier()
+        if WATCHDOG["hard_exit"]:      # a thread of this process is stuck inside ncclCommInitRank: it cannot be joined
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -124,8 +124,22 @@ enum {
                                      /* word (host and device pointers alike): flags raised   */
                                      /* by earlier asynchronous launches stay in the context  */
                                      /* for the next mtg_context_sync.  Not with              */
-                                     /* MTG_FLAG_COST_ONLY; rejected (invalid argument) by    */
-                                     /* mtg_solve_linear_sequence* and mtg_multi_create.      */
+                                     /* MTG_FLAG_COST_ONLY.  WHICH minimiser: a structurally  */
+                                     /* deficient plan is solved through its shadow -- the    */
+                                     /* LOWEST free slots (vertex, derivative < d) that       */
+                                     /* complete the fixed ones pinned to zero -- i.e. ONE of */
+                                     /* the minimisers: same cost and constraints as the      */
+                                     /* reference's basic solution, differing from it by an   */
+                                     /* element of the cost's null space (one polynomial of   */
+                                     /* degree < d over the whole trajectory); which columns  */
+                                     /* SparseQR drops depends on COLAMD's order.             */
+                                     /* mtg_solve_linear_sequence* and mtg_multi_create accept */
+                                     /* the flag and stay ASYNCHRONOUS: structurally deficient */
+                                     /* plans run on their shadow (a regular plan of the      */
+                                     /* queue / request like any other); there is no per-     */
+                                     /* trajectory host fall-back there -- a trajectory whose */
+                                     /* factorisation breaks down stays flagged in the        */
+                                     /* context's status word.                                */
 };
 #define MTG_HOST_BACKEND_MAX_BATCH 64
 
@@ -157,7 +171,13 @@ int mtg_plan_get_shape(const mtg_plan* plan, int32_t* n_coeffs, int32_t* dimensi
  * solve -- the reference's rank-revealing SparseQR returns a basic solution there (LIN:365-378): ask for it with
  * MTG_FLAG_BASIC_SOLUTION -- such a plan is then solved through its "shadow" (the same pattern with that many more slots
  * fixed to zero: a regular system, on the device like any other; free variables beyond the rank come back as exact zeros).
- * On regular plans the kernels flag a trajectory only when the factorisation breaks down (a non-positive or NaN pivot).     */
+ * On regular plans the kernels flag a trajectory only when the factorisation breaks down (a non-positive or NaN pivot).
+ * LIMITATION: the rank is computed at GENERIC vertex instants.  A Birkhoff-type pattern (a derivative fixed without the lower
+ * ones) can be regular generically and singular at a batch's actual times -- e.g. d = 3, ends position-only, the middle vertex
+ * velocity-only, EQUAL segment times: p(0), p'(T), p(2T) are dependent on the quadratics.  Such a plan reports 0 here, and a
+ * trajectory with exactly those times is caught only by the breakdown guard (a pivot of round-off size and either sign), where
+ * the reference's QR still returns a basic solution.  Hermite-type patterns (every fixed derivative with all lower ones: every
+ * pattern of the reference's tests and generators) are not affected.                                                        */
 int mtg_plan_rank_deficiency(const mtg_plan* plan);
 /* The same number from the description alone (host arithmetic only: no context, no device): fixed_mask[n_segments + 1] as in
  * mtg_plan_desc.  Negative: mtg_status.                                                                                      */

@@ -47,6 +47,14 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value);
  * checked against the 50-digit oracle in tests/test_gpu_literal_mfma.py.                                              */
 int mtg_lab_segment_cost_matrices(mtg_context* ctx, int32_t n_coeffs, int32_t derivative, int64_t n_segments,
                                   const double* times, double* h_out, int32_t variant);
+
+/* Shader clock while the caller's work runs: one wavefront on a stream of its own compares the shader-clock counter (s_memtime)
+ * with the constant 100 MHz counter (s_memrealtime) over `duration_us`.  start returns immediately (the probe is enqueued);
+ * finish waits for the probe, returns MHz and the probed interval, and releases it.  bench.py brackets its `sustained` run
+ * with it (the FP64-heavy solve kernels run power-limited: 1.75-1.96 GHz instead of the 2.4 GHz the peaks are quoted at).   */
+typedef struct mtg_lab_clock_probe mtg_lab_clock_probe;
+int mtg_lab_clock_probe_start(mtg_context* ctx, double duration_us, mtg_lab_clock_probe** out);
+int mtg_lab_clock_probe_finish(mtg_lab_clock_probe* probe, double* shader_mhz, double* measured_us);
 #ifdef __cplusplus
 }
 #endif

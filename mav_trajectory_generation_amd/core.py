@@ -75,6 +75,19 @@ class Context:
             self._leave(cur)
         return out
 
+    def clock_probe_start(self, duration_us: float):
+        """Start a shader-clock probe (include/mtg_hip_lab.h: mtg_lab_clock_probe_start) next to whatever runs on the device for
+        the next `duration_us`; returns the handle clock_probe_finish takes."""
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.mtg_lab_clock_probe_start(self.handle, float(duration_us), ctypes.byref(h)), self.handle)
+        return h
+
+    def clock_probe_finish(self, probe):
+        """(shader clock in MHz over the probed interval, the interval in us)."""
+        mhz, us = ctypes.c_double(0), ctypes.c_double(0)
+        _check(self.lib, self.lib.mtg_lab_clock_probe_finish(probe, ctypes.byref(mhz), ctypes.byref(us)), self.handle)
+        return mhz.value, us.value
+
     def _enter(self):
         """Order the library's stream after torch's current stream (no-op when they are the same)."""
         import torch
@@ -304,7 +317,7 @@ class Plan:
         return coeffs, d_free, cost
 
     def solve_sequence(self, sets, layout: str = "soa", dims: str = "auto", one_launch_per_batch: bool = False,
-                       start_event=None, stop_event=None, ordered: bool = True):
+                       start_event=None, stop_event=None, ordered: bool = True, basic_solution: bool = False):
         """A queue of INDEPENDENT batches of equal size (mtg_solve_linear_sequence[_events]): `sets` = sequence of
         (times, d_fixed, coeffs) CUDA tensors in `layout`, coeffs [B][K][D][N] allocated by the caller.  Plans with a
         slab-output kernel run the whole queue as ONE persistent launch (workgroups walk the tiles of all batches);
@@ -324,6 +337,8 @@ class Plan:
         flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE, "coop": L.FLAG_COOPERATIVE}[dims]
         if one_launch_per_batch:
             flags |= L.FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH
+        if basic_solution:   # a structurally rank-deficient plan runs the queue on its shadow (asynchronous; LIN:365-378)
+            flags |= L.FLAG_BASIC_SOLUTION
         ev = [ctypes.c_void_p(e.cuda_event) if e is not None else None for e in (start_event, stop_event)]
         cur = self.ctx._enter() if ordered else None
         rc = self.lib.mtg_solve_linear_sequence_events(self.handle, n, batch, ctypes.byref(lay), arr[0], arr[1], arr[2],
@@ -494,7 +509,7 @@ class MultiSolve:
     d_free, cost tensors (coeffs allocated here when missing; cost / d_free only when want_cost / want_free)."""
 
     def __init__(self, ctx: Context, items: Sequence[dict], want_cost: bool = False, want_free: bool = False,
-                 dims: str = "auto"):
+                 dims: str = "auto", basic_solution: bool = False):
         import torch
         self.ctx, self.lib = ctx, ctx.lib
         self.items = []
@@ -525,6 +540,8 @@ class MultiSolve:
         h = ctypes.c_void_p()
         flags = {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS,
                  "concurrent": L.FLAG_CONCURRENT_ITEMS}[dims]   # concurrent: one launch per item on the context's side streams
+        if basic_solution:   # items of structurally rank-deficient plans run on the plan's shadow (MTG_FLAG_BASIC_SOLUTION)
+            flags |= L.FLAG_BASIC_SOLUTION
         _check(self.lib, self.lib.mtg_multi_create(ctx.handle, len(items), arr, flags, ctypes.byref(h)), ctx.handle)
         self.handle = h
         self.launch_count = self.lib.mtg_multi_launch_count(h)

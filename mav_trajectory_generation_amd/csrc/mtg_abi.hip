@@ -529,6 +529,18 @@ __global__ void mtg_pin_gather_kernel(const double* __restrict__ src, long long 
   const int c = map[j];
   dst[i] = c >= 0 ? src[b * fs_b + dm * fs_d + c * fs_c] : 0.0;
 }
+// the same into a canonical SoA destination [D][nfs][Bs] (b fastest; Bs: the row stride) -- the asynchronous shadow solves of the
+// queue / merged entries keep the caller's layout KIND so that the shadow takes the same launch forms
+__global__ void mtg_pin_gather_soa_kernel(const double* __restrict__ src, long long fs_b, long long fs_d, long long fs_c, const int* __restrict__ map,
+                                          double* __restrict__ dst, long long B, long long Bs, int D, int nfs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D * nfs) return;
+  const long long b = i % B;
+  const int j = (int)((i / B) % nfs);
+  const int dm = (int)(i / (B * nfs));
+  const int c = map[j];
+  dst[((long long)dm * nfs + j) * Bs + b] = c >= 0 ? src[b * fs_b + dm * fs_d + c * fs_c] : 0.0;
+}
 // the caller's d_free (any strides) from the shadow's [B][D][nps]: free column j <- shadow column map[j], or 0 for a pinned slot
 __global__ void mtg_pin_scatter_kernel(const double* __restrict__ src, const int* __restrict__ map, double* __restrict__ dst, long long ps_b,
                                        long long ps_d, long long ps_c, long long B, int D, int np, int nps) {
@@ -545,6 +557,34 @@ static void flag_structurally_singular(const mtg_plan* p, hipStream_t st, int* s
   if (p->null_dim <= 0 || p->n_free == 0) return;
   const int64_t n = tstatus ? batch : 1;
   hipLaunchKernelGGL(mtg_flag_all_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, status, tstatus, (long long)batch, (int)MTG_FLAG_SINGULAR);
+}
+
+// MTG_FLAG_BASIC_SOLUTION in the asynchronous batched entries (mtg_solve_linear_sequence*, mtg_multi_*): a structurally
+// rank-deficient plan is replaced by its SHADOW (a regular plan like any other); what the shadow needs that the caller does not
+// hold is its d_fixed -- the caller's columns plus zeros at the pinned slots -- gathered on the device into `dst` in the caller's
+// layout KIND (SoA stays SoA: same launch forms).  SL: the caller's layout with the fixed-value strides of that buffer.
+// Nothing synchronises: the per-trajectory host fall-back of the synchronous entries (a trajectory on which the shadow's own
+// factorisation breaks down) does not exist here -- such a trajectory stays flagged in the context's status word.
+static int64_t padded16(int64_t batch);
+static size_t shadow_fixed_elems(const mtg_plan* p, int64_t batch) { return (size_t)padded16(batch) * p->D * std::max(p->shadow->n_fixed, 1); }
+static void shadow_gather_async(const mtg_plan* p, int64_t batch, const mtg_layout* L, const double* d_fixed, double* dst, mtg_layout* SL, hipStream_t st) {
+  const int Dd = p->D, nfs = p->shadow->n_fixed;
+  const bool soa = L->fixed_stride_b == 1 && L->times_stride_b == 1 && L->times_stride_k >= batch &&
+                   L->times_stride_k <= padded16(batch);                     // canonical / padded SoA inputs
+  *SL = *L;
+  const long long n = (long long)batch * Dd * nfs;
+  if (soa) {
+    const long long Bs = L->times_stride_k;                                 // the caller's row stride (batch, or its padded value)
+    SL->fixed_stride_b = 1; SL->fixed_stride_c = Bs; SL->fixed_stride_d = (int64_t)nfs * Bs;
+    if (n > 0)
+      hipLaunchKernelGGL(mtg_pin_gather_soa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_fixed, (long long)L->fixed_stride_b,
+                         (long long)L->fixed_stride_d, (long long)L->fixed_stride_c, (const int*)p->d_shadow_maps, dst, (long long)batch, Bs, Dd, nfs);
+  } else {
+    SL->fixed_stride_b = (int64_t)Dd * nfs; SL->fixed_stride_d = nfs; SL->fixed_stride_c = 1;
+    if (n > 0)
+      hipLaunchKernelGGL(mtg_pin_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_fixed, (long long)L->fixed_stride_b,
+                         (long long)L->fixed_stride_d, (long long)L->fixed_stride_c, (const int*)p->d_shadow_maps, dst, (long long)batch, Dd, nfs);
+  }
 }
 
 int mtg_plan_rank_deficiency(const mtg_plan* p) { return p ? p->null_dim : MTG_ERR_INVALID_ARGUMENT; }
@@ -1543,8 +1583,30 @@ int mtg_solve_linear_sequence_events(mtg_plan* plan, int32_t n, int64_t batch, c
   if (!plan || !layout || n < 0 || !times || !coeffs || (plan->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
   if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY)) return MTG_ERR_INVALID_ARGUMENT;
   mtg_context* ctx = plan->ctx;
-  if (flags & MTG_FLAG_BASIC_SOLUTION)   // (a synchronous per-call service of mtg_solve_linear / _status: a queue stays asynchronous)
-    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_BASIC_SOLUTION: mtg_solve_linear / mtg_solve_linear_status only");
+  if (flags & MTG_FLAG_BASIC_SOLUTION) {
+    // A queue stays asynchronous: a structurally rank-deficient plan runs the whole queue on its shadow (the pinned, regular
+    // system -- the shadow's d_fixed of every batch gathered on the device first); on a regular plan the flag changes nothing.
+    flags &= ~(uint32_t)MTG_FLAG_BASIC_SOLUTION;
+    if (plan->null_dim > 0 && plan->n_free > 0 && n > 0 && batch > 0) {
+      if (!plan->shadow) return set_err(ctx, MTG_ERR_UNSUPPORTED, "MTG_FLAG_BASIC_SOLUTION: this rank-deficient plan has no shadow plan");
+      const size_t per = shadow_fixed_elems(plan, batch);
+      mtg_layout SL;
+      std::vector<const double*> sfx((size_t)n);
+      {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int rs = ensure_buffer(ctx, &plan->shadow_buf, &plan->shadow_buf_bytes, per * (size_t)n * sizeof(double));
+        if (rs != MTG_OK) return rs;
+        for (int32_t i = 0; i < n; ++i) {
+          if (!d_fixed[i]) return MTG_ERR_INVALID_ARGUMENT;
+          shadow_gather_async(plan, batch, layout, d_fixed[i], plan->shadow_buf + per * (size_t)i, &SL, ctx->stream);
+          sfx[(size_t)i] = plan->shadow_buf + per * (size_t)i;
+        }
+        MTG_HIP_TRY(ctx, hipGetLastError());
+      }
+      return mtg_solve_linear_sequence_events(plan->shadow, n, batch, &SL, times, sfx.data(), coeffs, flags, start_event, stop_event);
+    }
+  }
   if (start_event) {
     MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     MTG_HIP_TRY(ctx, hipEventRecord((hipEvent_t)start_event, ctx->stream));
@@ -1661,6 +1723,11 @@ struct mtg_multi {
   bool concurrent = false;                  // MTG_FLAG_CONCURRENT_ITEMS: singles spread over the context's side streams
   std::vector<int> lane_of;                 // [singles.size()] side stream of each single (longest-processing-time first)
   int n_lanes = 0;
+  // MTG_FLAG_BASIC_SOLUTION: items of structurally rank-deficient plans run on the plan's shadow; their shadow d_fixed is gathered
+  // from the caller's buffer in front of every solve, their d_free (when asked for) scattered back behind it
+  struct ShadowFix { const mtg_plan* plan; int64_t batch; mtg_layout layout; const double* d_fixed; double* sfx; double* d_free; double* sfr; };
+  std::vector<ShadowFix> shadow_fix;
+  double* shadow_mem = nullptr;
 };
 
 static void multi_free(mtg_multi* m, bool context_locked) {
@@ -1681,6 +1748,7 @@ static void multi_free(mtg_multi* m, bool context_locked) {
     if (g.d_tiles) hipFree(g.d_tiles);
     if (g.d_ws) hipFree(g.d_ws);
   }
+  if (m->shadow_mem) hipFree(m->shadow_mem);
   delete m;
 }
 int mtg_multi_destroy(mtg_multi* m) {
@@ -1692,8 +1760,54 @@ int mtg_multi_destroy(mtg_multi* m) {
 int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* items, uint32_t flags, mtg_multi** out) {
   if (!ctx || !items || !out || n_items < 1) return MTG_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (flags & MTG_FLAG_BASIC_SOLUTION)
-    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_BASIC_SOLUTION: mtg_solve_linear / mtg_solve_linear_status only");
+  std::vector<mtg_multi_item> patched;
+  std::vector<mtg_multi::ShadowFix> fixes;
+  double* shadow_mem = nullptr;
+  if (flags & MTG_FLAG_BASIC_SOLUTION) {
+    // the request stays asynchronous: an item of a structurally rank-deficient plan becomes an item of that plan's SHADOW (the
+    // pinned, regular system: just another plan of the request); regular plans' items are unchanged
+    flags &= ~(uint32_t)MTG_FLAG_BASIC_SOLUTION;
+    patched.assign(items, items + n_items);
+    size_t total = 0;
+    for (int i = 0; i < n_items; ++i) {
+      const mtg_multi_item& it = items[i];
+      if (!it.plan || it.plan->ctx != ctx || it.batch < 0) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "mtg_multi_create: bad item");
+      if (it.plan->null_dim <= 0 || it.plan->n_free == 0 || it.batch == 0) continue;
+      if (!it.plan->shadow) return set_err(ctx, MTG_ERR_UNSUPPORTED, "MTG_FLAG_BASIC_SOLUTION: a rank-deficient plan of the request has no shadow plan");
+      if (!it.d_fixed) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "mtg_multi_create: bad item");
+      total += shadow_fixed_elems(it.plan, it.batch) + (it.d_free ? (size_t)it.batch * it.plan->D * std::max(it.plan->shadow->n_free, 1) : 0);
+    }
+    if (total > 0) {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+      MTG_HIP_TRY(ctx, hipMalloc((void**)&shadow_mem, total * sizeof(double)));
+      double* cur = shadow_mem;
+      for (int i = 0; i < n_items; ++i) {
+        mtg_multi_item& it = patched[(size_t)i];
+        const mtg_plan* p = it.plan;
+        if (p->null_dim <= 0 || p->n_free == 0 || it.batch == 0) continue;
+        mtg_multi::ShadowFix fx{p, it.batch, it.layout, it.d_fixed, cur, it.d_free, nullptr};
+        cur += shadow_fixed_elems(p, it.batch);
+        // the item's layout with the shadow buffer's fixed-value strides (same rule as shadow_gather_async) ...
+        const mtg_layout& L = items[i].layout;
+        const int nfs = p->shadow->n_fixed, nps = p->shadow->n_free;
+        const bool soa = L.fixed_stride_b == 1 && L.times_stride_b == 1 && L.times_stride_k >= it.batch && L.times_stride_k <= padded16(it.batch);
+        if (soa) { it.layout.fixed_stride_b = 1; it.layout.fixed_stride_c = L.times_stride_k; it.layout.fixed_stride_d = (int64_t)nfs * L.times_stride_k; }
+        else { it.layout.fixed_stride_b = (int64_t)p->D * nfs; it.layout.fixed_stride_d = nfs; it.layout.fixed_stride_c = 1; }
+        if (it.d_free) {     // ... and d_P through a contiguous [B][D][n_free of the shadow] buffer, scattered back after the solve
+          fx.sfr = cur;
+          cur += (size_t)it.batch * p->D * std::max(nps, 1);
+          it.layout.free_stride_b = (int64_t)p->D * nps; it.layout.free_stride_d = nps; it.layout.free_stride_c = 1;
+          it.d_free = fx.sfr;
+        }
+        it.plan = p->shadow;
+        it.d_fixed = fx.sfx;
+        fixes.push_back(fx);
+      }
+      items = patched.data();
+    }
+  }
+  struct ShadowMemGuard { double*& m; ~ShadowMemGuard() { if (m) hipFree(m); } } shadow_guard{shadow_mem};   // (released on every error return)
   for (int i = 0; i < n_items; ++i) {
     const mtg_multi_item& it = items[i];
     if (!it.plan || it.plan->ctx != ctx || it.batch < 0 || !it.times || !it.coeffs || (it.plan->n_fixed > 0 && !it.d_fixed))
@@ -1746,6 +1860,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
       delete m;
       return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: event creation failed");
     }
+    m->shadow_fix = std::move(fixes); m->shadow_mem = shadow_mem; shadow_mem = nullptr;
     *out = m;
     return MTG_OK;
   }
@@ -2004,6 +2119,7 @@ int mtg_multi_create(mtg_context* ctx, int32_t n_items, const mtg_multi_item* it
       return set_err(ctx, MTG_ERR_DEVICE, "mtg_multi_create: table upload failed");
     }
   }
+  m->shadow_fix = std::move(fixes); m->shadow_mem = shadow_mem; shadow_mem = nullptr;
   *out = m;
   return MTG_OK;
 }
@@ -2012,8 +2128,35 @@ int mtg_multi_launch_count(const mtg_multi* m) {
   return m ? (int)(m->groups.size() + m->singles.size() + (m->dl_any.nunits > 0 ? 1 : 0)) : 0;
 }
 
+static int multi_solve_body(mtg_multi* m);
 int mtg_multi_solve(mtg_multi* m) {
   if (!m) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = m->ctx;
+  if (!m->shadow_fix.empty()) {      // MTG_FLAG_BASIC_SOLUTION items: the shadows' d_fixed from the callers' current values
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mtg_layout unused;
+    for (const mtg_multi::ShadowFix& fx : m->shadow_fix) shadow_gather_async(fx.plan, fx.batch, &fx.layout, fx.d_fixed, fx.sfx, &unused, ctx->stream);
+    MTG_HIP_TRY(ctx, hipGetLastError());
+  }
+  const int rc = multi_solve_body(m);
+  if (rc != MTG_OK) return rc;
+  if (!m->shadow_fix.empty()) {      // ... and their d_P back into the callers' layout, exact zeros at the pinned slots
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (const mtg_multi::ShadowFix& fx : m->shadow_fix) {
+      if (!fx.d_free || fx.plan->n_free == 0) continue;
+      const long long n = (long long)fx.batch * fx.plan->D * fx.plan->n_free;
+      hipLaunchKernelGGL(mtg_pin_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)fx.sfr,
+                         (const int*)(fx.plan->d_shadow_maps + fx.plan->shadow->n_fixed), fx.d_free, (long long)fx.layout.free_stride_b,
+                         (long long)fx.layout.free_stride_d, (long long)fx.layout.free_stride_c, (long long)fx.batch, fx.plan->D, fx.plan->n_free,
+                         fx.plan->shadow->n_free);
+    }
+    MTG_HIP_TRY(ctx, hipGetLastError());
+  }
+  return MTG_OK;
+}
+static int multi_solve_body(mtg_multi* m) {
   mtg_context* ctx = m->ctx;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);

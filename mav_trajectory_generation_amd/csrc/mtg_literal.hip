@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <new>
 
 #include "../../include/mtg_hip_lab.h"
 
@@ -139,4 +140,71 @@ extern "C" int mtg_lab_segment_cost_matrices(mtg_context* ctx, int32_t n_coeffs,
     default: launch<6>(variant, st, times, h_out, n_segments, derivative); break;
   }
   return hipGetLastError() == hipSuccess ? MTG_OK : MTG_ERR_DEVICE;
+}
+
+// ---- shader-clock probe (include/mtg_hip_lab.h: mtg_lab_clock_probe_*) --------------------------------------------------------
+// One wavefront on a stream of its own reads the shader-clock counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) when it starts, sleeps in s_sleep for `duration_us` of the constant clock, and reads both again: ticks of the
+// first per tick of the second = the shader clock WHILE whatever else the caller has running on the device runs (the FP64-heavy
+// solve kernels pull it from 2.4 GHz down to 1.75-1.96 GHz, profiles/r05_long_timeline.txt).  The wave occupies one SIMD slot
+// and issues one instruction per ~64 cycles: it does not compete with the measured work.
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long* out, long long duration_ticks) {
+  if (threadIdx.x != 0) return;
+  const long long r0 = wall_clock64(), c0 = clock64();
+  long long r1 = r0;
+  while (r1 - r0 < duration_ticks) {
+    __builtin_amdgcn_s_sleep(16);
+    r1 = wall_clock64();
+  }
+  const long long c1 = clock64();
+  r1 = wall_clock64();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+}  // namespace
+
+struct mtg_lab_clock_probe {
+  int device;
+  hipStream_t stream;
+  long long* host;     // pinned, mapped: [shader ticks, 100 MHz ticks]
+};
+
+extern "C" int mtg_lab_clock_probe_start(mtg_context* ctx, double duration_us, mtg_lab_clock_probe** out) {
+  if (ctx == nullptr || out == nullptr || !(duration_us > 0.0) || duration_us > 60e6) return MTG_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  void* stream = nullptr;
+  int device = 0;
+  const int rc = mtg_context_stream_device(ctx, &stream, &device);
+  if (rc != MTG_OK) return rc;
+  if (hipSetDevice(device) != hipSuccess) return MTG_ERR_DEVICE;
+  mtg_lab_clock_probe* p = new (std::nothrow) mtg_lab_clock_probe{device, nullptr, nullptr};
+  if (!p) return MTG_ERR_DEVICE;
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&p->host, 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess) {
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return MTG_ERR_DEVICE;
+  }
+  p->host[0] = p->host[1] = 0;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->host, (long long)(duration_us * 100.0));
+  if (hipGetLastError() != hipSuccess) { hipHostFree(p->host); hipStreamDestroy(p->stream); delete p; return MTG_ERR_DEVICE; }
+  *out = p;
+  return MTG_OK;
+}
+
+extern "C" int mtg_lab_clock_probe_finish(mtg_lab_clock_probe* p, double* shader_mhz, double* measured_us) {
+  if (p == nullptr) return MTG_ERR_INVALID_ARGUMENT;
+  int rc = MTG_OK;
+  if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) rc = MTG_ERR_DEVICE;
+  if (rc == MTG_OK && p->host[1] > 0) {
+    if (shader_mhz) *shader_mhz = (double)p->host[0] / ((double)p->host[1] * 0.01);
+    if (measured_us) *measured_us = (double)p->host[1] * 0.01;
+  } else if (rc == MTG_OK) {
+    rc = MTG_ERR_DEVICE;
+  }
+  hipHostFree(p->host);
+  hipStreamDestroy(p->stream);
+  delete p;
+  return rc;
 }

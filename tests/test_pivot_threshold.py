@@ -212,6 +212,35 @@ def assert_cost_matches(n, d, masks, times, d_fixed, cost, cost_ref, tol):
             assert abs(cost[b] - truth) <= tol * abs(truth), (int(b), cost[b], cost_ref[b], truth)
 
 
+def assert_same_minimiser_up_to_the_null_space(n, d, masks, times, co, fr, co_ref, fr_ref, null_dim):
+    """The relation between the library's basic solution and the compiled reference's (oracle/_ref) on a rank-deficient problem,
+    coefficient level.  Both are minimisers (same cost, same constraints: asserted by the caller), both have null_dim exactly-zero
+    free variables -- at DIFFERENT slots: the library pins the LOWEST free slots (vertex, derivative < d) that complete the fixed
+    ones; oracle/_ref's QR drops the columns it meets last in ITS column order (the stand-in's minimum-degree
+    order; real Eigen: COLAMD's -- not reproducible in this image), here the top derivatives < d of the last interior vertex.
+    Hence the coefficients differ, by an element of the cost's null space: ONE polynomial of degree < d over the whole
+    trajectory.  Asserted: the d-th derivative of the difference vanishes on every segment (relative to the solution's own d-th
+    derivative); the difference is not small (the two solutions ARE different minimisers)."""
+    k, h = times.shape[1], n // 2
+    slots = [(v, q) for v in range(k + 1) for q in range(h) if not (masks[v] >> q) & 1]
+    zeros_lib = [slots[i] for i in np.nonzero(fr[0, 0] == 0.0)[0]]
+    zeros_ref = [slots[i] for i in np.nonzero(fr_ref[0, 0] == 0.0)[0]]
+    assert len(zeros_lib) == null_dim and len(zeros_ref) == null_dim, (zeros_lib, zeros_ref)
+    assert all(q < d for (_, q) in zeros_lib + zeros_ref)                    # only slots the cost's null space can move
+    assert zeros_lib == sorted(zeros_lib) and zeros_lib[0][0] <= 1 and zeros_ref[-1][0] >= k - 1, (zeros_lib, zeros_ref)
+    diff = co - co_ref
+    worst = scale = 0.0
+    for s in range(k):
+        for tt in np.linspace(0.0, 1.0, 9):
+            t = tt * times[:, s, None]
+            worst = max(worst, np.abs(helpers.evaluate(diff[:, s], t, d)).max())
+            scale = max(scale, np.abs(helpers.evaluate(co_ref[:, s], t, d)).max())
+    # a zero-cost direction: the difference's own cost is (worst / scale)^2 of the solution's, i.e. <= 1e-9 (N <= 10) / 1e-6 (N = 12)
+    # -- the caller's cost tolerance; measured 1e-9 ... 8e-7 (N <= 10, K = 8 ... 50), 4e-6 (N = 12) for worst / scale
+    assert worst <= (3e-5 if n <= 10 else 1e-3) * scale, (worst, scale)
+    assert np.abs(diff).max() > 1e-3 * np.abs(co_ref).max()                    # ... and not the same point of the solution set
+
+
 @pytest.mark.gpu
 @needs_ref
 @pytest.mark.parametrize("n,k", [(10, 8), (10, 16), (10, 32), (10, 50), (8, 16), (8, 50), (12, 8)])
@@ -230,7 +259,7 @@ def test_rank_deficient_long_chains_through_every_launch_route(ctx, n, k, which)
     rng = np.random.default_rng(k + n)
     nf = sum(bin(x).count("1") for x in masks)
     times, d_fixed = rng.uniform(0.8, 2.5, (bsz, k)), rng.uniform(-2.0, 2.0, (bsz, dim, nf))
-    _, _, cost_ref, _ = ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())
+    co_ref, fr_ref, cost_ref, _ = ref_linear.solve_batch(n, d, masks, times, d_fixed, nthreads=ref_linear.hardware_threads())
     cost_tol = 1e-9 if n <= 10 else 1e-6
     plan = m.Plan(ctx, n, dim, k, d, masks)
     assert plan.rank_deficiency == max(0, d - n_constraints)
@@ -277,6 +306,23 @@ def test_rank_deficient_long_chains_through_every_launch_route(ctx, n, k, which)
         assert_cost_matches(n, d, masks, times, d_fixed, cost, cost_ref, cost_tol)
         if deficient:       # basic: (at least) as many free variables as the rank is short are exactly zero
             assert int((fr[0, 0] == 0.0).sum()) >= plan.rank_deficiency
+            assert_same_minimiser_up_to_the_null_space(n, d, masks, times, co, fr, co_ref, fr_ref, plan.rank_deficiency)
+        # round 6: the flag through the ASYNCHRONOUS batched entries -- a queue and a merged request run the plan's shadow
+        sets = [(t, f, torch.full((bsz, k, dim, n), float("nan"), dtype=torch.float64, device="cuda")) for _ in range(3)]
+        plan.solve_sequence(sets, layout=layout, basic_solution=True)
+        ctx.sync()                                                          # MTG_OK: nothing flagged
+        for (_, _, c3) in sets:
+            assert np.abs(c3.cpu().numpy() - co).max() <= 1e-9 * np.abs(co).max()
+        req = m.MultiSolve(ctx, [dict(plan=plan, times=t, d_fixed=f, layout=layout) for _ in range(2)], want_free=True, want_cost=True,
+                           basic_solution=True)
+        outs = req.solve()
+        ctx.sync()
+        for (c4, f4, j4) in outs:
+            f4 = f4.cpu().numpy() if layout == "aos" else f4.permute(2, 0, 1).cpu().numpy()
+            assert np.abs(c4.cpu().numpy() - co).max() <= 1e-9 * np.abs(co).max()
+            assert np.abs(j4.cpu().numpy() / cost - 1).max() <= 1e-9
+            assert np.array_equal(f4 == 0.0, fr == 0.0) and np.abs(f4 - fr).max() <= 1e-9 * np.abs(fr).max()
+        req.close()
     for hb in (False, True):
         if deficient:
             with pytest.raises(m.MtgError) as e:
