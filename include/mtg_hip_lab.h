@@ -7,13 +7,11 @@
  *   "force_dg"         1..4, 0 = off               dimension-group size of the specialised fused / split kernels
  *   "prefer_rolled"    0 / 1                       rolled (run-time K) kernel even where a static one exists
  *   "no_dimlane"       0 / 1                       never the dimension-in-lane forms
- *   "dl_policy"        -1 default, 0 / 1 / 2       coefficient store policy of the dimension-in-lane form
  *   "no_slab"          0 / 1                       fused form without the slab-output kernel
  *   "no_slab_extra"    0 / 1                       extra outputs (cost / d_P) through the older fused kernel
  *   "no_dl_extra"      0 / 1                       extra outputs never through the dimension-in-lane kernels
  *   "no_queue"         0 / 1                       mtg_solve_linear_sequence as one launch per batch
  *   "no_balance"       0 / 1                       persistent grids not evened out over their rounds
- *   "dl_occ2"          -1 default, 0 never, 1 always   two-waves-per-SIMD twins of the dimension-in-lane variants
  *   "dl_rt"            -1 default, 0 never, 1 always   run-time-K dimension-in-lane body
  *   "dl_grid_per_cu"   >= 1 (default 8)            workgroups per CU of a non-workspace dimension-in-lane launch
  *   "dl_any_sched_rr"  0 / 1                       round 2's unit schedule of the cross-structure launch
@@ -24,8 +22,6 @@
  *   "extrema_split"    -1 default; bits 0-1: lanes that share one root search of the extrema kernels (1, 2, 3 = four; 0 = by
  *                      launch size, the default); bit 2: one code body for all levels of the derivative chain
  *   "sample_generic"   0 / 1                       mtg_sample_range never through its compile-time-shape kernels
- *   "dl_stagger"       >= 0 (default 0)            every second workgroup of a single dimension-in-lane launch starts
- *                                                  value x 2048 shader cycles late (phase-lock experiment: no effect)
  * Returns MTG_OK, or MTG_ERR_INVALID_ARGUMENT for an unknown name.                                                  */
 #ifndef MTG_HIP_LAB_H_
 #define MTG_HIP_LAB_H_

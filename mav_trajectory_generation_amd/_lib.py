@@ -122,13 +122,13 @@ EXPORTS = {
 _flag = lambda e: 1
 ENV_OPTIONS = {
     "MTG_FORCE_DG": ("force_dg", int), "MTG_PREFER_ROLLED": ("prefer_rolled", _flag), "MTG_NO_DIMLANE": ("no_dimlane", _flag),
-    "MTG_DL_POLICY": ("dl_policy", int), "MTG_NO_SLAB": ("no_slab", _flag), "MTG_NO_QUEUE": ("no_queue", _flag),
+    "MTG_NO_SLAB": ("no_slab", _flag), "MTG_NO_QUEUE": ("no_queue", _flag),
     "MTG_NO_SLAB_EXTRA": ("no_slab_extra", _flag), "MTG_NO_DL_EXTRA": ("no_dl_extra", _flag),
-    "MTG_NO_BALANCE": ("no_balance", _flag), "MTG_DL_OCC2": ("dl_occ2", int), "MTG_DL_RT": ("dl_rt", int),
+    "MTG_NO_BALANCE": ("no_balance", _flag), "MTG_DL_RT": ("dl_rt", int),
     "MTG_DL_GRID_PER_CU": ("dl_grid_per_cu", int), "MTG_DL_ANY_SCHED": ("dl_any_sched_rr", lambda e: int(e == "rr")),
     "MTG_SLAB_POLICY": ("slab_policy", lambda e: 1 if int(e) else 0), "MTG_ROLLED_WG_PER_CU": ("rolled_wg_per_cu", int),
     "MTG_DL_MAX_UNITS": ("dl_max_units", int), "MTG_SAMPLE_GENERIC": ("sample_generic", _flag),
-    "MTG_DL_STAGGER": ("dl_stagger", int), "MTG_COOP": ("coop", int),
+    "MTG_COOP": ("coop", int),
     "MTG_EXTREMA_SPLIT": ("extrema_split", int),
 }
 

@@ -124,16 +124,13 @@ struct mtg_context {
   bool knob_no_queue = false;        // MTG_NO_QUEUE: mtg_solve_linear_sequence as one launch per batch
   int knob_dl_grid_per_cu = 8;       // MTG_DL_GRID_PER_CU: workgroups per CU of a (non-workspace) dimension-in-lane launch
   int knob_dl_rt = -1;               // MTG_DL_RT: 1 = the run-time-K body even where a static variant exists, 0 = never (default: where none exists)
-  int knob_dl_occ2 = -1;             // MTG_DL_OCC2: 1 always / 0 never use the two-waves-per-SIMD twins (default: by launch size)
   bool knob_dl_any_rr = false;       // MTG_DL_ANY_SCHED=rr: round 2's unit schedule of the cross-structure launch
   bool knob_no_balance = false;      // MTG_NO_BALANCE: persistent grids are not evened out over their rounds
   int knob_slab_policy = -1;         // MTG_SLAB_POLICY: 0 write-back, 1 nt sc1
   int rolled_wg_per_cu = 4;          // MTG_ROLLED_WG_PER_CU: persistent workgroups per CU of the rolled (workspace) kernels
-  int knob_dl_policy = -1;           // MTG_DL_POLICY: coefficient store policy of the dimension-in-lane form (0 nt sc1, 1 sc1, 2 write-back; 1 / 2 only in builds with -DMTG_DL_ALL_POLICIES)
   bool knob_sample_generic = false;  // MTG_SAMPLE_GENERIC: mtg_sample_range never through its LDS-staged kernel
   int knob_extrema_split = -1;       // MTG_EXTREMA_SPLIT: lanes per root search of the extrema kernels (include/mtg_hip_lab.h; -1: default)
   int knob_coop = -1;                // MTG_COOP: 1 always / 0 never take the row-cooperative form where eligible (default: by size)
-  int knob_dl_stagger = 0;           // MTG_DL_STAGGER: every second workgroup of a dimension-in-lane launch starts n x 2048 cycles late
   // MTG_FLAG_CONCURRENT_ITEMS requests: side streams (created on first use) + fork / join events
   std::vector<hipStream_t> side_streams;
   hipEvent_t fork_event = nullptr;
@@ -167,7 +164,6 @@ struct LaunchRecord {
   size_t lds = 0;
   const MtgDimlaneEntry* dl = nullptr;   // dimension-in-lane launch (mtg_dimlane.h): uses params.{times,dfix,coeffs,status,tstatus,B}
   const MtgDimlaneRtEntry* rt = nullptr; // run-time-K dimension-in-lane launch (mtg_dimlane_rt.h)
-  int dl_policy = 0;
   int dl_aos = 0;                        // input layout kind of a dimension-in-lane launch (dimlane_input_kind)
   bool coop = false;                     // row-cooperative launch (mtg_coop.hip)
   double* dl_ws = nullptr;
@@ -184,7 +180,6 @@ struct mtg_plan {
   const MtgStaticEntry* fast = nullptr;        // all dimensions in one workgroup
   const MtgStaticEntry* fast_split = nullptr;  // smallest dimension group that divides D
   const MtgDimlaneEntry* dimlane = nullptr;    // dimension-in-lane form (canonical SoA inputs, coefficient output only)
-  const MtgDimlaneEntry* dimlane2 = nullptr;   // its throughput twin (two waves per SIMD), where one exists
   const MtgDimlaneRtEntry* dimlane_rt = nullptr;   // run-time-K dimension-in-lane body (mtg_dimlane_rt.h): any chain length of the standard shapes
   bool slab_attr_set[2] = {false, false};      // LDS attribute of the slab-output kernels set
   bool slab_queue_attr_set = false;
@@ -316,13 +311,11 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   if (n == "force_dg") ctx->knob_force_dg = value;
   else if (n == "prefer_rolled") ctx->knob_prefer_rolled = value != 0;
   else if (n == "no_dimlane") ctx->knob_no_dimlane = value != 0;
-  else if (n == "dl_policy") ctx->knob_dl_policy = value;
   else if (n == "no_slab") ctx->knob_no_slab = value != 0;
   else if (n == "no_queue") ctx->knob_no_queue = value != 0;
   else if (n == "no_slab_extra") ctx->knob_no_slab_extra = value != 0;
   else if (n == "no_dl_extra") ctx->knob_no_dl_extra = value != 0;
   else if (n == "no_balance") ctx->knob_no_balance = value != 0;
-  else if (n == "dl_occ2") ctx->knob_dl_occ2 = value;
   else if (n == "dl_rt") ctx->knob_dl_rt = value;
   else if (n == "dl_grid_per_cu") ctx->knob_dl_grid_per_cu = std::max(1, value);
   else if (n == "dl_any_sched_rr") ctx->knob_dl_any_rr = value != 0;
@@ -332,7 +325,6 @@ int mtg_context_set_option(mtg_context* ctx, const char* name, int value) {
   else if (n == "sample_generic") ctx->knob_sample_generic = value != 0;
   else if (n == "coop") ctx->knob_coop = value;
   else if (n == "extrema_split") ctx->knob_extrema_split = value;
-  else if (n == "dl_stagger") ctx->knob_dl_stagger = std::max(0, std::min(value, 1 << 20));
   else return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "unknown option: " + n);
   return MTG_OK;
 }
@@ -632,7 +624,6 @@ int mtg_plan_create(mtg_context* ctx, const mtg_plan_desc* desc, mtg_plan** out)
     if (D % dg == 0) p->fast_split = mtg_find_static(p->H, dg, K, d, p->mask.data());
   }
   p->dimlane = mtg_find_dimlane(p->H, D, K, d, p->mask.data());
-  p->dimlane2 = p->dimlane ? mtg_find_dimlane(p->H, D, K, d, p->mask.data(), 2) : nullptr;
   p->dimlane_rt = mtg_find_dimlane_rt(p->H, D, K, d, p->mask.data());
   std::vector<int> tab;
   tab.insert(tab.end(), p->mask.begin(), p->mask.end());
@@ -749,17 +740,6 @@ static int balanced_grid(const mtg_context* ctx, int ntiles, int cap) {
   if (ntiles <= cap || ctx->knob_no_balance) return std::min(ntiles, cap);
   const int rounds = (ntiles + cap - 1) / cap;
   return (ntiles + rounds - 1) / rounds;
-}
-
-// The two-waves-per-SIMD twin of a dimension-in-lane variant (MTG_DLO) for launches with more workgroups than `kOcc2MinWgPerCu`
-// per CU: below that every workgroup has a CU to itself anyway and the plain variant (no spills) is faster.
-constexpr int kOcc2MinWgPerCu = 2;
-static const MtgDimlaneEntry* dimlane_twin(const mtg_plan* p, const MtgDimlaneEntry* dl, int64_t trajectories) {
-  if (!dl || dl != p->dimlane || !p->dimlane2 || p->ctx->knob_dl_occ2 == 0) return dl;
-  if (p->ctx->knob_dl_occ2 == 1) return p->dimlane2;
-  const int64_t units = ((trajectories + dl->tpw - 1) / dl->tpw + dl->np - 1) / dl->np;
-  if (p->dimlane2->ws_per_lane) return dl;      // long-chain twins (MTG_DLO2): lab option only
-  return units > (int64_t)kOcc2MinWgPerCu * p->ctx->n_cu ? p->dimlane2 : dl;
 }
 
 // default range of the dimension-in-lane form (mtg_dimlane_variants.inc): LO * CUs <= workgroups <= HI * CUs / 2
@@ -944,7 +924,7 @@ static SolveForm pick_form(SolveCall& c, bool update_only) {
   if (update_only) return SolveForm::kUpdate;
   if (pick_coop(c.p, c.batch, c.L, c.P, c.flags, c.cost_only)) return SolveForm::kCoop;
   if ((c.rt = pick_dimlane_rt(c.p, c.batch, c.L, c.P, c.flags, c.cost_only))) return SolveForm::kDimlaneRt;
-  if ((c.dl = dimlane_twin(c.p, pick_dimlane(c.p, c.batch, c.L, c.P, c.flags, c.cost_only), c.batch))) return SolveForm::kDimlane;
+  if ((c.dl = pick_dimlane(c.p, c.batch, c.L, c.P, c.flags, c.cost_only))) return SolveForm::kDimlane;
   return SolveForm::kFused;
 }
 
@@ -1021,29 +1001,22 @@ static int launch_dimlane(SolveCall& c) {
   const int nt = (int)((c.batch + dl->tpw - 1) / dl->tpw);
   const int units = (nt + dl->np - 1) / dl->np;
   int grid = std::min(units, ctx->n_cu * ctx->knob_dl_grid_per_cu);
-  const int policy = ctx->knob_dl_policy >= 0 ? ctx->knob_dl_policy : 0;
   double* dl_ws = nullptr;
   if (dl->ws_per_lane) {
     // long chains: part of the back-substitution data goes through the workspace; persistent workgroups only (two
     // 2-wave workgroups per CU, one wave per SIMD), so the workspace stays small enough to live in the Infinity Cache
-    grid = std::min(units, ctx->n_cu * 4 * dl->occ / (2 * dl->np));
+    grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
     const int rc = workspace(p, dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave, &dl_ws);
     if (rc != MTG_OK) return rc;
   }
-  // Phase stagger (mtg_dimlane.h; measurement knob "dl_stagger", default off).  Round 4 tested whether persistent one-wave-per-
-  // SIMD workgroups stay phase-locked (everyone eliminating, then everyone storing).  A sweep inside ONE process seemed to show
-  // 5-11 % for the workspace hybrids (profiles/r04a_stagger_sweep.jsonl) -- but with a fresh context, plan and buffers per setting
-  // the effect is gone (profiles/r04g_stagger_check_fresh_contexts.jsonl: N = 10 / K = 32 300 / 300 / 299 us for default / 0 / 8):
-  // the sweep had measured the process warming up (the same kernel gets ~10 % faster over its first ~200 launches), not the stagger.
-  const int stagger = ctx->knob_dl_stagger > 0 ? ctx->knob_dl_stagger : 0;
-  const int aos = dimlane_input_kind(p, c.L, c.batch) | (stagger << 8);
+  const int aos = dimlane_input_kind(p, c.L, c.batch);
   const int lrc = (P.dfree || P.cost)
                       ? dl->launch_extra((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, dl_ws, aos,
                                          P.dfree, P.cost, P.ps_b, P.ps_d, P.ps_c)
-                      : dl->launch((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, policy, dl_ws, aos);
+                      : dl->launch((void*)c.st, grid, P.times, P.dfix, P.coeffs, P.status, c.dts, (int)c.batch, nt, dl_ws, aos);
   if (lrc != 0) return set_err(ctx, MTG_ERR_DEVICE, "dimension-in-lane launch set-up failed");
   LaunchRecord r;
-  r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_policy = policy; r.dl_ws = dl_ws; r.dl_aos = aos;
+  r.valid = true; r.params = P; r.ntiles = nt; r.grid = grid; r.dl = dl; r.dl_ws = dl_ws; r.dl_aos = aos;
   p->last.push_back(r);
   return MTG_OK;
 }
@@ -1527,7 +1500,6 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
     dl = nullptr;
   if (slab && dl && !(flags & MTG_FLAG_DIMLANE) && !dimlane_is_default(p, dl, batch * (int64_t)n_launch)) dl = nullptr;
   if (!slab && !dl) return 1;
-  dl = dimlane_twin(p, dl, batch * (int64_t)n_launch);
   for (int32_t i = 0; i < n; ++i) {
     if (!times[i] || !coeffs[i] || (p->n_fixed > 0 && !d_fixed[i])) return MTG_ERR_INVALID_ARGUMENT;
     if (reinterpret_cast<uintptr_t>(coeffs[i]) & 15) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "coeffs must be 16-byte aligned");
@@ -1555,7 +1527,7 @@ static int sequence_as_queue(mtg_plan* p, int32_t n, int64_t batch, const mtg_la
       int grid = std::min(units, ctx->n_cu * 8);
       double* dl_ws = nullptr;
       if (dl->ws_per_lane) {   // long chains: persistent workgroups only, as in single launches
-        grid = std::min(units, ctx->n_cu * 4 * dl->occ / (2 * dl->np));
+        grid = std::min(units, ctx->n_cu * 4 / (2 * dl->np));
         const size_t need = dl->ws_per_lane * (size_t)grid * dl->np * 2 * kWave;
         if (p->user_ws) {
           if (p->user_ws_bytes < need) return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "user workspace too small");
@@ -2242,7 +2214,7 @@ int mtg_time_last_solve(mtg_plan* p, int iters, double* mean_us) {
                              r.params.ps_b, r.params.ps_d, r.params.ps_c);
         else
           r.dl->launch((void*)ctx->stream, r.grid, r.params.times, r.params.dfix, r.params.coeffs, r.params.status,
-                       r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_policy, r.dl_ws, r.dl_aos);
+                       r.params.tstatus, (int)r.params.B, r.ntiles, r.dl_ws, r.dl_aos);
         continue;
       }
       // (the cost accumulators are not re-zeroed between the timed launches: values are irrelevant here, and a memset

@@ -22,9 +22,6 @@
 #define MTG_DIMLANE_H_
 #include "mtg_kernels.h"   // (brings in mtg_slab.h: MtgSlabOut)
 
-#ifndef MTG_DL_OCC
-#define MTG_DL_OCC 1   // waves per SIMD the register allocation is held to
-#endif
 // (Built, measured and removed in round 3 / 4: requesting the NEXT tile's inputs before the current tile is solved -- 30 more
 // registers, no effect: B = 125k 90.3 vs 91.4 us, N = 12 / K = 8 at 100k 93.7 vs 92.0 us.  The third of its lifetime a wave
 // spends parked, profiles/r03f_pmc_stalls.txt, is not the input round trip.)
@@ -98,13 +95,6 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
   }
 }
 
-#if defined(MTG_LAB_TIMELINE)   // per-tile stamps of the first MTG_LAB_TIMELINE tiles of every wave (tools/lab/long_timeline.hip)
-#define MTG_DL_STAMP(slot) MTG_TL(P, slot)
-#elif defined(MTG_LAB_TIMING)
-#define MTG_DL_STAMP(slot) do { if (lane == 0 && first) tdbg[slot] = clock64(); } while (0)
-#else
-#define MTG_DL_STAMP(slot) do { } while (0)
-#endif
 
 // C: static configuration with C::D == 1 (one dimension per lane); DL: dimensions of the plan (lanes per trajectory);
 // NP: (tile, direction-pair) units per workgroup (2: four waves, one per SIMD of a CU; 1 where two slabs pairs do not fit
@@ -115,24 +105,15 @@ __device__ __forceinline__ void mtg_dl_preload(const double* __restrict__ times,
 // extra outputs of a launch (OUT bits 0 / 1: cost, d_P): destination pointers (either may be null) and the d_P strides
 struct MtgDlExtra { double* dfree; double* cost; long long ps_b, ps_d, ps_c; };
 
-template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE, int OCC = 1>
+template <class C, int DL, int NP, int OUT, int AUX, bool QUEUE>
 __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ times, const double* __restrict__ dfix,
                                                   double* __restrict__ coeffs, int* status, int* traj_status, int B, int ntiles,
                                                   int nwg, double* ws, int aos, const MtgSeqQueue* q,
-                                                  const MtgDlExtra* xo = nullptr
-#if defined(MTG_LAB_TIMING)
-                                                  , long long* tdbg_base = nullptr
-#endif
-) {
+                                                  const MtgDlExtra* xo = nullptr) {
   static_assert(C::kStatic && C::D == 1 && C::KT >= 2, "dimension-in-lane form: static one-dimension configurations");
   static_assert(DL >= 1 && DL <= 4, "1..4 dimensions per trajectory");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   constexpr int TPW = kWave / DL;
-  // Phase stagger (measurement knob "dl_stagger", bits 8.. of the layout word; 0 = off): every second workgroup starts
-  // `stagger` x 2048 cycles late -- the round-4 test of "persistent one-wave-per-SIMD workgroups of equal work stay phase-locked
-  // (everyone eliminating, then everyone storing)".  They do not: no effect on any variant once the process is warm
-  // (profiles/r04g_stagger_check_fresh_contexts.jsonl)
-  const int stagger = aos >> 8;
   // Layout word, bit 1: SoA with the row stride PADDED to a multiple of 16 trajectories (times[K][Bs], d_fixed[DL][n_fixed][Bs],
   // Bs = (B + 15) & ~15).  A tile's row pieces (16 or 21 trajectories x 8 bytes) then start on 128-byte boundaries whatever B is;
   // with the plain stride B the pieces of B = 12 500 (BASELINE config 5 per GPU: 100 000-byte rows) straddle two 128-byte lines
@@ -140,16 +121,9 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   // (profiles/r04_config5_pmc_traffic.json).
   const unsigned Bs = (aos & 2) ? (((unsigned)B + 15u) & ~15u) : (unsigned)B;
   aos &= 1;
-  if (stagger > 0 && (blockIdx.x & 1)) {
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
-  }
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;      // wave-uniform
   const int pair = w >> 1, dir = w & 1;
-#if defined(MTG_LAB_TIMING)
-  long long* tdbg = tdbg_base + ((long long)(blockIdx.x * (NP * 2) + w)) * 16;
-  if (lane == 0) { tdbg[0] = clock64(); tdbg[14] = wall_clock64(); }
-#endif
   int d = lane / TPW, t = lane - d * TPW;
   const bool dup = d >= DL;            // surplus lanes (64 % DL) duplicate the last lane's work, outputs suppressed
   if (dup) { d = DL - 1; t = TPW - 1; }
@@ -215,11 +189,6 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     fetch(cur, ln.T, ln.fx);
   }
   const int lane_io = lane, t_io = t, d_io = d;
-#if defined(MTG_LAB_TIMING) && !defined(MTG_LAB_TIMELINE)
-  if (lane == 0) tdbg[1] = clock64();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) tdbg[6] = clock64();
-#endif
   constexpr int mm = C::MI;
   constexpr int fmid = C::H - C::popc(mm);
   constexpr int nslots = fmid * (fmid + 1) / 2 + fmid;
@@ -235,18 +204,7 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   MtgSlabOut<C, DL, -1, AUX, MTG_DL_PEND> ioB;
   ioA.init(my_slab, lane_io, t_io, d_io);
   ioB.init(my_slab, lane_io, t_io, d_io);
-#if defined(MTG_LAB_TIMELINE)
-  int tl_iter = 0;
-#endif
   for (int it = blockIdx.x; it < nunits; it += nwg) {
-    [[maybe_unused]] const bool first = it == (int)blockIdx.x;
-#if defined(MTG_LAB_TIMELINE)
-    // rows of 8 stamps behind the 16 x 8192 slots of the first-tile stamps: [wave][tile iteration][slot]
-    P.tl = tl_iter < MTG_LAB_TIMELINE
-               ? tdbg_base + 16 * 8192 + (((long long)(blockIdx.x * (NP * 2) + w)) * MTG_LAB_TIMELINE + tl_iter) * 8 : nullptr;
-    ++tl_iter;
-    MTG_DL_STAMP(0);
-#endif
     const bool has_next = it + nwg < nunits;
     Where nxt = cur;
     if (has_next) {
@@ -268,9 +226,7 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     if (dir == 0) mtg_lane_forward<C, 1>(P, b, ln, wsl, false);
     else mtg_lane_forward<C, -1>(P, b, ln, wsl, false);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
-    MTG_DL_STAMP(2);
     __syncthreads();
-    MTG_DL_STAMP(3);
     [[maybe_unused]] double part = 0.0;
     if (dir == 0) {
       ioA.begin_tile(cur.c, b0, B);
@@ -289,13 +245,6 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
       if (P.cost != nullptr && active && lane_io < TPW) atomicAdd(P.cost + b, sum);
 #endif
     }
-#if defined(MTG_LAB_TIMELINE)
-    MTG_DL_STAMP(4);
-#elif defined(MTG_LAB_TIMING)
-    MTG_DL_STAMP(4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && first) { tdbg[5] = clock64(); tdbg[15] = wall_clock64(); }
-#endif
     if (has_next) {
       fetch(nxt, ln.T, ln.fx);
       cur = nxt;
@@ -306,33 +255,19 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
     // the launch time: what the end of a tile waits for is the other direction's wave, whose back-substitution finishes up to
     // 20 % apart -- profiles/r05_long_timeline.txt.)
     __syncthreads();
-#if defined(MTG_LAB_TIMELINE)
-    MTG_DL_STAMP(5);
-#endif
   }
-#if defined(MTG_LAB_TIMELINE)
-  if (lane == 0) { tdbg[1] = clock64(); tdbg[15] = wall_clock64(); }   // (entry: tdbg[0] / tdbg[14])
-#endif
 }
 
-template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
-__global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_kernel(const double* __restrict__ times,
+template <class C, int DL, int NP, int OUT, int AUX>
+__global__ __launch_bounds__(NP * 2 * kWave, 1) void mtg_solve_dl_kernel(const double* __restrict__ times,
                                                                             const double* __restrict__ dfix,
                                                                             double* __restrict__ coeffs, int* status,
                                                                             int* traj_status, int B, int ntiles, int nwg,
                                                                             int aos, double* ws   // (aos: the 14th dword, still preloaded; ws is first needed late)
-#if defined(MTG_LAB_TIMING)
-                                                                            , long long* tdbg_base
-#endif
 ) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false, OCC>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr
-#if defined(MTG_LAB_TIMING)
-                                                , tdbg_base
-#endif
-  );
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr);
 }
 
-#if !defined(MTG_LAB_TIMING)
 // solves that also return the cost and / or d_P (OUT = 3; round 3): same body, the cost as per-lane partial sums (dimension
 // lane x direction) added atomically to cost[b], d_P written by the lane that owns the vertex and the dimension
 template <class C, int DL, int NP, int AUX>
@@ -341,16 +276,15 @@ __global__ __launch_bounds__(NP * 2 * kWave, 1) void mtg_solve_dl_extra_kernel(c
                                                                               double* __restrict__ coeffs, int* status,
                                                                               int* traj_status, int B, int ntiles, int nwg,
                                                                               int aos, double* ws, MtgDlExtra xo) {
-  mtg_solve_dl_body<C, DL, NP, 3, AUX, false, 1>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, &xo);
+  mtg_solve_dl_body<C, DL, NP, 3, AUX, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, &xo);
 }
 
 // the queue form: same body, the batches' pointer triples in the kernel arguments (mtg_solve_linear_sequence)
-template <class C, int DL, int NP, int OUT, int AUX, int OCC = MTG_DL_OCC>
-__global__ __launch_bounds__(NP * 2 * kWave, OCC) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
+template <class C, int DL, int NP, int OUT, int AUX>
+__global__ __launch_bounds__(NP * 2 * kWave, 1) void mtg_solve_dl_queue_kernel(int* status, int B, int ntiles, int nwg,
                                                                                   int aos, double* ws, MtgSeqQueue q) {
-  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true, OCC>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, aos, &q);
+  mtg_solve_dl_body<C, DL, NP, OUT, AUX, true>(nullptr, nullptr, nullptr, status, nullptr, B, ntiles, nwg, ws, aos, &q);
 }
-#endif
 
 // ---- cross-structure launch: the buckets of a mixed request (BASELINE config 4: N in {8, 10, 12} x K in {4, 8, 16, 32}) in ONE
 // launch, each unit (one tile = 64 / DL trajectories, both chain directions) running its own static configuration.  The

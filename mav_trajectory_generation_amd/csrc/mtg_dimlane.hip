@@ -12,7 +12,7 @@ const MtgDimlaneEntry* mtg_dimlane_more_h4b(int* count);
 const MtgDimlaneEntry* mtg_dimlane_more_h5b(int* count);
 const MtgDimlaneEntry* mtg_dimlane_more_h6b(int* count);
 
-const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask, int occ) {
+const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask) {
   typedef const MtgDimlaneEntry* (*TableFn)(int*);
   static const TableFn tables[] = {mtg_dimlane_main,    mtg_dimlane_more_h4,  mtg_dimlane_more_h5, mtg_dimlane_more_h6,
                                    mtg_dimlane_more_h4b, mtg_dimlane_more_h5b, mtg_dimlane_more_h6b};
@@ -21,7 +21,7 @@ const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const i
     const MtgDimlaneEntry* tab = fn(&n);
     for (int i = 0; i < n; ++i) {
       const MtgDimlaneEntry& e = tab[i];
-      if (e.h != h || e.dl != dl || e.k != k || e.dv != deriv || e.occ != occ) continue;
+      if (e.h != h || e.dl != dl || e.k != k || e.dv != deriv) continue;
       bool ok = mask[0] == e.ms && mask[k] == e.me;
       for (int v = 1; v < k && ok; ++v) ok = mask[v] == e.mi;
       if (ok) return &e;

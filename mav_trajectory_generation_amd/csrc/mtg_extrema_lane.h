@@ -124,14 +124,11 @@ MTGX_HD void horner2_multi(const double* a, const double (&x)[NCH], double (&f)[
     for (int c = 0; c < NCH; ++c) f[c] = fma(f[c], x[c], a[j]);
   }
 }
-#ifndef MTGX_CHAINS
 // brackets a lane refines at once (and partition points it evaluates at once).  2: with value and derivative that is four
 // independent FMAs per Horner step -- the 4-cycle issue already covers the 8-cycle dependent latency.  4 measured 20 % SLOWER at
 // every launch size (round 5, profiles/r05_extrema_lanes_per_search.jsonl: 10k x 8 segments 237 vs 192 us): most levels have one
 // or two brackets per lane, the idle chains are pure instructions.
-#define MTGX_CHAINS 2
-#endif
-constexpr int kChains = MTGX_CHAINS;
+constexpr int kChains = 2;
 
 // Bisection-safeguarded Newton on kChains brackets at once (each: f of opposite sign at its ends, monotone inside); a bracket that
 // has converged keeps its x while the others finish.  Same step rule as the one-bracket form of round 3.

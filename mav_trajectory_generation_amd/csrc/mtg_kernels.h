@@ -119,11 +119,6 @@ __host__ __device__ constexpr size_t mtg_stage_doubles() { return (size_t)64 * (
 template <class C>
 constexpr int mtg_waves_per_simd() { return (C::kStatic && C::D <= 2) ? 2 : 1; }
 
-#if defined(MTG_TIMING)   // measurement-only build: per-wave phase timestamps (shader cycles) into P.ws
-#define MTG_TSTAMP(slot) do { if (tdo && lane == 0 && tile == (int)blockIdx.x) tdbg[slot] = clock64(); } while (0)
-#else
-#define MTG_TSTAMP(slot) do { } while (0)
-#endif
 
 template <class C, int OUT>
 __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_kernel(MtgParams P, int ntiles) {
@@ -169,17 +164,6 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
   const double* other = xch + (size_t)(1 - dir) * nslots * kWave + lane;
   double* wsl = (P.ws && !C::kStatic)
                     ? P.ws + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x) : nullptr;
-#if defined(MTG_TIMING)
-  long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + dir) * 16;
-  const bool tdo = C::kStatic && P.ws != nullptr;
-  if (tdo && lane == 0) {   // [14]/[15]: device-wide 100 MHz clock; [13]: where the wave runs (HW_ID | XCC_ID << 32)
-    tdbg[0] = clock64();
-    tdbg[14] = wall_clock64();
-    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
-    tdbg[13] = (long long)hw | ((long long)xcc << 32);
-  }
-#endif
   // Software prefetch (register-rich static variants): the inputs of this workgroup's NEXT tile are requested
   // before the current tile is solved and land while it computes (measured: the exposed input latency was
   // ~10k of ~40k cycles per tile at B = 1M).  The light 2-waves-per-SIMD variants have no registers to spare
@@ -199,19 +183,9 @@ __global__ __launch_bounds__(kBlock, mtg_waves_per_simd<C>()) void mtg_solve_ker
     if (dir == 0) mtg_lane_forward<C, 1>(Pt, b, ln, wsl, need_preload);
     else mtg_lane_forward<C, -1>(Pt, b, ln, wsl, need_preload);
     mtg_pack_mid<C>(ln, mm, mine, kWave);
-    MTG_TSTAMP(1);
     __syncthreads();
-    MTG_TSTAMP(2);
     if (dir == 0) mtg_lane_finish<C, 1, OUT>(Pt, b, ln, wsl, other, kWave, io, active);
     else mtg_lane_finish<C, -1, OUT>(Pt, b, ln, wsl, other, kWave, io, active);
-    MTG_TSTAMP(3);
-#if defined(MTG_TIMING)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    MTG_TSTAMP(4);
-#if defined(MTG_TIMING)
-    if (tdo && lane == 0 && tile == (int)blockIdx.x) tdbg[15] = wall_clock64();
-#endif
     if (has_next) {
 #pragma unroll
       for (int j = 0; j < C::KCS; ++j) ln.T[j] = nT[j];
@@ -495,15 +469,13 @@ struct MtgDimlaneEntry {
   int lo_per_cu, hi_per_cu;   // default form while lo * CUs <= workgroups <= hi * CUs / 2 (hi = 0: no upper limit; hi counts HALF workgroups per CU)
   size_t lds;         // dynamic LDS per workgroup
   size_t ws_per_lane; // long-chain variants (MtgCfg::WSJ > 0): workspace bytes per resident lane (grid * np * 128 lanes), else 0
-  // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads; policy = coefficient store
-  // cache policy (0 nt sc1, 1 sc1, 2 write-back); aos: input layout (0 canonical SoA, 1 canonical AoS); returns 0 or -1
-  // (attribute / launch set-up failed)
+  // enqueues one launch on `stream` (a hipStream_t): grid workgroups of np * 128 threads (coefficient stores: nt sc1); aos: input
+  // layout (0 canonical SoA, 1 canonical AoS, 2 padded SoA); returns 0 or -1 (attribute / launch set-up failed)
   int (*launch)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
-                int* traj_status, int B, int ntiles, int policy, double* ws, int aos);
+                int* traj_status, int B, int ntiles, double* ws, int aos);
   // a queue of batches in one launch (mtg_solve_linear_sequence; main-table variants only, else null): ntiles = tiles of
   // all batches (q->n * q->tiles_per_batch)
   int (*launch_queue)(void* stream, int grid, const MtgSeqQueue* q, int* status, int B, int ntiles, double* ws, int aos);
-  int occ;            // waves per SIMD the kernel's registers allow: 1, or 2 for the throughput twins (MTG_DLO)
   // solves that also return the cost and / or d_P (either pointer may be null; cost zeroed by the caller; ps_*: d_P strides
   // in doubles); main-table variants only, else null
   int (*launch_extra)(void* stream, int grid, const double* times, const double* dfix, double* coeffs, int* status,
@@ -514,7 +486,7 @@ struct MtgDimlaneEntry {
 // dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])
 int mtg_any_cfg_index(const MtgStaticEntry* e);
 SolveMultiFn mtg_multi_any_fn(int dg, int variant);
-const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask, int occ = 1);
+const MtgDimlaneEntry* mtg_find_dimlane(int h, int dl, int k, int deriv, const int* mask);
 
 // cross-structure dimension-in-lane launches (mtg_dimlane.h: mtg_solve_dl_any_kernel)
 struct MtgDlAnyItem {     // one bucket

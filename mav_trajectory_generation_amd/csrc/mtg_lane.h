@@ -57,16 +57,7 @@ struct MtgParams {
   // tile -> (variant, tile of the real batch); pert_seg is that tile's perturbed segment (-1: none).
   int pert_on, pert_seg, pert_tpv;   // pert_tpv: tiles per variant
   double pert_h, pert_corr, pert_lo;
-#if defined(MTG_LAB_TIMELINE)
-  long long* tl;   // measurement build (tools/lab/long_timeline.hip): this wave's stamp row of the current tile, or null
-#endif
 };
-// measurement build: shader-clock stamp `slot` of the current tile by lane 0 (compiled out of the product)
-#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
-#define MTG_TL(P, slot) do { if ((threadIdx.x & 63) == 0 && (P).tl != nullptr) (P).tl[slot] = clock64(); } while (0)
-#else
-#define MTG_TL(P, slot) do { } while (0)
-#endif
 
 // segment time as the virtual problem sees it (identity unless a perturbed-time launch)
 MTG_HD double mtg_perturb(const MtgParams& P, int seg, double T) {
@@ -87,9 +78,6 @@ constexpr int mtg_ainv_offset(int n) {
   return off;
 }
 
-#ifndef MTG_FACTOR_STORE
-#define MTG_FACTOR_STORE 1     // (0: the round-3 form, G itself in the workspace -- A/B builds)
-#endif
 #ifndef MTG_PARTIAL_ALL
 // 1: EVERY kernel's forward step eliminates partially (Schur update from W = L^-1 U, the back-substitution for G after it).  Built and
 // measured in round 4 (profiles/r04v_*): the K = 8 kernels are unchanged at 100k (38.0 / 49.5 / 93.0 us), the bench line 0.668-0.671
@@ -98,18 +86,6 @@ constexpr int mtg_ainv_offset(int n) {
 // positive pivot and is not flagged.  Off until the pivot test is a relative threshold.
 // (Round 5: rank deficiency is structural now -- see mtg_ldl -- so the association no longer decides what is flagged.)
 #define MTG_PARTIAL_ALL 0
-#endif
-#ifndef MTG_LDS_RING
-// 1: long static chains whose workspace steps are split between the wave's LDS and global memory (MtgCfg::LSJ < MtgCfg::WSJ)
-// bring the global steps back THROUGH the LDS step slots during the backward sweep (MtgCfg::kRing).  Built and measured in
-// round 5 (tools/build_ring_ab.sh, tools/ab_lds_ring.py, profiles/r05_lds_ring_ab.txt): bit-identical coefficients, every
-// long-chain parity test green, and NO change in time (N = 12 / K = 32 at 100k: 474.6 us without, 481.3 us with; K = 17 .. 31
-// and N = 10 / K = 50 within +-2 %) -- the memory round trip of the workspace steps is not what these kernels wait for.
-// Off: the direct form needs no hand-counted s_waitcnt.
-#define MTG_LDS_RING 0
-#endif
-#ifndef MTG_FS_PARTIAL
-#define MTG_FS_PARTIAL 1       // (0: factor-store steps still solve for G in the forward sweep -- A/B builds)
 #endif
 template <int H_, int D_, int KT_, int MS_, int MI_, int ME_, int DV_ = 0, int PT_ = 0, int WS_ = 0, int DLW_ = 0, int LS_ = 0, int RS_ = 0>
 struct MtgCfg {
@@ -149,19 +125,12 @@ struct MtgCfg {
   // G = Dtilde^-1 U (f * f numbers).  The back-substitution then forms x_l = g - Dtilde^-1 (U x_r) with U rebuilt from the
   // constant table and the segment time (mtg_bwd_backsub_fs): ~2 f^2 more FP64 operations per step and dimension lane, on a
   // kernel whose time is the workspace round trip -- 14 -> 10 rows per step for N = 12, 10 -> 8 for N = 10, 6 -> 5 for N = 8.
-  static constexpr bool kFS = MTG_FACTOR_STORE != 0 && DLW_ > 0 && ((kStatic && WS_ > 0) || kRolled);
+  static constexpr bool kFS = DLW_ > 0 && ((kStatic && WS_ > 0) || kRolled);
   // (factor-store entries are standard shapes: with fully fixed trajectory ends R_PP is positive definite for every T > 0)
   static_assert(!kFS || (MS_ == (1 << H_) - 1 && ME_ == (1 << H_) - 1), "factor-store kernels: trajectory ends fully fixed");
   static constexpr int FCNT = kFS ? FMAXW * (FMAXW + 1) / 2 : FMAXW * FMAXW;   // kept numbers per step besides g
   static constexpr int WSE = DLW > 0 ? (FCNT + DLW - 1) / DLW + FMAXW
                                      : FMAXW * FMAXW + D_ * FMAXW;   // workspace rows per step (free x free of G, free of g)
-  // Ring (round 5; chains with LDS steps AND global steps): the LSJ step slots of the wave's LDS are a ring in the backward
-  // sweep.  As soon as step j has been consumed from its slot, global step j - LSJ is requested INTO that slot by direct-to-LDS
-  // loads (global_load_lds_dwordx4: 16 bytes per lane, one instruction per two workspace rows, no registers), LSJ - 1 steps
-  // before it is needed; the back-substitution then reads every workspace step from the LDS.  (The direct form issues a
-  // global step's loads one step ahead, into registers.)  Same numbers, same order of operations: bit-identical to the
-  // direct form -- and, measured, not faster (see MTG_LDS_RING).
-  static constexpr bool kRing = MTG_LDS_RING != 0 && kStatic && DLW_ > 0 && LS_ >= 2 && WS_ > LS_ && WSE % 2 == 0;
   // RS_ != 0 (with DLW_): the REGISTER steps keep G shared as well -- lane of dimension k holds elements k, DLW + k, ... of
   // G (GROWS doubles instead of up to H * H) and fetches its siblings' elements with ds_bpermute at back-substitution time
   // (the three lanes of a trajectory compute identical G): half the registers per step, i.e. twice the steps on chip.
@@ -207,7 +176,9 @@ MTG_HD void mtg_store2(double* p, double a, double b) {
 // order: the compiler has to wait for it with vmcnt(0) lgkmcnt(0) -- i.e. each backward step waited for the acknowledgement of the
 // coefficient stores issued AFTER its workspace loads (found in round 6: the N = 12 / K = 32 kernel had 20 such waits per tile and
 // direction).  As global_load / global_store the waits are counted (vmcnt(n): only what was issued before the loads).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MTG_WS_FLAT)   // (MTG_WS_FLAT: the A/B build of tools/gpu_r06_variants.sh)
+// Measured (profiles/r06a_flat_vs_global_ab.jsonl, r06a_other_k_ws_global.jsonl): bit-identical; the static bodies inside the noise,
+// the run-time-K body (most steps through the workspace) 1-6 % faster at K = 100.
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double mtg_glb_double;
 __device__ __forceinline__ mtg_glb_double* mtg_glb(double* p) { return (mtg_glb_double*)p; }
 __device__ __forceinline__ const mtg_glb_double* mtg_glb(const double* p) { return (const mtg_glb_double*)p; }
@@ -265,22 +236,18 @@ MTG_HD double mtg_rcp(double x) {
 
 // Table bases.  Static mode: compile-time offset => every entry folds to an immediate (no SGPR
 // pressure, trivially rematerialisable).  Generic mode: runtime offset, laundered (see above).
+// (Round 6, looked at and not built further: the immediates cost two s_mov_b32 per constant whose low word is not zero -- 2658 in
+// the N = 12 / K = 32 body, 10 % of its instructions.  Reading the static bodies' constants with s_load instead (the laundered
+// offset) removes them and puts 1465 s_add_u32 / s_addc_u32 pairs, 1685 s_load, 730 more s_waitcnt and 350 more spilled SGPRs
+// (2170 v_readlane) in their place.)
 template <class C> MTG_HD const double* mtg_h1(const MtgParams& P) {
-#if defined(MTG_TABLE_SLOAD)
-  if constexpr (C::kCT) return kH1 + mtg_launder(C::H1OFF); else return kH1 + mtg_launder(P.h1off);
-#else
   if constexpr (C::kCT) return kH1 + C::H1OFF; else return kH1 + mtg_launder(P.h1off);
-#endif
 }
 template <class C> MTG_HD const double* mtg_q1(const MtgParams& P) {
   if constexpr (C::kCT) return kQ1 + C::H1OFF; else return kQ1 + mtg_launder(P.h1off);
 }
 template <class C> MTG_HD const double* mtg_ainv(const MtgParams& P) {
-#if defined(MTG_TABLE_SLOAD)
-  if constexpr (C::kCT) return kAinvLo + mtg_launder(C::AINVOFF); else return kAinvLo + mtg_launder(P.ainvoff);
-#else
   if constexpr (C::kCT) return kAinvLo + C::AINVOFF; else return kAinvLo + mtg_launder(P.ainvoff);
-#endif
 }
 template <class C> MTG_HD int mtg_deriv(const MtgParams& P) {
   if constexpr (C::kCT) return C::DV; else return P.deriv;
@@ -600,7 +567,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
   mtg_ldl<H>(A, dinv, ml, ln.flags);
 
   const double* hrr = mtg_h1<C>(P);
-  if constexpr ((C::kFS && MTG_FS_PARTIAL != 0) || MTG_PARTIAL_ALL != 0) {
+  if constexpr (C::kFS || MTG_PARTIAL_ALL != 0) {
     // Factor store, partial elimination: nothing in the FORWARD sweep needs G = Dtilde^-1 U itself.  With W = L^-1 U and
     // z = L^-1 rv (forward substitution only), U^T G = W^T D^-1 W and U^T g = W^T D^-1 z: the carried Schur complement is what
     // f pivots of the 2f x 2f block [Dtilde U; U^T a_rr] leave behind.  The back-substitution half of the solve is needed for
@@ -1232,41 +1199,6 @@ template <class C>
 __device__ __forceinline__ mtg_lds_double* mtg_lds_step(const MtgParams& P, int j) {
   return (mtg_lds_double*)(size_t)(P.lds_steps + (unsigned)(j - (C::WSJ - C::LSJ)) * (unsigned)(C::WSE * 64 * sizeof(double)));
 }
-// MtgCfg::kRing: byte address of this lane's column in the slot workspace step j uses (any j < WSJ; steps LSJ apart share one)
-template <class C>
-__device__ __forceinline__ unsigned mtg_lds_ring_addr(const MtgParams& P, int j) {
-  constexpr int L = C::LSJ > 0 ? C::LSJ : 1;
-  const int s = (((j - (C::WSJ - C::LSJ)) % L) + L) % L;
-  return P.lds_steps + (unsigned)s * (unsigned)(C::WSE * 64 * sizeof(double));
-}
-// One workspace step, global -> LDS slot, asynchronously.  src: this lane's source address for rows 0 / 1 (lanes 0-31 the
-// first row's 16-byte pieces, lanes 32-63 the second row's); slot: the WAVE's slot address (uniform).  The instruction
-// writes lane l's 16 bytes to M0 + 16 l, i.e. two consecutive 512-byte rows.  The compiler does NOT track these writes
-// (no s_waitcnt before a later ds_read of the slot: checked in the ISA) -- the consumer waits with mtg_wait_vmcnt.
-template <class C>
-__device__ __forceinline__ void mtg_ws_prefetch_lds(const double* src, long long ws_stride, unsigned slot) {
-  typedef __attribute__((address_space(1))) const void gvoid;
-  typedef __attribute__((address_space(3))) void lvoid;
-  asm volatile("" ::: "memory");   // after the LDS reads that consumed the slot's previous step
-#pragma unroll
-  for (int q = 0; q < C::WSE / 2; ++q) {
-    __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)(size_t)(slot + (unsigned)q * 1024u), 16, 0, 0);
-    src += 2 * ws_stride;
-  }
-  asm volatile("" ::: "memory");
-}
-// s_waitcnt vmcnt(n) as a compiler-level memory barrier; n folds to a constant in the unrolled loops that call it.
-__device__ __forceinline__ void mtg_wait_vmcnt(int n) {
-#define MTG_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    MTG_VMCNT_CASE(1) MTG_VMCNT_CASE(2) MTG_VMCNT_CASE(3) MTG_VMCNT_CASE(4) MTG_VMCNT_CASE(5) MTG_VMCNT_CASE(6)
-    MTG_VMCNT_CASE(7) MTG_VMCNT_CASE(8) MTG_VMCNT_CASE(9) MTG_VMCNT_CASE(10) MTG_VMCNT_CASE(11) MTG_VMCNT_CASE(12)
-    MTG_VMCNT_CASE(13) MTG_VMCNT_CASE(14) MTG_VMCNT_CASE(15) MTG_VMCNT_CASE(16) MTG_VMCNT_CASE(17) MTG_VMCNT_CASE(18)
-    MTG_VMCNT_CASE(19) MTG_VMCNT_CASE(20) MTG_VMCNT_CASE(21) MTG_VMCNT_CASE(22) MTG_VMCNT_CASE(23) MTG_VMCNT_CASE(24)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef MTG_VMCNT_CASE
-}
 #endif
 template <int DL>
 MTG_HD double mtg_pick(int d, const double (&c)[DL]) {
@@ -1414,13 +1346,6 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
   constexpr int H = C::H, D = C::D;
   ln.flags = 0;
   if (do_preload) mtg_preload<C, DIR>(P, b, ln);
-#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-  {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (DIR > 0 ? 0 : 1)) * 16;
-    if (C::kStatic && P.ws != nullptr && (threadIdx.x & 63) == 0 && b < 64 * (long long)gridDim.x) tdbg[5] = clock64();
-  }
-#endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
@@ -1435,16 +1360,7 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
-#if defined(MTG_TIE_NEXT) && defined(__HIP_DEVICE_COMPILE__)
-      // Scheduling hint (no instruction): the T-only work of step j+1 (scales, block assembly, right-hand-side partial
-      // sums) may not start before step j's dependent chain does -- it then fills that chain's latency gaps instead of
-      // being hoisted in front of all chains.
-      if (j + 1 < KC) asm("" : "+v"(ln.T[j + 1]) : "v"(ln.Sc[H - 1][H - 1]));
-#endif
       const int ml = mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mr = mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j));
-#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
-      if (j == 1 || j == 2) { asm volatile("" : "+v"(ln.Sc[H - 1][H - 1])); MTG_TL(P, j == 1 ? 1 : 7); }   // steps 0 / 1 done
-#endif
       if (j < C::WSJ) {
         double G[H][H], g[D][H];
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
@@ -1528,17 +1444,8 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
   const int mm = C::kRolled ? C::MI : mtg_mask<C>(P, vm);   // rolled: K >= 2, the middle vertex is interior
   double xr[D][H];
   mtg_solve_mid<C, DIR>(P, b, ln, vm, mm, other, stride, xr);
-#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-  long long* tdbg = reinterpret_cast<long long*>(P.ws) + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (DIR > 0 ? 0 : 1)) * 16;
-  const bool tdo = C::kStatic && P.ws != nullptr && (threadIdx.x & 63) == 0 && b < 64 * (long long)gridDim.x;
-  if (tdo) tdbg[6] = clock64();
-#endif
   if (DIR > 0) mtg_store_free<C, OUT>(P, b, vm, mm, xr);
   double cost = 0.0;
-#if defined(MTG_LAB_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(xr[0][0]));
-  MTG_TL(P, 6);   // middle vertex solved
-#endif
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
     // steps below C::WSJ: (G, g) come back from the workspace, requested one step ahead -- right after the previous
@@ -1549,23 +1456,6 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
     if constexpr (C::kRegShared) {   // byte addresses (4 * lane) of this trajectory's dimension lanes, for ds_bpermute
 #pragma unroll
       for (int k = 0; k < C::DLW; ++k) perm[k] = 4 * ((int)(threadIdx.x & 63) + (int)P.ws_share + k * (64 / C::DLW));
-    }
-#endif
-    // MtgCfg::kRing.  JTOP: steps below it come back from the workspace.  ringed(p): global step p is brought into the slot
-    // of step p + LSJ once that step has been consumed (iteration p + LSJ of the loop below), and read from there.
-    [[maybe_unused]] constexpr int JTOP = C::WSJ < KC ? C::WSJ : KC;
-    [[maybe_unused]] constexpr int RG = C::WSE / 2;   // direct-to-LDS instructions per step
-    [[maybe_unused]] auto ringed = [&](int p) {
-      return C::kRing && p >= 0 && p < C::WSJ - C::LSJ && p + C::LSJ < JTOP &&
-             C::popc(mtg_mask<C>(P, mtg_vl<DIR>(C::KT, p))) < H;   // (a step whose left vertex is fixed keeps nothing)
-    };
-#if defined(__HIP_DEVICE_COMPILE__)
-    [[maybe_unused]] const double* ring_src = nullptr;
-    [[maybe_unused]] unsigned ring_lane8 = 0;
-    if constexpr (C::kRing) {
-      const int lane = (int)(threadIdx.x & 63);
-      ring_src = wsl - lane + 2 * (lane & 31) + (lane >> 5) * P.ws_stride;
-      ring_lane8 = (unsigned)lane * 8u;
     }
 #endif
     auto request = [&](int j) {
@@ -1579,19 +1469,7 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
       }
       if constexpr (C::DLW > 0) {
-        if (ringed(j)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          // Everything issued before step j's group must have landed: the groups of steps j - 1 .. j - LSJ + 1 (those that
-          // exist) were issued after it -- this call runs in iteration j + 1, after that iteration's group -- and so were
-          // an unknown number of coefficient stores (the counter retires in order, so they only make the bound safer).
-          int later = 0;
-#pragma unroll
-          for (int p = j - 1; p > j - C::LSJ; --p) later += ringed(p) ? RG : 0;
-          mtg_wait_vmcnt(later);
-          mtg_ws_load_shared<C>((mtg_lds_double*)(size_t)mtg_lds_ring_addr<C>(P, j), 64, P.ws_share, Gw, gw,
-                                mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)), mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
-#endif
-        } else if (j >= C::WSJ - C::LSJ) {
+        if (j >= C::WSJ - C::LSJ) {
 #if defined(__HIP_DEVICE_COMPILE__)
           mtg_ws_load_shared<C>(mtg_lds_step<C>(P, j), 64, P.ws_share, Gw, gw, mtg_mask<C>(P, mtg_vl<DIR>(C::KT, j)),
                                 mtg_mask<C>(P, mtg_vr<DIR>(C::KT, j)));
@@ -1624,21 +1502,11 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         }
         // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
         // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (C::kRing) {   // step j's slot is free (its reads fed the back-substitution above): refill it
-          if (j < JTOP && ringed(j - C::LSJ))
-            mtg_ws_prefetch_lds<C>(ring_src + (long long)(j - C::LSJ) * C::WSE * P.ws_stride, P.ws_stride,
-                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(mtg_lds_ring_addr<C>(P, j) - ring_lane8)));
-        }
-#endif
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
       } else {
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);
       }
-#if defined(MTG_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-      if (tdo && j < 8) tdbg[7 + j] = clock64();
-#endif
     }
   } else {
     const int kc = DIR > 0 ? (K + 1) / 2 : K / 2;

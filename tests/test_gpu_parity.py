@@ -506,6 +506,28 @@ def mel_err(got, ref):
     return float((np.abs(got - ref) / scale).max())
 
 
+def mel_assert(got, ref, n, d, masks, times, d_fixed, tol):
+    """Gradient against the reference-side value, per trajectory within `tol` of its largest component.  The forward difference
+    amplifies the cost's float64 evaluation error by J / (0.1 |g|): a trajectory between tol and 10 tol (seen: 1.14e-9 on the
+    16-segment case, against the reference's member and its restatement alike) is arbitrated by the 50-digit solve of the same K + 1
+    problems -- accepted only when the HIP gradient is within tol of THAT (as the coefficient parity tests do)."""
+    scale = np.maximum(np.abs(ref).max(axis=1), 1e-300)
+    err = np.abs(got - ref).max(axis=1) / scale
+    assert err.max() <= 10 * tol, err
+    for b in np.nonzero(err > tol)[0]:
+        from oracle import oracle_mp
+        k = times.shape[1]
+        j0 = oracle_mp.solve(n, d, masks, times[b], d_fixed[b])[2]
+        truth = np.zeros(k)
+        for s_ in range(k):
+            tb = times[b].copy()
+            for i in range(k):
+                tb[i] += 0.1 if i == s_ else -0.1 / (k - 1.0)
+            truth[s_] = (oracle_mp.solve(n, d, masks, np.maximum(0.1, tb), d_fixed[b])[2] - j0) / 0.1
+        e_hip, e_ref = np.abs(got[b] - truth).max() / scale[b], np.abs(ref[b] - truth).max() / scale[b]
+        assert e_hip <= tol, (int(b), float(err[b]), float(e_hip), float(e_ref))
+
+
 @pytest.mark.parametrize("name", MEL_NAMES)
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 def test_mellinger_entry_vs_the_references_own_member(ctx, name, layout):
@@ -528,7 +550,7 @@ def test_mellinger_entry_vs_the_references_own_member(ctx, name, layout):
     got = grad.cpu().numpy() if layout == "aos" else grad.t().cpu().numpy()
     tol = MEL_TOL if n <= 10 else 5e-8          # N = 12: the reference's own float64 evaluation (tol_for of test_gpu_vs_reference.py)
     assert np.abs(j0.cpu().numpy() / MEL[f"{name}/cost_ref"] - 1).max() < tol
-    assert mel_err(got, MEL[f"{name}/grad_ref"]) <= (10 * tol if n > 10 else tol)
+    mel_assert(got, MEL[f"{name}/grad_ref"], n, d, masks, times, d_fixed, 10 * tol if n > 10 else tol)
     if k == 1:
         assert np.all(got == 0.0)
     plan.close()
@@ -623,7 +645,7 @@ def test_mellinger_cost_gradient_entry(ctx, n, d, k, dim, masks, bsz, layout):
     nchk = min(bsz, 6)
     jd, want = onp.mellinger_cost_gradient(n, d, masks, times[:nchk], d_fixed[:nchk])
     assert np.allclose(j0.cpu().numpy()[:nchk], jd, rtol=1e-8)
-    assert mel_err(got[:nchk], want) <= MEL_TOL
+    mel_assert(got[:nchk], want, n, d, masks, times[:nchk], d_fixed[:nchk], MEL_TOL)
     if k == 1:
         assert np.all(got == 0.0)
     plan.close()

@@ -22,9 +22,6 @@
 #ifndef LT_D
 #define LT_D 3
 #endif
-#ifndef LT_OCC
-#define LT_OCC 1
-#endif
 constexpr int H = LT_H, N = 2 * H, K = LT_K, D = LT_D, NP = LT_NP;
 using C = MtgCfg<H, 1, K, (1 << H) - 1, 1, (1 << H) - 1, H - 1, 0, LT_WS, ((LT_WS > 0 || LT_RS) ? D : 0), LT_LS, LT_RS>;
 constexpr int NF = 2 * H + (K - 1);
@@ -60,10 +57,10 @@ int main(int argc, char** argv) {
   constexpr int TPW = 64 / D;
   const int ntiles = (B + TPW - 1) / TPW;
   const int nunits = (ntiles + NP - 1) / NP;
-  const int nwg = std::min((NP == 1 ? 512 : 256) * LT_OCC, nunits);
+  const int nwg = std::min(NP == 1 ? 512 : 256, nunits);
   CK(hipMalloc(&ws, (size_t)nwg * (NP * 128) * std::max(1, C::WSJ * C::WSE) * 8));
   int* dstat; CK(hipMalloc(&dstat, 4)); CK(hipMemset(dstat, 0, 4));
-  auto kern = mtg_solve_dl_kernel<C, D, NP, 0, 18, LT_OCC>;
+  auto kern = mtg_solve_dl_kernel<C, D, NP, 0, 18>;
   const size_t lds = mtg_dl_lds_bytes<C, D, NP>();
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)kern));
@@ -95,9 +92,9 @@ int main(int argc, char** argv) {
     amax = std::max(amax, std::fabs(x)); finite = finite && std::isfinite(x);
   }
   const double bytes = 8.0 * (K + D * NF + K * D * N) * B;
-  std::printf("{\"tag\": \"%s\", \"N\": %d, \"K\": %d, \"D\": %d, \"B\": %d, \"NP\": %d, \"occ\": %d, \"wg\": %d, \"lds\": %zu, \"vgprs\": %d, \"scratch\": %zu, "
+  std::printf("{\"tag\": \"%s\", \"N\": %d, \"K\": %d, \"D\": %d, \"B\": %d, \"NP\": %d, \"wg\": %d, \"lds\": %zu, \"vgprs\": %d, \"scratch\": %zu, "
               "\"us_mean\": %.2f, \"us_best\": %.2f, \"frac_8TBps\": %.4f, \"status\": %d, \"finite\": %s, \"max_abs\": %.6g, \"hash\": \"%016llx\"}\n",
-              tag, N, K, D, B, NP, LT_OCC, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
+              tag, N, K, D, B, NP, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
               finite ? "true" : "false", amax, (unsigned long long)hsh);
   return 0;
 }
