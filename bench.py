@@ -79,6 +79,10 @@ def parse_args(argv=None):
                     "ncclCommInitRank on a watchdog thread (--mtg-comm-init-timeout); a rank that cannot join in time makes ALL "
                     "ranks fall back to the torch.distributed figure, and the line says so")
     ap.add_argument("--mtg-comm-init-timeout", type=float, default=90.0, help="seconds the watchdog waits for ncclCommInitRank")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic in this invocation (default at N = 1: "
+                    "after its own measurements rank 0 re-runs this command's timed region as child processes under rocprofv3 --pmc "
+                    "FETCH_SIZE / WRITE_SIZE -- separate passes, calibrated in the same visit, tools/gpu_profile3.sh -- which adds about "
+                    "a minute; without it, or when rocprofv3 is not there, the committed profile of the same arguments is quoted)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0, help="length of the `sustained` run: continuous queue launches "
                     "over the HBM-sized rotation with the shader clock probed next to them (0: skip)")
     ap.add_argument("--exercise-collectives", action="store_true",
@@ -167,6 +171,48 @@ def profile_traffic(batch, config, steps, warmup):
                 "algorithmic_bytes_per_step": d.get("algorithmic_bytes_per_step"), "bench_args_of_the_profile": d.get("bench_args"),
                 "note": d.get("note", "separate rocprofv3 --pmc run of this command")}
     return None
+
+
+def live_traffic(args, batch):
+    """roofline.traffic measured BY THIS INVOCATION (a stored profile cannot notice a regression between
+    the profile visit and the run): the same command's timed region re-run as child processes under rocprofv3 --pmc (FETCH_SIZE and
+    WRITE_SIZE in separate passes with --kernel-trace only, the counters calibrated on 2 GiB streams in the same visit -- exactly
+    tools/gpu_profile3.sh, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  None when that is not possible here."""
+    import shutil
+    import subprocess
+    if os.environ.get("MTG_BENCH_PROFILED_CHILD") or not shutil.which("rocprofv3"):
+        return None
+    calib = os.path.join(ROOT, "tools", "micro", "fetch_calib")
+    if not os.path.exists(calib):
+        return None
+    tag = f"live{os.getpid()}"
+    argv = ["--config", str(args.config), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(batch),
+            "--layout", args.layout, "--dims", args.dims, "--sequence", args.sequence, "--settle-ms", str(args.settle_ms),
+            "--sustained-seconds", "0", "--no-live-traffic"]
+    if args.buffer_sets is not None:
+        argv += ["--buffer-sets", str(args.buffer_sets)]
+    env = dict(os.environ, MTG_BENCH_PROFILED_CHILD="1", GRAFT_REPO_ROOT=ROOT)
+    t0 = time.perf_counter()
+    try:
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "gpu_profile3.sh"), tag] + argv, env=env, cwd=ROOT, timeout=420,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")
+        d = json.load(open(path))
+        for f in (f"{tag}_pmc_traffic.json", f"{tag}_kernel_stats.csv", f"{tag}_kernel_trace_solve_launches.csv", f"{tag}_stats_bench.json"):
+            try:
+                os.remove(os.path.join(ROOT, "gpurun_out", f))
+            except OSError:
+                pass
+        if not d.get("hbm_bytes_per_step"):
+            return None
+        return {"file": None, "measured": "by this invocation: child runs of the same command under rocprofv3 --pmc (tools/gpu_profile3.sh)",
+                "seconds": time.perf_counter() - t0, "hbm_bytes_per_step": d.get("hbm_bytes_per_step"),
+                "hbm_read_bytes_per_step": d.get("hbm_read_bytes_per_step"), "hbm_write_bytes_per_step": d.get("hbm_write_bytes_per_step"),
+                "algorithmic_bytes_per_step": d.get("algorithmic_bytes_per_step"), "kernel": d.get("kernel"),
+                "rocprof_us_per_step": d.get("rocprof_us_per_step"), "calibration_true_bytes_per_counted_byte": d.get("calibration_true_bytes_per_counted_byte"),
+                "note": d.get("note")}
+    except Exception:   # noqa: BLE001  (evidence, never a reason to fail the bench)
+        return None
 
 
 PARITY_TOL = 1e-9   # BASELINE.json north_star: coefficients within 1e-9 (relative, per polynomial) of the Eigen reference
@@ -457,9 +503,7 @@ def fp64_issue_roofline(row, us, B):
     """The compute-bound (f) rows against the FP64 VECTOR peak: one VALU instruction per 4 cycles and SIMD (for FMAs: 78.6 TFLOP/s,
     /opt/skills/guides/MI355X_MICROARCH.md).  VALU instructions per call from the committed rocprofv3 PMC pass of the same row at
     this size (profiles/r04_next_rows_pmc.json, tools/gpu_profile_rows.sh: its own profiling run); the duration is this run's."""
-    path = os.path.join(ROOT, "profiles", "r05_next_rows_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r04_next_rows_pmc.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_next_rows_pmc.json") for r in (6, 5, 4)) if os.path.exists(q)), "")
     if B != 10_000 or not os.path.exists(path):
         return None
     try:
@@ -471,6 +515,18 @@ def fp64_issue_roofline(row, us, B):
     pk = FP64_VALU_PEAK
     issue_s = d["valu_insts_per_call"] * pk["cycles_per_wave_instruction"] / (pk["simds"] * pk["clock_hz"])
     frac = issue_s / (us * 1e-6)
+    f64 = d.get("f64_insts_per_call")
+    if f64 and sum(f64.values()) > 0:
+        # round 6: flops from the FP64 instruction counters (wave instructions x 64 lanes; FMA = 2 flops, MUL / ADD / TRANS = 1)
+        flops = 64.0 * (2.0 * f64.get("FMA_F64", 0.0) + f64.get("MUL_F64", 0.0) + f64.get("ADD_F64", 0.0) + f64.get("TRANS_F64", 0.0))
+        achieved = flops / (us * 1e-6) * 1e-12
+        return {"bound": "fp64", "peak": pk["tflops"], "unit": "TFLOP/s", "frac": achieved / pk["tflops"], "achieved": achieved,
+                "achieved_is": "FP64 flops from SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 of the committed PMC pass (FMA = 2 flops per lane) / this run's duration",
+                "fp64_wave_instructions_per_call": f64, "valu_instructions_per_call": d["valu_insts_per_call"],
+                "fp64_share_of_valu_instructions": sum(f64.values()) / d["valu_insts_per_call"],
+                "valu_issue_us_at_peak": issue_s * 1e6, "valu_issue_frac": frac,
+                "valu_issue_frac_is": "all VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) / duration: how busy the issue slots are, whatever they issue",
+                "counters_from": os.path.relpath(path, ROOT)}
     return {"bound": "fp64", "peak": pk["tflops"], "unit": "TFLOP/s", "valu_instructions_per_call": d["valu_insts_per_call"],
             "valu_issue_us_at_peak": issue_s * 1e6, "frac": frac, "achieved": frac * pk["tflops"],
             "achieved_is": "upper bound: as if every VALU instruction were an FP64 FMA (64 lanes x 2 flops)",
@@ -1042,7 +1098,11 @@ def main():
                       f"({nsets * set_bytes / 2**20:.0f} MiB) resident in HBM; inputs {args.layout.upper()}"
                       + (" (SoA, row stride padded to a multiple of 16 trajectories: mtg_layout_soa_padded)" if args.layout == "soa16" else "")
                       + ", coeffs [B][K][D][N]")
-        traffic_prof = profile_traffic(traj_per_step, args.config, args.steps, args.warmup)
+        traffic_prof = None
+        if world == 1 and not args.no_live_traffic and not args.no_extras:
+            traffic_prof = live_traffic(args, B)
+        if traffic_prof is None:
+            traffic_prof = profile_traffic(traj_per_step, args.config, args.steps, args.warmup)
         if args.settle_ms > 0:
             what += (f"; set-up before the contract's warm-up + timed steps: {args.settle_ms:g} ms of the same work (a fresh process "
                      f"starts on an idle GPU; the timed region measured before that phase is reported as cold_start)"

@@ -111,6 +111,21 @@ enum {
                                      /* of long chains) where the plan and the call are       */
                                      /* eligible (standard shapes, D = 3, coefficients only); */
                                      /* default: chosen from the batch size and chain length  */
+  MTG_FLAG_REFINE = 1u << 12,        /* mtg_solve_linear / _status, device pointers: ONE step */
+                                     /* of iterative refinement on the free derivatives --    */
+                                     /* the residual -(R_PP d_P + R_PF d_F) formed in double- */
+                                     /* double from the exact unit-time table (csrc/          */
+                                     /* mtg_refine.hip), the correction solved and the        */
+                                     /* coefficients recovered by the ordinary float64        */
+                                     /* kernels.  For problems whose float64 solution is      */
+                                     /* conditioning-limited (N = 12, d < N/2 - 1: every      */
+                                     /* float64 evaluation, the reference's own included, is  */
+                                     /* 1e-8 .. 2e-6 from the 50-digit solution) the result   */
+                                     /* is good to ~1e-13.  An ACCURACY mode: five launches,  */
+                                     /* the correction through the generic kernel -- measured */
+                                     /* 10-25x a plain solve (N = 12 / K = 32 at 100k: 5.2 ms */
+                                     /* against 0.5 ms); asynchronous.  Not with COST_ONLY /  */
+                                     /* HOST_POINTERS / BASIC_SOLUTION.                       */
   MTG_FLAG_BASIC_SOLUTION = 1u << 10 /* mtg_solve_linear / _status: reference behaviour on     */
                                      /* RANK-DEFICIENT free systems (LIN:365-378: the rank-   */
                                      /* revealing SparseQR returns a basic solution and       */

@@ -144,6 +144,7 @@ FLAG_SEQUENCE_ONE_LAUNCH_PER_BATCH = 256
 FLAG_QUERY_EXTRA_OUTPUTS = 512
 FLAG_BASIC_SOLUTION = 1024
 FLAG_COOPERATIVE = 2048
+FLAG_REFINE = 4096
 
 _lib = None
 

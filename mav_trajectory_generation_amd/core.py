@@ -271,7 +271,7 @@ class Plan:
 
     def solve(self, times, d_fixed, layout: str = "aos", want_free: bool = False, want_cost: bool = False,
               coeffs=None, d_free=None, cost=None, generic: bool = False, dims: str = "auto", ordered: bool = True,
-              traj_status=None, basic_solution: bool = False, batch: Optional[int] = None):
+              traj_status=None, basic_solution: bool = False, batch: Optional[int] = None, refine: bool = False):
         """times / d_fixed: float64 CUDA tensors in `layout` ('aos': [B][K], [B][D][n_fixed];
         'soa': [K][B], [D][n_fixed][B]).  Asynchronous; returns (coeffs [B][K][D][N], d_free, cost).
         dims: launch form -- 'auto', 'fused', 'split' (one dimension group per workgroup) or 'dimlane' (all dimensions of
@@ -280,6 +280,8 @@ class Plan:
         traj_status: optional int32 CUDA tensor [B] that receives the per-trajectory status bits (1 bad time, 2 singular).
         basic_solution: the reference's behaviour on rank-deficient free systems (MTG_FLAG_BASIC_SOLUTION: flagged trajectories
         get the basic solution of a pivoted QR on the host; the call is then synchronous).
+        refine: MTG_FLAG_REFINE -- one step of iterative refinement with the residual in double-double (conditioning-limited
+        problems: N = 12, d < N/2 - 1); about five plain solves.
         ordered=False skips the automatic ordering against torch's current stream (the caller forks / joins the
         context's stream itself -- MixedBatchSolver runs independent buckets concurrently that way); output tensors
         must then be passed in, allocated by the caller before the fork."""
@@ -305,6 +307,8 @@ class Plan:
         flags |= {"auto": 0, "fused": L.FLAG_FUSED_DIMS, "split": L.FLAG_SPLIT_DIMS, "dimlane": L.FLAG_DIMLANE, "coop": L.FLAG_COOPERATIVE}[dims]
         if basic_solution:
             flags |= L.FLAG_BASIC_SOLUTION
+        if refine:
+            flags |= L.FLAG_REFINE
         if traj_status is not None:
             assert traj_status.dtype == torch.int32 and traj_status.is_cuda and traj_status.numel() >= batch
         cur = self.ctx._enter() if ordered else None

@@ -205,6 +205,8 @@ struct mtg_plan {
   int* d_shadow_maps = nullptr;      // device copy: shadow_fixed_src | free_in_shadow
   double* shadow_buf = nullptr;      // [batch][D][n_fixed of the shadow] | [batch][D][n_free of the shadow]
   size_t shadow_buf_bytes = 0;
+  double* refine_buf = nullptr;      // MTG_FLAG_REFINE: x | residual | delta ([batch][D][n_free] each) | zeros ([batch][D][n_fixed])
+  size_t refine_buf_bytes = 0;
   std::vector<LaunchRecord> last;
 };
 
@@ -678,6 +680,7 @@ int mtg_plan_destroy(mtg_plan* p) {
   if (p->basic_status) hipFree(p->basic_status);
   if (p->d_shadow_maps) hipFree(p->d_shadow_maps);
   if (p->shadow_buf) hipFree(p->shadow_buf);
+  if (p->refine_buf) hipFree(p->refine_buf);
   if (p->shadow) mtg_plan_destroy(p->shadow);
   delete p;
   return MTG_OK;
@@ -1207,7 +1210,8 @@ static int solve_on_host_backend(mtg_plan* p, int64_t batch, const mtg_layout* L
 static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
                       double* coeffs, double* d_free, double* cost, uint32_t flags, bool update_only,
                       int32_t* traj_status = nullptr, const PerturbedTimes* pert = nullptr,
-                      hipStream_t on_stream = nullptr, int* own_status_dev = nullptr) {
+                      hipStream_t on_stream = nullptr, int* own_status_dev = nullptr, const double* explicit_rhs = nullptr) {
+  // explicit_rhs (MTG_FLAG_REFINE's correction solve; with MTG_FLAG_GENERIC_KERNEL): [batch][D][n_free], added to the right-hand side
   // own_status_dev: a device status word of the CALL (zeroed here) instead of the context's -- flags of earlier asynchronous
   // launches stay where the next mtg_context_sync finds them
   const bool cost_only = !update_only && (flags & MTG_FLAG_COST_ONLY) != 0;
@@ -1246,6 +1250,7 @@ static int solve_impl(mtg_plan* p, int64_t batch, const mtg_layout* L, const dou
   else if (own_status_dev) c.P.status = own_status_dev;
   c.P.times = dt; c.P.dfix = dfx; c.P.coeffs = dco; c.P.dfree = (p->n_free ? dfr : nullptr); c.P.cost = dcs;
   c.P.tstatus = c.dts;
+  if (explicit_rhs) { c.P.rhs = explicit_rhs; c.P.rh_b = (long long)p->D * p->n_free; c.P.rh_d = p->n_free; c.P.rh_c = 1; }
   c.wc = dcs != nullptr || (!update_only && c.P.dfree != nullptr);
   c.ntiles = (int)((batch + kWave - 1) / kWave);
   if (pert) {   // cost-only launch over (K + 1) x batch virtual problems; cost = [(K + 1)][batch]
@@ -1464,8 +1469,61 @@ static int solve_with_basic_solution(mtg_plan* p, int64_t batch, const mtg_layou
   return any_bad_time ? set_err(ctx, MTG_ERR_BAD_SEGMENT_TIME, mtg_status_string(MTG_ERR_BAD_SEGMENT_TIME)) : MTG_OK;
 }
 
+// MTG_FLAG_REFINE (asynchronous, device pointers): x = the ordinary solve's d_P; r = -(R_PP x + R_PF d_F) in double-double
+// (mtg_refine.hip); R_PP delta = r by the generic float64 kernel (zero fixed values, r as its explicit right-hand side);
+// x += delta; coefficients (and the cost) recovered from x by the update path (LIN:263-283).
+static int solve_refined(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                         double* coeffs, double* d_free, double* cost, int32_t* traj_status, uint32_t flags) {
+  if (!p || !L) return MTG_ERR_INVALID_ARGUMENT;
+  mtg_context* ctx = p->ctx;
+  if (flags & (MTG_FLAG_HOST_POINTERS | MTG_FLAG_COST_ONLY | MTG_FLAG_BASIC_SOLUTION))
+    return set_err(ctx, MTG_ERR_INVALID_ARGUMENT, "MTG_FLAG_REFINE: device pointers, coefficient output, not with MTG_FLAG_BASIC_SOLUTION");
+  const uint32_t inner = flags & ~(uint32_t)MTG_FLAG_REFINE;
+  if (batch <= 0 || p->n_free == 0) return solve_impl(p, batch, L, times, d_fixed, coeffs, d_free, cost, inner, false, traj_status);
+  const size_t nfree = (size_t)batch * p->D * p->n_free, nfix = (size_t)batch * p->D * std::max(p->n_fixed, 1);
+  double *xbuf, *rbuf, *dbuf, *zbuf;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rb = ensure_buffer(ctx, &p->refine_buf, &p->refine_buf_bytes, (3 * nfree + nfix) * sizeof(double));
+    if (rb != MTG_OK) return rb;
+    xbuf = p->refine_buf; rbuf = xbuf + nfree; dbuf = rbuf + nfree; zbuf = dbuf + nfree;
+    MTG_HIP_TRY(ctx, hipMemsetAsync(zbuf, 0, nfix * sizeof(double), ctx->stream));
+  }
+  // x lives in the caller's d_free when there is one, else in the plan's scratch (contiguous [B][D][n_free])
+  mtg_layout XL = *L;
+  double* x = d_free;
+  if (!x) { x = xbuf; XL.free_stride_b = (int64_t)p->D * p->n_free; XL.free_stride_d = p->n_free; XL.free_stride_c = 1; }
+  int rc = solve_impl(p, batch, &XL, times, d_fixed, coeffs, x, nullptr, inner, false, traj_status);
+  if (rc != MTG_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MtgParams P;
+    fill_common(p, P, batch, &XL);
+    if (mtg_refine_residual_launch((void*)ctx->stream, p->H, p->K, p->D, p->deriv, P.h1off, P.vmask, P.offF, P.offP, (long long)batch, times,
+                                   P.ts_b, P.ts_k, d_fixed, P.fs_b, P.fs_d, P.fs_c, x, P.ps_b, P.ps_d, P.ps_c, rbuf, p->n_free) != 0)
+      return set_err(ctx, MTG_ERR_DEVICE, "MTG_FLAG_REFINE: residual launch failed");
+  }
+  // the correction solve: zero fixed values (contiguous), the residual as explicit right-hand side, delta contiguous
+  mtg_layout CL = *L;
+  CL.fixed_stride_b = (int64_t)p->D * p->n_fixed; CL.fixed_stride_d = p->n_fixed; CL.fixed_stride_c = 1;
+  CL.free_stride_b = (int64_t)p->D * p->n_free; CL.free_stride_d = p->n_free; CL.free_stride_c = 1;
+  const uint32_t generic = (inner & ~(uint32_t)(MTG_FLAG_FUSED_DIMS | MTG_FLAG_SPLIT_DIMS | MTG_FLAG_DIMLANE | MTG_FLAG_COOPERATIVE)) | MTG_FLAG_GENERIC_KERNEL;
+  rc = solve_impl(p, batch, &CL, times, zbuf, coeffs, dbuf, nullptr, generic, false, nullptr, nullptr, nullptr, nullptr, rbuf);
+  if (rc != MTG_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (mtg_refine_axpy_launch((void*)ctx->stream, x, XL.free_stride_b, XL.free_stride_d, XL.free_stride_c, dbuf, (long long)batch, p->D, p->n_free) != 0)
+      return set_err(ctx, MTG_ERR_DEVICE, "MTG_FLAG_REFINE: update launch failed");
+  }
+  return solve_impl(p, batch, &XL, times, d_fixed, coeffs, x, cost, inner, true);
+}
+
 int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                      const double* d_fixed, double* coeffs, double* d_free, double* cost, uint32_t flags) {
+  if (flags & MTG_FLAG_REFINE) return solve_refined(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, nullptr, flags);
   if (flags & MTG_FLAG_BASIC_SOLUTION) return solve_with_basic_solution(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, nullptr, flags);
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false);
 }
@@ -1473,6 +1531,7 @@ int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout, co
 int mtg_solve_linear_status(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                             const double* d_fixed, double* coeffs, double* d_free, double* cost,
                             int32_t* trajectory_status, uint32_t flags) {
+  if (flags & MTG_FLAG_REFINE) return solve_refined(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, trajectory_status, flags);
   if (flags & MTG_FLAG_BASIC_SOLUTION)
     return solve_with_basic_solution(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, trajectory_status, flags);
   return solve_impl(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, flags, false, trajectory_status);

@@ -144,6 +144,7 @@ __device__ __forceinline__ void mtg_solve_dl_body(const double* __restrict__ tim
   P.B = B; P.K = C::KT; P.Dtot = DL; P.dim0 = d;   // dim0 is a per-lane value here
   P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
   P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
+  P.rhs = nullptr; P.rh_b = P.rh_d = P.rh_c = 0;
 
   const int nunits = (ntiles + NP - 1) / NP;
   MtgLane<C> ln;
@@ -319,6 +320,7 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   P.B = B; P.K = C::KT; P.Dtot = DL; P.dim0 = d;
   P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
   P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
+  P.rhs = nullptr; P.rh_b = P.rh_d = P.rh_c = 0;
   MtgLane<C> ln;
   const long long b0 = (long long)tile * TPW;
   const long long bl = b0 + t;

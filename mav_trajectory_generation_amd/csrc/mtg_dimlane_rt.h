@@ -288,6 +288,7 @@ __global__ __launch_bounds__(2 * kWave, 1) void mtg_solve_dl_rt_kernel(const dou
   P.B = B; P.K = K; P.Dtot = DL; P.dim0 = d;     // dim0 is a per-lane value here
   P.deriv = C::DV; P.h1off = C::H1OFF; P.ainvoff = C::AINVOFF;
   P.pert_on = 0; P.pert_seg = -1; P.pert_tpv = 1; P.pert_h = P.pert_corr = P.pert_lo = 0.0;
+  P.rhs = nullptr; P.rh_b = P.rh_d = P.rh_c = 0;
   const int kc = dir == 0 ? (K + 1) / 2 : K / 2;
   constexpr size_t half = mtg_rt_half_bytes<C, DL>();
   char* my_slab = lds_raw + (size_t)dir * half;

@@ -482,6 +482,13 @@ struct MtgDimlaneEntry {
                       int* traj_status, int B, int ntiles, double* ws, int aos, double* dfree, double* cost, long long ps_b,
                       long long ps_d, long long ps_c);
 };
+// MTG_FLAG_REFINE (mtg_refine.hip): r = -(R_PP x + R_PF d_F) in double-double for every trajectory and dimension ([B][D][n_free],
+// contiguous), and x += delta over the free slots; 0 or -1 (launch failed)
+int mtg_refine_residual_launch(void* stream, int H, int K, int D, int deriv, int h1off, const int* d_vmask, const int* d_offF,
+                               const int* d_offP, long long B, const double* times, long long ts_b, long long ts_k,
+                               const double* dfix, long long fs_b, long long fs_d, long long fs_c, const double* dfree,
+                               long long ps_b, long long ps_d, long long ps_c, double* rhs, int n_free);
+int mtg_refine_axpy_launch(void* stream, double* x, long long ps_b, long long ps_d, long long ps_c, const double* delta, long long B, int D, int np);
 // cross-structure launches (mtg_solve_multi_any_kernel): index of a rolled entry's configuration, or -1; kernel for a
 // dimension-group size (1 | 3) and output variant ([extra outputs] + 2 * [write-through])
 int mtg_any_cfg_index(const MtgStaticEntry* e);

@@ -57,6 +57,10 @@ struct MtgParams {
   // tile -> (variant, tile of the real batch); pert_seg is that tile's perturbed segment (-1: none).
   int pert_on, pert_seg, pert_tpv;   // pert_tpv: tiles per variant
   double pert_h, pert_corr, pert_lo;
+  // Generic mode only (MTG_FLAG_REFINE, the correction solve R_PP delta = r of one step of iterative refinement): an EXPLICIT
+  // right-hand side over the free slots, [B][D][n_free] with these strides, ADDED to the one the fixed values produce (which the
+  // caller makes zero); null otherwise
+  const double* rhs;    long long rh_b, rh_d, rh_c;
 };
 
 // segment time as the virtual problem sees it (identity unless a perturbed-time launch)
@@ -726,10 +730,29 @@ MTG_HD double mtg_step_time(const MtgParams& P, long long b, int j, const MtgLan
   }
 }
 
+// generic mode: the explicit right-hand side (MtgParams::rhs) of vertex v's free slots joins the carried one
+template <class C>
+MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mask, MtgLane<C>& ln) {
+  if constexpr (!C::kCT) {
+    if (P.rhs == nullptr) return;
+    const int off = mtg_offP<C>(P, v);
+#pragma unroll
+    for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+      for (int p = 0; p < C::H; ++p) {
+        if ((mask >> p) & 1) continue;
+        const int col = off + (p - mtg_popc(mask & ((1 << p) - 1)));
+        ln.rc[dm][p] += P.rhs[b * P.rh_b + (long long)(P.dim0 + dm) * P.rh_d + (long long)col * P.rh_c];
+      }
+    }
+  }
+}
+
 template <class C, int DIR>
 MTG_HD void mtg_fwd_step(const MtgParams& P, long long b, int j, int ml, int mr, MtgLane<C>& ln,
                          double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
   const int K = mtg_nseg<C>(P);
+  mtg_add_explicit_rhs<C>(P, b, mtg_vl<DIR>(K, j), ml, ln);      // (the step completes its LEFT vertex)
   const double T = mtg_step_time<C, DIR>(P, b, j, ln);
   double fix_l[C::D][C::H], fix_r[C::D][C::H];
   mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(K, j), ml, ln, fix_l);
@@ -1429,6 +1452,8 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
         mtg_fwd_step<C, DIR>(P, b, j, ml, mr, ln, G, g);
         mtg_ws_store<C>(mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride), P.ws_stride, G, g, ml, mr);
       }
+      // the middle vertex's explicit right-hand side: once, by the forward direction (both directions sum the two carried ones)
+      if (DIR > 0) mtg_add_explicit_rhs<C>(P, b, (K + 1) / 2, mtg_mask<C>(P, (K + 1) / 2), ln);
     }
   }
 }

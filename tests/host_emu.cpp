@@ -125,6 +125,20 @@ const StaticEntry kStatic[] = {
 // AoS layouts: times[B][K], dfix[B][D][n_fixed], dfree[B][D][n_free], coeffs[B][K][D][N].
 // mode: 0 = generic solve, 1 = static variant if one matches (returns -2 if none), 2 = update-from-free,
 // 3 = rolled variant if one matches (returns -2 if none).
+static const double* g_explicit_rhs = nullptr;   // mtg_emu_run_rhs: [B][D][n_free], added to the right-hand side (generic mode)
+
+extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long long B, const double* times,
+                           const double* dfix, double* coeffs, double* dfree, double* cost, int mode, int* status);
+// the generic solve with an EXPLICIT right-hand side over the free slots (MtgParams::rhs: the correction solve of
+// MTG_FLAG_REFINE) -- same arguments as mtg_emu_run with mode 0
+extern "C" int mtg_emu_run_rhs(int N, int D, int K, int deriv, const int* mask, long long B, const double* times, const double* dfix,
+                               double* coeffs, double* dfree, const double* rhs, int* status) {
+  g_explicit_rhs = rhs;
+  const int rc = mtg_emu_run(N, D, K, deriv, mask, B, times, dfix, coeffs, dfree, nullptr, 0, status);
+  g_explicit_rhs = nullptr;
+  return rc;
+}
+
 extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long long B, const double* times,
                            const double* dfix, double* coeffs, double* dfree, double* cost, int mode, int* status) {
   const int H = N / 2;
@@ -148,6 +162,7 @@ extern "C" int mtg_emu_run(int N, int D, int K, int deriv, const int* mask, long
   P.B = B; P.K = K; P.Dtot = D; P.deriv = deriv;
   P.ainvoff = kAinvLoOff[H];
   P.h1off = kH1Off[H][deriv];
+  if (g_explicit_rhs && mode == 0) { P.rhs = g_explicit_rhs; P.rh_b = (long long)D * n_free; P.rh_d = n_free; P.rh_c = 1; }
   if (cost) for (long long b = 0; b < B; ++b) cost[b] = 0.0;
   const bool wc = cost != nullptr || (mode != 2 && n_free > 0 && dfree != nullptr);
   if (mode == 1 || mode == 3) {
