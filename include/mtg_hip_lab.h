@@ -48,6 +48,11 @@ int mtg_lab_segment_cost_matrices(mtg_context* ctx, int32_t n_coeffs, int32_t de
  * with the constant 100 MHz counter (s_memrealtime) over `duration_us`.  start returns immediately (the probe is enqueued);
  * finish waits for the probe, returns MHz and the probed interval, and releases it.  bench.py brackets its `sustained` run
  * with it (the FP64-heavy solve kernels run power-limited: 1.75-1.96 GHz instead of the 2.4 GHz the peaks are quoted at).   */
+/* The residual of MTG_FLAG_REFINE alone: rhs_out [batch][D][n_free] (contiguous, device) = -(R_PP d_free + R_PF d_fixed), formed in
+ * double-double (csrc/mtg_refine.hip) from device buffers in `layout`; asynchronous on the context's stream.  The tests compare it
+ * with the residual formed at 50 digits.                                                                                       */
+int mtg_lab_refine_residual(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times, const double* d_fixed,
+                            const double* d_free, double* rhs_out);
 typedef struct mtg_lab_clock_probe mtg_lab_clock_probe;
 int mtg_lab_clock_probe_start(mtg_context* ctx, double duration_us, mtg_lab_clock_probe** out);
 int mtg_lab_clock_probe_finish(mtg_lab_clock_probe* probe, double* shader_mhz, double* measured_us);

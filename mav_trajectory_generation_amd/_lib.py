@@ -40,6 +40,8 @@ EXPORTS = {
     "mtg_context_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),   # include/mtg_hip_lab.h
     "mtg_lab_segment_cost_matrices": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),   # include/mtg_hip_lab.h
+    "mtg_lab_refine_residual": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]),   # include/mtg_hip_lab.h
     "mtg_lab_clock_probe_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]),   # include/mtg_hip_lab.h
     "mtg_lab_clock_probe_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "mtg_last_error_string": (ctypes.c_char_p, [ctypes.c_void_p]),

@@ -1521,6 +1521,22 @@ static int solve_refined(mtg_plan* p, int64_t batch, const mtg_layout* L, const 
   return solve_impl(p, batch, &XL, times, d_fixed, coeffs, x, cost, inner, true);
 }
 
+// include/mtg_hip_lab.h: the double-double residual alone (what the tests compare with the residual formed at 50 digits)
+extern "C" int mtg_lab_refine_residual(mtg_plan* p, int64_t batch, const mtg_layout* L, const double* times, const double* d_fixed,
+                                       const double* d_free, double* rhs_out) {
+  if (!p || !L || !times || !d_free || !rhs_out || batch < 0 || (p->n_fixed > 0 && !d_fixed)) return MTG_ERR_INVALID_ARGUMENT;
+  if (batch == 0 || p->n_free == 0) return MTG_OK;
+  mtg_context* ctx = p->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  MTG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MtgParams P;
+  fill_common(p, P, batch, L);
+  if (mtg_refine_residual_launch((void*)ctx->stream, p->H, p->K, p->D, p->deriv, P.h1off, P.vmask, P.offF, P.offP, (long long)batch, times,
+                                 P.ts_b, P.ts_k, d_fixed, P.fs_b, P.fs_d, P.fs_c, d_free, P.ps_b, P.ps_d, P.ps_c, rhs_out, p->n_free) != 0)
+    return set_err(ctx, MTG_ERR_DEVICE, "residual launch failed");
+  return MTG_OK;
+}
+
 int mtg_solve_linear(mtg_plan* plan, int64_t batch, const mtg_layout* layout, const double* times,
                      const double* d_fixed, double* coeffs, double* d_free, double* cost, uint32_t flags) {
   if (flags & MTG_FLAG_REFINE) return solve_refined(plan, batch, layout, times, d_fixed, coeffs, d_free, cost, nullptr, flags);

@@ -20,6 +20,10 @@
 #ifndef MTG_RT_INPUT_DEPTH
 #define MTG_RT_INPUT_DEPTH 3      // steps the on-demand input loads run ahead of their use (beyond the next step)
 #endif
+// (Round 6, built, measured and removed: the back-substitution rows of a head step requested TWO steps ahead through a second
+// register set -- paid with 0 / 2 / 2 register steps for N = 10 / 8 / 12.  K = 100 at B = 100k: 873 / 1338 / 1965 us against
+// 843 / 1283 / 1791 us one step ahead (N = 8 / 10 / 12; profiles/r06g_other_k_rows_two_steps_ahead_not_adopted.jsonl): the lead of
+// the workspace loads is not what the head steps wait for.)
 #include "mtg_kernels.h"
 
 // C: rolled configuration (KT_ < 0) with D == 1, DLW = DL, RS = 1.  R: register steps, L: LDS steps.

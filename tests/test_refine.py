@@ -73,6 +73,40 @@ def test_explicit_rhs_correction_solve_through_the_lane_code(n, d, k, pool):
         assert e0 > 1e-8          # the case the flag exists for (ratio of segment times 16.8)
 
 
+def build_refine_emu():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so, src = os.path.join(root, "tests", "librefine_emu.so"), os.path.join(root, "tests", "refine_emu.cpp")
+    deps = [src] + [os.path.join(root, "mav_trajectory_generation_amd", "csrc", f) for f in ("mtg_refine_dd.h", "mtg_tables.inc", "mtg_tables_dd.inc")]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.mtg_refine_emu_residual.argtypes = [ctypes.c_int] * 4 + [ip, ctypes.c_longlong, dp, dp, dp, dp]
+    lib.mtg_refine_emu_residual.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("n,d,k,pool", [(12, 5, 16, 400), (12, 2, 8, 60), (10, 4, 8, 60), (8, 3, 5, 40), (6, 0, 3, 20)])
+def test_double_double_residual_host_build_against_the_50_digit_residual(n, d, k, pool):
+    """csrc/mtg_refine_dd.h (the code the device kernel runs) built for the host: the residual of the lane code's own d_P within
+    2e-15 of the residual formed at 50 digits, relative to its largest entry -- which is itself ~1e-8 ... 1e-15 of the terms it is the
+    difference of."""
+    lib, emu = build_refine_emu(), build_emu(False)
+    dim = 3
+    masks, t, f = worst_ratio_problems(n, k, dim, 31415 + 7 * k + n, pool, 2)
+    rc, _, fr, _, st = helpers.emu_run(emu, n, dim, k, d, masks, t, f, want_cost=False)
+    assert rc == 0 and st == 0
+    fr = np.ascontiguousarray(fr)
+    got = np.zeros_like(fr)
+    m = np.array(masks, dtype=np.int32)
+    assert lib.mtg_refine_emu_residual(n, dim, k, d, m.ctypes.data_as(ip), 2, t.ctypes.data_as(dp), f.ctypes.data_as(dp), fr.ctypes.data_as(dp),
+                                       got.ctypes.data_as(dp)) == 0
+    for b in range(2):
+        want = exact_residual(n, d, masks, t[b], f[b], fr[b])
+        assert np.abs(got[b] - want).max() <= 2e-15 * np.abs(want).max()
+
+
 @pytest.fixture(scope="module")
 def ctx():
     import torch
@@ -112,17 +146,48 @@ def test_refined_solve_against_the_50_digit_solution(ctx, n, d, k, pool, layout)
     e_plain, e_ref = [], []
     for b in range(count):
         c_mp, f_mp, j_mp = oracle_mp.solve(n, d, masks, t_h[b], f_h[b])
-        e_plain.append(max(np.abs(fr0n[b] - f_mp).max() / np.abs(f_mp).max(), helpers.poly_relerr(co0n[b], c_mp)))
-        e_ref.append(max(np.abs(fr1n[b] - f_mp).max() / np.abs(f_mp).max(), helpers.poly_relerr(co1n[b], c_mp)))
+        e_plain.append((np.abs(fr0n[b] - f_mp).max() / np.abs(f_mp).max(), helpers.poly_relerr(co0n[b], c_mp)))
+        e_ref.append((np.abs(fr1n[b] - f_mp).max() / np.abs(f_mp).max(), helpers.poly_relerr(co1n[b], c_mp)))
         # (the cost is 0.5 c^T Q c evaluated in float64 FROM the coefficients: its own cancellation, 3e-11 ... 6e-9 measured)
         assert abs(float(j1[b]) - j_mp) <= (1e-7 if n == 12 or d < n // 2 - 1 else 1e-10) * abs(j_mp)
-    assert max(e_ref) <= 1e-11, (e_plain, e_ref)
-    assert max(e_ref) <= max(max(e_plain), 1e-13)
+    # (d_P error, coefficient error) per sampled trajectory
+    assert max(max(e) for e in e_ref) <= 1e-11, (e_plain, e_ref)
+    assert max(max(e) for e in e_ref) <= max(max(max(e) for e in e_plain), 1e-13), (e_plain, e_ref)
     if (n, d, k) == (12, 5, 16):
-        assert max(e_plain) > 1e-8
+        assert max(max(e) for e in e_plain) > 1e-8
     # the rest of the batch: the refined coefficients stay within the plain solve's own error of it
     assert helpers.poly_relerr(co1n[count:], co0n[count:]) < (1e-6 if n == 12 or d < n // 2 - 1 else 1e-9)
     assert helpers.check_path(masks, t_all, f_all, co1n) < 1e-6
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,k,pool,layout", [(12, 5, 16, 400, "soa"), (12, 5, 8, 200, "aos"), (10, 4, 8, 60, "soa"), (8, 2, 5, 40, "aos")])
+def test_device_residual_against_the_50_digit_residual(ctx, n, d, k, pool, layout):
+    """The double-double residual kernel alone (include/mtg_hip_lab.h: mtg_lab_refine_residual) on the plain solve's d_P: within
+    1e-13 of the residual formed at 50 digits, relative to its largest entry (a float64 evaluation of the same expression is wrong in
+    the FIRST digit there: the residual is ~1e-8 of the terms it is the difference of)."""
+    import torch
+    import mav_trajectory_generation_amd as m
+    dim, count = 3, 2
+    masks, t_h, f_h = worst_ratio_problems(n, k, dim, 31415 + 7 * k + n, pool, count)
+    plan = m.Plan(ctx, n, dim, k, d, masks)
+    t, f = torch.from_numpy(t_h).cuda(), torch.from_numpy(f_h).cuda()
+    if layout == "soa":
+        t, f = t.t().contiguous(), f.permute(1, 2, 0).contiguous()
+    _, fr, _ = plan.solve(t, f, layout=layout, want_free=True)
+    rhs = torch.zeros((count, dim, plan.n_free), dtype=torch.float64, device="cuda")
+    lay = plan.layout(count, layout)
+    cur = ctx._enter()
+    rc = plan.lib.mtg_lab_refine_residual(plan.handle, count, ctypes.byref(lay), t.data_ptr(), f.data_ptr(), fr.data_ptr(), rhs.data_ptr())
+    ctx._leave(cur)
+    assert rc == 0
+    ctx.sync()
+    frn = fr.cpu().numpy() if layout == "aos" else fr.permute(2, 0, 1).cpu().numpy()
+    got = rhs.cpu().numpy()
+    for b in range(count):
+        want = exact_residual(n, d, masks, t_h[b], f_h[b], frn[b])
+        assert np.abs(got[b] - want).max() <= 1e-13 * np.abs(want).max(), (b, np.abs(got[b] - want).max() / np.abs(want).max())
     plan.close()
 
 
