@@ -152,7 +152,7 @@ def profile_traffic(batch, config, steps, warmup):
     (profiles/r04_config<N>_pmc_traffic.json, tools/gpu_profile3.sh: FETCH_SIZE / WRITE_SIZE in their own passes, calibrated in
     the same visit): evidence from a separate profiling run, NOT measured in this run -- the file name travels with the number.
     Only a profile of the same arguments (batch, --steps, --warmup) counts."""
-    for name in (f"r05_config{config}_pmc_traffic.json", f"r04_config{config}_pmc_traffic.json",
+    for name in (f"r06_config{config}_pmc_traffic.json", f"r05_config{config}_pmc_traffic.json", f"r04_config{config}_pmc_traffic.json",
                  {2: "r03z_driver_args_pmc_traffic.json", 4: "r03z_config4_pmc_traffic.json"}.get(config)):
         path = os.path.join(ROOT, "profiles", name) if name else None
         if not path or not os.path.exists(path):

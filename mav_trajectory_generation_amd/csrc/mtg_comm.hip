@@ -197,18 +197,27 @@ int mtg_comm_solve_all_gather(mtg_comm* c, mtg_plan* plan, int64_t batch, const 
   if (rc != MTG_OK) return rc;
   const int64_t bc = batch / n_chunks;
   const int64_t per_chunk = bc * (int64_t)K * D * N;       // doubles per chunk: coeffs [Bc][K][D][N]
+  // (a failure in chunk i leaves the gathers of chunks < i in flight on the communicator's stream: the solve stream is joined to it on
+  // EVERY way out, so that whatever the caller enqueues next on the context runs behind them)
+  auto join = [&]() {
+    return hipEventRecord(c->gathered, c->comm_stream) == hipSuccess && hipStreamWaitEvent(c->solve_stream, c->gathered, 0) == hipSuccess;
+  };
   for (int32_t ch = 0; ch < n_chunks; ++ch) {
+    // Chunk = the trajectories [ch bc, (ch + 1) bc) of the caller's buffers through the layout's batch strides.  For AoS inputs a chunk
+    // is itself a canonical AoS batch and takes the same kernels as the whole batch; for canonical SoA inputs the rows keep the
+    // FULL batch's stride, which the dimension-in-lane / queue kernels do not take (their row stride is the batch size or its
+    // multiple of 16): such chunks run the strided fused kernels -- correct, slower.  Callers that want the fast path with SoA data
+    // hand over pre-chunked buffers (dist.ChunkedSolveGather does) or AoS.
     const double* t = times + ch * bc * layout->times_stride_b;
     const double* f = d_fixed ? d_fixed + ch * bc * layout->fixed_stride_b : nullptr;
     double* co = local_coeffs + ch * per_chunk;
     rc = mtg_solve_linear(plan, bc, layout, t, f, co, nullptr, nullptr, flags);
-    if (rc != MTG_OK) return rc;
-    if (hipEventRecord(c->solved[ch], c->solve_stream) != hipSuccess) return comm_err(c, MTG_ERR_DEVICE, "hipEventRecord");
+    if (rc != MTG_OK) { join(); return rc; }
+    if (hipEventRecord(c->solved[ch], c->solve_stream) != hipSuccess) { join(); return comm_err(c, MTG_ERR_DEVICE, "hipEventRecord"); }
     rc = all_gather_on_comm_stream(c, co, per_chunk, gathered + (int64_t)ch * c->world * per_chunk, c->solved[ch]);
-    if (rc != MTG_OK) return rc;
+    if (rc != MTG_OK) { join(); return rc; }
   }
-  if (hipEventRecord(c->gathered, c->comm_stream) != hipSuccess || hipStreamWaitEvent(c->solve_stream, c->gathered, 0) != hipSuccess)
-    return comm_err(c, MTG_ERR_DEVICE, "joining the communicator's stream failed");
+  if (!join()) return comm_err(c, MTG_ERR_DEVICE, "joining the communicator's stream failed");
   return MTG_OK;
 }
 

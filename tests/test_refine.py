@@ -118,11 +118,12 @@ def ctx():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,d,k,pool,layout", [(12, 5, 16, 400, "soa"), (12, 5, 32, 300, "aos"), (12, 5, 8, 200, "soa"), (12, 3, 8, 100, "aos"),
-                                               (10, 2, 8, 100, "soa"), (10, 4, 8, 60, "aos"), (8, 3, 50, 40, "soa")])
+@pytest.mark.parametrize("n,d,k,pool,layout", [(12, 5, 16, 2000, "soa"), (12, 5, 32, 1000, "aos"), (12, 5, 8, 2000, "soa"), (12, 5, 4, 2000, "aos"),
+                                               (12, 3, 8, 100, "aos"), (10, 2, 8, 100, "soa"), (10, 4, 8, 60, "aos"), (8, 3, 50, 40, "soa")])
 def test_refined_solve_against_the_50_digit_solution(ctx, n, d, k, pool, layout):
     """The flag on the device (double-double residual kernel, generic correction solve, update path): the worst-conditioned
-    trajectories of a pool against the 50-digit solve -- d_P and coefficients within 1e-11 (measured ~1e-14), where the plain solve
+    trajectories of a pool (N = 12: config 4's buckets K = 4 / 8 / 16 / 32, the three largest segment-time ratios of 1000-2000
+    random-waypoint trajectories) against the 50-digit solve -- d_P and coefficients within 1e-11 (measured ~1e-14), where the plain solve
     is up to 2e-7 off; results with and without a caller-side d_free buffer agree bit for bit; cost as the plain solve's."""
     import torch
     import mav_trajectory_generation_amd as m
@@ -153,7 +154,7 @@ def test_refined_solve_against_the_50_digit_solution(ctx, n, d, k, pool, layout)
     # (d_P error, coefficient error) per sampled trajectory
     assert max(max(e) for e in e_ref) <= 1e-11, (e_plain, e_ref)
     assert max(max(e) for e in e_ref) <= max(max(max(e) for e in e_plain), 1e-13), (e_plain, e_ref)
-    if (n, d, k) == (12, 5, 16):
+    if (n, d, k) == (12, 5, 16) and pool >= 400:
         assert max(max(e) for e in e_plain) > 1e-8
     # the rest of the batch: the refined coefficients stay within the plain solve's own error of it
     assert helpers.poly_relerr(co1n[count:], co0n[count:]) < (1e-6 if n == 12 or d < n // 2 - 1 else 1e-9)
