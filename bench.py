@@ -198,9 +198,10 @@ def live_traffic(args, batch):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")
         d = json.load(open(path))
-        for f in (f"{tag}_pmc_traffic.json", f"{tag}_kernel_stats.csv", f"{tag}_kernel_trace_solve_launches.csv", f"{tag}_stats_bench.json"):
+        import glob
+        for f in glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_*")):     # (the script's per-pass logs and copies)
             try:
-                os.remove(os.path.join(ROOT, "gpurun_out", f))
+                os.remove(f)
             except OSError:
                 pass
         if not d.get("hbm_bytes_per_step"):

@@ -50,8 +50,9 @@ fetch = last(table("fetch", "counter_collection.csv"), kernel, "FETCH_SIZE")
 write = last(table("write", "counter_collection.csv"), kernel, "WRITE_SIZE")
 f8 = cal.get("k_read8") or 1.0
 fw = cal.get("k_write16") or 1.0
-per_launch_steps = steps / n_timed
 rf = bench["roofline"]
+# steps of the LAST timed launch (a queue of more than 96 batches is cut: 200 steps = 96 + 96 + 8): its counters / its steps
+per_launch_steps = steps - (rf["batches_per_launch"] or steps) * (n_timed - 1) if n_timed > 1 else steps
 res = {"bench_args": args, "kernel": kernel, "timed_launches": n_timed, "batches_per_launch": rf["batches_per_launch"],
        "trajectories_per_step": bench["config"]["trajectories_per_step"],
        "rocprof_timed_launch_ns": dur_ns, "rocprof_us_per_step": span_ns * 1e-3 / steps,
