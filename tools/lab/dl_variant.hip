@@ -22,9 +22,20 @@
 #ifndef LT_D
 #define LT_D 3
 #endif
+#ifndef LT_OCC
+#define LT_OCC 1      // waves per SIMD the register allocation of the lab kernel is held to (the product kernels: 1)
+#endif
 constexpr int H = LT_H, N = 2 * H, K = LT_K, D = LT_D, NP = LT_NP;
 using C = MtgCfg<H, 1, K, (1 << H) - 1, 1, (1 << H) - 1, H - 1, 0, LT_WS, ((LT_WS > 0 || LT_RS) ? D : 0), LT_LS, LT_RS>;
 constexpr int NF = 2 * H + (K - 1);
+
+// the product body under the lab's own launch bounds (LT_OCC = 2: the register allocation held to 256, two workgroup sets per CU)
+template <class CC, int DL_, int NP_>
+__global__ __launch_bounds__(NP_ * 2 * kWave, LT_OCC) void lab_dl_kernel(const double* __restrict__ times, const double* __restrict__ dfix,
+                                                                       double* __restrict__ coeffs, int* status, int* traj_status, int B,
+                                                                       int ntiles, int nwg, int aos, double* ws) {
+  mtg_solve_dl_body<CC, DL_, NP_, 0, 18, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr);
+}
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 100000;
@@ -57,10 +68,10 @@ int main(int argc, char** argv) {
   constexpr int TPW = 64 / D;
   const int ntiles = (B + TPW - 1) / TPW;
   const int nunits = (ntiles + NP - 1) / NP;
-  const int nwg = std::min(NP == 1 ? 512 : 256, nunits);
+  const int nwg = std::min((NP == 1 ? 512 : 256) * LT_OCC, nunits);
   CK(hipMalloc(&ws, (size_t)nwg * (NP * 128) * std::max(1, C::WSJ * C::WSE) * 8));
   int* dstat; CK(hipMalloc(&dstat, 4)); CK(hipMemset(dstat, 0, 4));
-  auto kern = mtg_solve_dl_kernel<C, D, NP, 0, 18>;
+  auto kern = lab_dl_kernel<C, D, NP>;
   const size_t lds = mtg_dl_lds_bytes<C, D, NP>();
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)kern));
@@ -92,9 +103,9 @@ int main(int argc, char** argv) {
     amax = std::max(amax, std::fabs(x)); finite = finite && std::isfinite(x);
   }
   const double bytes = 8.0 * (K + D * NF + K * D * N) * B;
-  std::printf("{\"tag\": \"%s\", \"N\": %d, \"K\": %d, \"D\": %d, \"B\": %d, \"NP\": %d, \"wg\": %d, \"lds\": %zu, \"vgprs\": %d, \"scratch\": %zu, "
+  std::printf("{\"tag\": \"%s\", \"N\": %d, \"K\": %d, \"D\": %d, \"B\": %d, \"NP\": %d, \"occ\": %d, \"wg\": %d, \"lds\": %zu, \"vgprs\": %d, \"scratch\": %zu, "
               "\"us_mean\": %.2f, \"us_best\": %.2f, \"frac_8TBps\": %.4f, \"status\": %d, \"finite\": %s, \"max_abs\": %.6g, \"hash\": \"%016llx\"}\n",
-              tag, N, K, D, B, NP, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
+              tag, N, K, D, B, NP, LT_OCC, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
               finite ? "true" : "false", amax, (unsigned long long)hsh);
   return 0;
 }
