@@ -1016,8 +1016,17 @@ def main():
                     box = {}
 
                     def init_comm():
+                        # (the thread: the communicator's init AND its first collectives -- three warm-up solve + gather calls and a
+                        # sync -- so that a collective that cannot complete is caught by the watchdog too, not only the init)
                         try:
-                            box["comm"] = mdist.Communicator(ctx, rank, world, ids[0])
+                            torch.cuda.set_device(device_index)          # (the current device is per thread)
+                            c_ = mdist.Communicator(ctx, rank, world, ids[0])
+                            box["init_s"] = time.perf_counter() - t_init
+                            with torch.cuda.stream(ctx.stream):
+                                for _ in range(3):
+                                    box["loc"], box["gat"] = c_.solve_all_gather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks)
+                                c_.sync()
+                            box["comm"] = c_
                         except Exception as e_:   # noqa: BLE001
                             box["error"] = repr(e_)[:300]
                     th = threading.Thread(target=init_comm, daemon=True)
@@ -1030,14 +1039,11 @@ def main():
                         stuck = th.is_alive()
                         if stuck:
                             WATCHDOG["hard_exit"] = True
-                        raise RuntimeError("mtg_comm init did not complete on every rank within %.0f s (this rank: %s); "
+                        raise RuntimeError("mtg_comm init + first collectives did not complete on every rank within %.0f s (this rank: %s); "
                                            "gather figures are torch.distributed's" % (args.mtg_comm_init_timeout,
                                            "timed out" if stuck else box.get("error", "joined")))
-                    comm = box["comm"]
-                    init_s = time.perf_counter() - t_init
-                    for _ in range(3):
-                        loc, gat = comm.solve_all_gather(plan, t, f, layout=g_layout, n_chunks=args.gather_chunks)
-                    comm.sync()
+                    comm, loc, gat = box["comm"], box["loc"], box["gat"]
+                    init_s = box["init_s"]
                     barrier()
                     t0 = time.perf_counter()
                     for _ in range(reps):

@@ -207,6 +207,21 @@ def coeff_only(ctx, n, d, masks, times, d_fixed, dims):
 CONFIG4 = [(n, n // 2 - 1, k) for n in (8, 10, 12) for k in (4, 8, 16, 32)]
 
 
+def log_arbitration(n, d, k, per_traj):
+    """What the gate below actually saw, one line per call, where a GPU visit collects it (gpurun_out/parity_arbitration.jsonl ->
+    profiles/): how many trajectories of the batch were above 1e-9 against the reference (and therefore arbitrated by the 50-digit
+    solve), the maximum and the median."""
+    import json
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_arbitration.jsonl"), "a") as fh:
+            fh.write(json.dumps({"N": n, "d": d, "K": int(k), "trajectories": int(len(per_traj)), "above_1e-9_vs_reference": int((~(per_traj < 1e-9)).sum()),
+                                 "max_vs_reference": float(per_traj.max()), "median_vs_reference": float(np.median(per_traj))}) + "\n")
+    except OSError:
+        pass
+
+
 def assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c):
     """N <= 10: the north-star tolerance, 1e-9 norm-wise per polynomial.  N = 12: a 2000-trajectory random-waypoint batch contains
     trajectories (a very short segment next to long ones) on which the PROBLEM is so ill-conditioned that float64 evaluation
@@ -216,6 +231,7 @@ def assert_close_to_reference(n, d, masks, times, d_fixed, co, ref_c):
     beyond 1e-5, and on the three WORST trajectories the 50-digit solve (oracle/oracle_mp.py) must put the HIP result within
     5e-8 of the truth or within twice the reference's own distance to it (i.e. never the side that is clearly off)."""
     per_traj = np.array([helpers.poly_relerr(co[b:b + 1], ref_c[b:b + 1]) for b in range(co.shape[0])])
+    log_arbitration(n, d, times.shape[1], per_traj)
     if n <= 10:
         # EVERY trajectory above the north-star tolerance is arbitrated by the 50-digit solve (seen on long chains, K = 100: one
         # of 1000 at 1.1e-9): accepted only when the HIP result is within 1e-9 of the truth, i.e. the reference is the side
