@@ -1019,6 +1019,8 @@ def main():
                         # (the thread: the communicator's init AND its first collectives -- three warm-up solve + gather calls and a
                         # sync -- so that a collective that cannot complete is caught by the watchdog too, not only the init)
                         try:
+                            if os.environ.get("MTG_BENCH_TEST_COMM_HANG"):   # (tests/test_bench.py: the watchdog's way out, end to end)
+                                time.sleep(1e6)
                             torch.cuda.set_device(device_index)          # (the current device is per thread)
                             c_ = mdist.Communicator(ctx, rank, world, ids[0])
                             box["init_s"] = time.perf_counter() - t_init

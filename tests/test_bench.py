@@ -93,6 +93,23 @@ def test_rccl_branches_run_on_a_one_rank_group(launcher):
 
 
 @pytest.mark.gpu
+def test_watchdog_falls_back_when_the_second_communicator_cannot_be_set_up():
+    """The north-star gather (mtg_comm_*) is measured by default at every N; its ncclCommInitRank and first collectives run on a
+    watchdog thread.  A rank that never comes back from them (simulated: MTG_BENCH_TEST_COMM_HANG) must not hang the run: the line
+    is printed with the torch.distributed figures, says that it fell back, and the process exits 0 through os._exit."""
+    import time
+    t0 = time.time()
+    r = run_bench("--gpus", "1", "--exercise-collectives", "--steps", "6", "--warmup", "2", "--batch", "4000", "--buffer-sets", "2",
+                  "--no-cpu-baseline", "--no-extras", "--gather-chunks", "2", "--mtg-comm-init-timeout", "3", env={"MTG_BENCH_TEST_COMM_HANG": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert time.time() - t0 < 300
+    out = last_json(r.stdout)
+    via = out["gather"]["via_mtg_comm"]
+    assert "did not complete" in via["error"] and "torch.distributed" in via["fell_back"]
+    assert out["gather"]["solve_plus_gather_ms"] > 0 and out["gather"]["own_slice_matches_local_solve"] is True
+
+
+@pytest.mark.gpu
 def test_two_rank_bench_carries_the_cpu_baseline():
     r = run_bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "2", "--batch", "2000",
                   "--buffer-sets", "2", "--no-gather", "--no-extras")
