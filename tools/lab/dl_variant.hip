@@ -37,6 +37,17 @@ __global__ __launch_bounds__(NP_ * 2 * kWave, LT_OCC) void lab_dl_kernel(const d
   mtg_solve_dl_body<CC, DL_, NP_, 0, 18, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr);
 }
 
+// shader clock while the measured launches run: one wave on its own stream spins (s_sleep) until the host raises a flag in mapped
+// memory, reading s_memtime (shader clock) and s_memrealtime (100 MHz) at both ends
+__global__ __launch_bounds__(64) void lab_clock_probe(volatile int* stop, long long* out) {
+  if (threadIdx.x != 0) return;
+  const long long r0 = wall_clock64(), c0 = clock64();
+  while (*stop == 0 && wall_clock64() - r0 < 2000000000LL) __builtin_amdgcn_s_sleep(32);     // (at most 20 s, whatever the host does)
+  const long long c1 = clock64(), r1 = wall_clock64();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 100000;
   const char* tag = argc > 2 ? argv[2] : "variant";
@@ -68,7 +79,9 @@ int main(int argc, char** argv) {
   constexpr int TPW = 64 / D;
   const int ntiles = (B + TPW - 1) / TPW;
   const int nunits = (ntiles + NP - 1) / NP;
-  const int nwg = std::min((NP == 1 ? 512 : 256) * LT_OCC, nunits);
+  // argv[3] (optional): number of persistent workgroups (default: one wave per SIMD of the whole chip) -- fewer workgroups = fewer busy
+  // SIMDs per CU: does a wave get faster when its CU's other SIMDs are idle (a shared resource) or not (its own latency chain)?
+  const int nwg = argc > 3 ? std::min(atoi(argv[3]), nunits) : std::min((NP == 1 ? 512 : 256) * LT_OCC, nunits);
   CK(hipMalloc(&ws, (size_t)nwg * (NP * 128) * std::max(1, C::WSJ * C::WSE) * 8));
   int* dstat; CK(hipMalloc(&dstat, 4)); CK(hipMemset(dstat, 0, 4));
   auto kern = lab_dl_kernel<C, D, NP>;
@@ -81,6 +94,11 @@ int main(int argc, char** argv) {
   };
   for (int i = 0; i < 3; ++i) go();
   CK(hipStreamSynchronize(st));
+  hipStream_t pst; CK(hipStreamCreateWithFlags(&pst, hipStreamNonBlocking));
+  int* stop; long long* pout;
+  CK(hipHostMalloc((void**)&stop, sizeof(int), hipHostMallocMapped)); CK(hipHostMalloc((void**)&pout, 2 * sizeof(long long), hipHostMallocMapped));
+  *stop = 0; pout[0] = pout[1] = 0;
+  hipLaunchKernelGGL(lab_clock_probe, dim3(1), dim3(64), 0, pst, (volatile int*)stop, pout);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double best = 1e30, sum = 0;
   const int reps = 5, per = 6;
@@ -91,6 +109,9 @@ int main(int argc, char** argv) {
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     best = std::min(best, (double)ms * 1e3 / per); sum += (double)ms * 1e3 / per;
   }
+  *stop = 1;
+  CK(hipStreamSynchronize(pst));
+  const double mhz = pout[1] > 0 ? (double)pout[0] / ((double)pout[1] * 0.01) : 0.0;
   int hs = 0; CK(hipMemcpy(&hs, dstat, 4, hipMemcpyDeviceToHost));
   const size_t nh = std::min<size_t>(ncoef, (size_t)4096 * K * D * N);
   std::vector<double> out(nh);
@@ -104,8 +125,8 @@ int main(int argc, char** argv) {
   }
   const double bytes = 8.0 * (K + D * NF + K * D * N) * B;
   std::printf("{\"tag\": \"%s\", \"N\": %d, \"K\": %d, \"D\": %d, \"B\": %d, \"NP\": %d, \"occ\": %d, \"wg\": %d, \"lds\": %zu, \"vgprs\": %d, \"scratch\": %zu, "
-              "\"us_mean\": %.2f, \"us_best\": %.2f, \"frac_8TBps\": %.4f, \"status\": %d, \"finite\": %s, \"max_abs\": %.6g, \"hash\": \"%016llx\"}\n",
-              tag, N, K, D, B, NP, LT_OCC, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
+              "\"shader_mhz\": %.0f, \"us_mean\": %.2f, \"us_best\": %.2f, \"frac_8TBps\": %.4f, \"status\": %d, \"finite\": %s, \"max_abs\": %.6g, \"hash\": \"%016llx\"}\n",
+              tag, N, K, D, B, NP, LT_OCC, nwg, lds, fa.numRegs, (size_t)fa.localSizeBytes, mhz, sum / reps, best, bytes / (sum / reps * 1e-6) / 8e12, hs,
               finite ? "true" : "false", amax, (unsigned long long)hsh);
   return 0;
 }
