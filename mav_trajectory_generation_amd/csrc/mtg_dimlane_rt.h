@@ -71,13 +71,7 @@ __device__ __forceinline__ void mtg_lane_forward_rt(const MtgParams& P, long lon
   constexpr int M0 = DIR > 0 ? C::MS : C::ME;
   static_assert(C::popc(M0) == H, "run-time-K body: the trajectory ends are fully fixed (no back-substitution data for step 0)");
   const int K = P.K;
-  ln.flags = 0;
-#pragma unroll
-  for (int p = 0; p < H; ++p) {
-    ln.rc[0][p] = 0.0;
-#pragma unroll
-    for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
-  }
+  mtg_lane_reset<C, DIR>(ln);
   // Issue order per step: inputs of step j + 1 + PD, arithmetic of step j, then step j's back-substitution stores.  The segment
   // time and the fixed values of the right vertex are requested PD + 1 steps ahead (a ring of PD entries: 1 + popc(MI) doubles
   // each): one step of arithmetic (~0.7 us) does not cover the latency of a load that goes to HBM behind a store stream.
@@ -139,6 +133,7 @@ __device__ __forceinline__ void mtg_lane_forward_rt(const MtgParams& P, long lon
       shift(T_nxt);
     }
   }
+  mtg_unscale_carried<C, DIR>(P, ln);      // (scaled-variable chain: plain Schur complement / right-hand side for the middle vertex)
 }
 
 template <class C, int R, int L, int DIR, class IO>
@@ -218,22 +213,24 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
         for (int k = 0; k < C::DLW; ++k) pt[k] = perm[k] + zt;
         mtg_rs_unpack<C>(pt, tail.Gs[r], C::MI, C::MI, Gw);
       }
-      if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl);
-      else mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, tail.g[r], xr, xl);
+      MtgScaledEnds<C> ye;
+      if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl, ye);
+      else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl, ye);
       tie_on = xl[0][H - 1];
       if (r > 0 && j - 1 >= 1) request_inputs(j - 1);    // next: tail position r - 1 (its G comes from registers)
       else request_head(j - 1);                          // next: the last head step, or step 0
-      mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io);
+      mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io, ye);
     }
   }
   for (int j = (nh - 1 < kc - 1 ? nh - 1 : kc - 1); j >= 1; --j) {     // head steps nh - 1 .. 1
     double xl[1][H];
     const double T_use = T_cur;
-    if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl);
-    else mtg_bwd_backsub<C>(C::MI, C::MI, fl, Gw, gw, xr, xl);
+    MtgScaledEnds<C> ye;
+    if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl, ye);
+    else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl, ye);
     tie_on = xl[0][H - 1];
     request_head(j - 1);
-    mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io);
+    mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io, ye);
   }
   {   // step 0: every slot of the end vertex is fixed
     double xl[1][H];

@@ -277,6 +277,21 @@ template <int DIR> MTG_HD int mtg_seg(int K, int j) { return DIR > 0 ? j : K - 1
 template <int DIR> MTG_HD int mtg_vl(int K, int j) { return DIR > 0 ? j : K - j; }
 template <int DIR> MTG_HD int mtg_vr(int K, int j) { return DIR > 0 ? j + 1 : K - 1 - j; }
 
+// Scaled-variable chain (round 6).  The forward sweep carries the Schur complement and its right-hand side in the SCALING OF THE
+// CURRENT SEGMENT: with tau = DIR T, s_p = tau^p, t = T^(1-2d) it holds  Sc^ = Sc / (t s_p s_q),  rc^ = rc / (t s_p)  and solves for
+// x^ = s_p x_p.  In these variables the segment's blocks are the CONSTANT tables: pivot block D^ = Sc^ + H1_ss, coupling
+// U^ = H1_se, the right vertex's diagonal H1_ee -- no products with powers of T for U (2 f_l f_r multiplications per step) nor
+// for the diagonal block (f_r (f_r + 1)); what is left of the assembly is the conversion of the carried block from the previous
+// segment's scaling, one FMA per entry: D^_pq = kappa sigma^(p+q) Sc^'_pq + H1_ss,pq  with sigma = tau' / tau and
+// kappa = (T' / T)^(1-2d) (mtg_step_scales: for d = h - 1 all 2h - 1 factors are powers of T / T' and one T' / T).  The
+// back-substitution works on x^ as well and hands the scaled vertex values s_p x_p, which the coefficient recovery needs anyway
+// (impl/...:276-277 through the scaling identity), to mtg_recover.  Unscaled quantities cross the function boundaries: the two
+// directions exchange Sc, rc (mtg_unscale_carried at the end of the forward phase), xl / xr / d_P are plain derivatives.
+// MTG_SCALED_CHAIN=0: the assembly of rounds 1-5 (every block formed as T^(1-2d) S H1 S).
+#ifndef MTG_SCALED_CHAIN
+#define MTG_SCALED_CHAIN 1
+#endif
+
 template <class C>
 struct MtgLane {
   double G[C::kRegShared ? 1 : C::KREG][C::H][C::H];  // G_v = Dtilde_v^-1 U_v          (static mode: registers; steps >= C::WSJ)
@@ -286,8 +301,27 @@ struct MtgLane {
   double rc[C::D][C::H];          // its right-hand side
   double T[C::KCS];               // static mode: this lane's segment times, chain order
   double fx[C::D][C::NC];         // static mode: this lane's fixed values (columns colBegin..colEnd)
+  double cT, cTinv;               // MTG_SCALED_CHAIN: signed time DIR T (and its reciprocal) of the segment whose scaling Sc / rc are in
   int flags;
 };
+
+// start of a half-chain: nothing carried, unit scaling
+template <class C, int DIR>
+MTG_HD void mtg_lane_reset(MtgLane<C>& ln) {
+  ln.flags = 0;
+#pragma unroll
+  for (int p = 0; p < C::H; ++p) {
+#pragma unroll
+    for (int q = 0; q < C::H; ++q) ln.Sc[p][q] = 0.0;
+  }
+#pragma unroll
+  for (int dm = 0; dm < C::D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < C::H; ++p) ln.rc[dm][p] = 0.0;
+  }
+  ln.cT = DIR > 0 ? 1.0 : -1.0;
+  ln.cTinv = ln.cT;
+}
 
 // Static mode: issue every input load of this lane's half-chain up front with incrementally
 // advanced per-lane pointers (one v_lshl_add_u64 per load, no hoistable 64-bit stride products).
@@ -474,6 +508,82 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
   for (int p = 0; p < H; ++p) bs[p] = mtg_mul(base, s[p]);
 }
 
+// Scaled-variable chain: scale vector of the step, s[p] = (DIR T)^p, and the factors that bring the carried block from the previous
+// step's scaling (ln.cT) into this one:  pw[m] = kappa sigma^m,  sigma = tau_prev / tau,  kappa = (T_prev / T)^(1 - 2 d)
+// (entry (p, q) of the Schur complement takes pw[p + q], entry p of its right-hand side pw[p]).  With rho = 1 / sigma the factor
+// is rho^(2d - 1 - m): compile-time derivative => the non-negative exponents come from one power table of rho, the negative ones
+// from one of sigma (d = h - 1: 2h - 2 powers of rho and sigma itself).
+// pw[m] = rho^(2 DV - 1 - m), m = 0 .. 2H - 2, from the power tables of rho and sigma = 1 / rho
+template <int H, int DV>
+MTG_HD void mtg_pw_table(double rho, double sigma, double (&pw)[2 * H - 1]) {
+  constexpr int E = 2 * DV - 1;
+  constexpr int NR = E > 0 ? E + 1 : 1;                           // rho^0 .. rho^E
+  constexpr int NS = 2 * H - 2 - E > 0 ? 2 * H - 2 - E + 1 : 1;   // sigma^0 .. sigma^(2H - 2 - E)
+  double rp[NR], sg[NS];
+  rp[0] = 1.0; sg[0] = 1.0;
+  if constexpr (NR > 1) rp[1] = rho;
+  if constexpr (NS > 1) sg[1] = sigma;
+#pragma unroll
+  for (int e = 2; e < NR; ++e) rp[e] = mtg_mul(rp[e / 2], rp[e - e / 2]);
+#pragma unroll
+  for (int e = 2; e < NS; ++e) sg[e] = mtg_mul(sg[e / 2], sg[e - e / 2]);
+#pragma unroll
+  for (int m = 0; m < 2 * H - 1; ++m) pw[m] = E - m >= 0 ? rp[E - m >= 0 ? E - m : 0] : sg[m - E > 0 ? m - E : 0];
+}
+// run-time derivative (generic kernels): the same table, selected by a wave-uniform branch -- the generic and the specialised
+// kernels of a shape then form identical factors (a one-ulp difference in them is round-off x cond(R_PP) in the solution)
+template <int H, int DV>
+MTG_HD void mtg_pw_dispatch(int deriv, double rho, double sigma, double (&pw)[2 * H - 1]) {
+  if (deriv == DV) mtg_pw_table<H, DV>(rho, sigma, pw);
+  else if constexpr (DV + 1 < H) mtg_pw_dispatch<H, DV + 1>(deriv, rho, sigma, pw);
+  else mtg_pw_table<H, DV>(rho, sigma, pw);     // (not reached: derivative_to_optimize < h)
+}
+
+template <class C, int DIR>
+MTG_HD void mtg_step_scales(const MtgParams& P, double T, const MtgLane<C>& ln, double (&s)[C::H], double (&pw)[2 * C::H - 1],
+                            double& tinv, int& flags) {
+  constexpr int H = C::H;
+  if (!(T > 0.0)) flags |= MTG_FLAG_BAD_TIME;
+  tinv = mtg_rcp(T);
+  const double ts = DIR > 0 ? T : -T;
+  s[0] = 1.0;
+  if constexpr (H > 1) s[1] = ts;
+#pragma unroll
+  for (int p = 2; p < H; ++p) s[p] = mtg_mul(s[p / 2], s[p - p / 2]);   // depth log2(p)
+  const double sigma = mtg_mul(ln.cT, DIR > 0 ? tinv : -tinv);          // tau_prev / tau  (> 0: both carry DIR's sign)
+  const double rho = mtg_mul(ts, ln.cTinv);                             // tau / tau_prev
+  if constexpr (C::kCT) mtg_pw_table<H, C::DV>(rho, sigma, pw);
+  else mtg_pw_dispatch<H, 0>(P.deriv, rho, sigma, pw);
+}
+
+// End of the forward phase (scaled-variable chain): the carried Schur complement and right-hand side leave the last segment's
+// scaling -- the two directions add theirs at the middle vertex (mtg_pack_mid / mtg_solve_mid work on plain quantities).
+template <class C, int DIR>
+MTG_HD void mtg_unscale_carried(const MtgParams& P, MtgLane<C>& ln) {
+#if MTG_SCALED_CHAIN
+  constexpr int H = C::H;
+  const int deriv = mtg_deriv<C>(P);
+  const double T = ln.cT < 0.0 ? -ln.cT : ln.cT, tinv = ln.cTinv < 0.0 ? -ln.cTinv : ln.cTinv;
+  const double base = deriv == 0 ? T : mtg_powi<2 * H - 1>(tinv, 2 * deriv - 1);
+  double s[H], bs[H];
+  s[0] = 1.0;
+  if constexpr (H > 1) s[1] = ln.cT;
+#pragma unroll
+  for (int p = 2; p < H; ++p) s[p] = mtg_mul(s[p / 2], s[p - p / 2]);
+#pragma unroll
+  for (int p = 0; p < H; ++p) bs[p] = mtg_mul(base, s[p]);
+#pragma unroll
+  for (int p = 0; p < H; ++p) {
+#pragma unroll
+    for (int q = 0; q <= p; ++q) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), ln.Sc[p][q]);
+#pragma unroll
+    for (int dm = 0; dm < C::D; ++dm) ln.rc[dm][p] = mtg_mul(bs[p], ln.rc[dm][p]);
+  }
+  ln.cT = 1.0;       // plain quantities from here on
+  ln.cTinv = 1.0;
+#endif
+}
+
 // One forward elimination step (chain step j): completes the left vertex, produces
 // (G, g) for back-substitution and the carried Schur complement for the right vertex.
 // The arithmetic of one step on inputs that are already in registers: segment time T and the (unscaled) fixed values of
@@ -484,8 +594,13 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
                               const double (&fix_l)[C::D][C::H], const double (&fix_r)[C::D][C::H],
                               double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D, N = C::N;
+#if MTG_SCALED_CHAIN
+  double s[H], pw[2 * H - 1], tinv;
+  mtg_step_scales<C, DIR>(P, T, ln, s, pw, tinv, ln.flags);
+#else
   double s[H], bs[H], tinv;
   mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, ln.flags);
+#endif
 
   // scaled fixed values
   double val_l[D][H], val_r[D][H];
@@ -544,8 +659,13 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
     for (int p = 0; p < H; ++p) {
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
+#if MTG_SCALED_CHAIN
+        rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(pw[p], ln.rc[dm][p], -accl[p][dm]);
+        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -accr[p][dm];
+#else
         rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[p][dm], ln.rc[dm][p]);
         rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : mtg_mul(-bs[p], accr[p][dm]);
+#endif
       }
     }
   }
@@ -562,8 +682,13 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         A[p][q] = 0.0;
         U[p][q] = 0.0;
         if (!((ml >> p) & 1)) {
+#if MTG_SCALED_CHAIN
+          if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(pw[p + q], ln.Sc[p][q], hc[p * N + q]);
+          if (!((mr >> q) & 1)) U[p][q] = hc[p * N + H + q];
+#else
           if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(mtg_mul(bs[p], s[q]), hc[p * N + q], ln.Sc[p][q]);
           if (!((mr >> q) & 1)) U[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hc[p * N + H + q]);
+#endif
         }
       }
     }
@@ -585,11 +710,15 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) X[p][H + dm] = rv[dm][p];
     }
+    // (scaled-variable chain: U is the constant table, so the first free row of X and the initial value of every other row are
+    // literals; the rows are eliminated from the nearest one down, so that only the LAST product of a row meets two literals'
+    // worth of operands -- an FMA takes one)
 #pragma unroll
     for (int i = 0; i < H; ++i) {
       if ((ml >> i) & 1) continue;
 #pragma unroll
-      for (int k = 0; k < i; ++k) {
+      for (int kk = 0; kk < i; ++kk) {
+        const int k = MTG_SCALED_CHAIN ? i - 1 - kk : kk;
         if ((ml >> k) & 1) continue;
 #pragma unroll
         for (int c = 0; c < H + D; ++c) {
@@ -608,7 +737,11 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
       for (int q = 0; q < H; ++q) {
         ln.Sc[p][q] = 0.0;
+#if MTG_SCALED_CHAIN
+        if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = hrr[(H + p) * N + H + q];
+#else
         if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
+#endif
       }
     }
 #pragma unroll
@@ -617,7 +750,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       for (int p = 0; p < H; ++p) ln.rc[dm][p] = rnext[dm][p];
     }
 #pragma unroll
-    for (int m = 0; m < H; ++m) {
+    for (int mm = 0; mm < H; ++mm) {
+      const int m = MTG_SCALED_CHAIN ? H - 1 - mm : mm;     // (scaled chain: the literal row of X -- the first free one -- last)
       if ((ml >> m) & 1) continue;
 #pragma unroll
       for (int p = 0; p < H; ++p) {
@@ -684,7 +818,11 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       ln.Sc[p][q] = 0.0;
+#if MTG_SCALED_CHAIN
+      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = hrr[(H + p) * N + H + q];
+#else
       if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
+#endif
     }
   }
 #pragma unroll
@@ -717,6 +855,10 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         G[p][q] = (((ml >> p) & 1) || ((ml >> q) & 1) || q > p) ? 0.0 : (q == p ? dinv[p] : A[p][q]);
     }
   }
+#if MTG_SCALED_CHAIN
+  ln.cT = DIR > 0 ? T : -T;          // what is carried on is in this segment's scaling
+  ln.cTinv = DIR > 0 ? tinv : -tinv;
+#endif
 }
 
 // segment time of chain step j (static mode: preloaded register; otherwise a global load)
@@ -735,6 +877,16 @@ template <class C>
 MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mask, MtgLane<C>& ln) {
   if constexpr (!C::kCT) {
     if (P.rhs == nullptr) return;
+#if MTG_SCALED_CHAIN
+    // the carried right-hand side is in the scaling of ln.cT: entry p divided by t s_p, t = |cT|^(1-2d), s_p = cT^p
+    double rs[C::H];
+    {
+      const double Ta = ln.cT < 0.0 ? -ln.cT : ln.cT, Tai = ln.cTinv < 0.0 ? -ln.cTinv : ln.cTinv;
+      rs[0] = P.deriv == 0 ? Tai : mtg_powi<2 * C::H - 1>(Ta, 2 * P.deriv - 1);
+#pragma unroll
+      for (int p = 1; p < C::H; ++p) rs[p] = rs[p - 1] * ln.cTinv;
+    }
+#endif
     const int off = mtg_offP<C>(P, v);
 #pragma unroll
     for (int dm = 0; dm < C::D; ++dm) {
@@ -742,7 +894,11 @@ MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mas
       for (int p = 0; p < C::H; ++p) {
         if ((mask >> p) & 1) continue;
         const int col = off + (p - mtg_popc(mask & ((1 << p) - 1)));
+#if MTG_SCALED_CHAIN
+        ln.rc[dm][p] += P.rhs[b * P.rh_b + (long long)(P.dim0 + dm) * P.rh_d + (long long)col * P.rh_c] * rs[p];
+#else
         ln.rc[dm][p] += P.rhs[b * P.rh_b + (long long)(P.dim0 + dm) * P.rh_d + (long long)col * P.rh_c];
+#endif
       }
     }
   }
@@ -778,9 +934,12 @@ struct MtgDirectOut {
   }
 };
 
-template <class C, int OUT, class IO>
+// SGN != 0 (scaled-variable chain): the back-substitution hands over yS / yE = (SGN T)^p x_p of the segment's start / end vertex,
+// which is dl up to the sign of the odd derivatives in the backward direction; SGN == 0: dl is formed here.
+template <class C, int OUT, int SGN = 0, class IO>
 MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
-                          const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H], IO& io) {
+                          const double (&xS)[C::D][C::H], const double (&xE)[C::D][C::H], IO& io,
+                          const double (*yS)[C::H] = nullptr, const double (*yE)[C::H] = nullptr) {
   constexpr int H = C::H, D = C::D, N = C::N;
   int dummy = 0;
   double s[H], bs[H], tinv;
@@ -819,8 +978,13 @@ MTG_HD double mtg_recover(const MtgParams& P, long long b, int seg, double T,
     double clo[H + 1];
 #pragma unroll
     for (int p = 0; p < H; ++p) {
-      dl[dm][p] = mtg_mul(s[p], xS[dm][p]);
-      dl[dm][H + p] = mtg_mul(s[p], xE[dm][p]);
+      if constexpr (SGN == 0) {
+        dl[dm][p] = mtg_mul(s[p], xS[dm][p]);
+        dl[dm][H + p] = mtg_mul(s[p], xE[dm][p]);
+      } else {
+        dl[dm][p] = (SGN < 0 && (p & 1)) ? -yS[dm][p] : yS[dm][p];
+        dl[dm][H + p] = (SGN < 0 && (p & 1)) ? -yE[dm][p] : yE[dm][p];
+      }
       clo[p] = mtg_mul(xS[dm][p], invfact[p]);
       qs[dm][p] = mtg_mul(dl[dm][p], invfact[p]);
     }
@@ -1024,13 +1188,46 @@ MTG_HD constexpr bool mtg_keep(int p, int q, int ml, int mr) {
   return !((mr >> q) & 1);
 }
 
+// s_p x_p of a chain step's two vertices (every slot, s = (DIR T)^p): what the back-substitution of the scaled-variable chain
+// works on, and what the coefficient recovery multiplies A(1)^-1 with
+template <class C>
+struct MtgScaledEnds { double l[C::D][C::H], r[C::D][C::H]; };
+
+// s[p] = (DIR T)^p, si[p] = (DIR T)^-p
+template <int H, int DIR>
+MTG_HD void mtg_bwd_scales(double T, double (&s)[H], double (&si)[H]) {
+  const double tinv = mtg_rcp(T);
+  s[0] = 1.0; si[0] = 1.0;
+  if constexpr (H > 1) { s[1] = DIR > 0 ? T : -T; si[1] = DIR > 0 ? tinv : -tinv; }
+#pragma unroll
+  for (int p = 2; p < H; ++p) {
+    s[p] = mtg_mul(s[p / 2], s[p - p / 2]);
+    si[p] = mtg_mul(si[p / 2], si[p - p / 2]);
+  }
+}
+
 // Back-substitution of one chain step from the FACTOR of its pivot block (MtgCfg::kFS): F strict lower = L, diagonal = 1 / d,
 // xl = [fixed values | g - (L D L^T)^-1 (U xr)], U = T^(1-2d) S_l H1_lr S_r rebuilt from the table and the segment time.
 template <class C, int DIR>
 MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
                                const double (&F)[C::H][C::H], const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H],
-                               double (&xl)[C::D][C::H]) {
+                               double (&xl)[C::D][C::H], MtgScaledEnds<C>& ye) {
   constexpr int H = C::H, D = C::D, N = C::N;
+#if MTG_SCALED_CHAIN
+  // scaled-variable chain: F factors the pivot block in the segment's scaling, U^ = H1_lr is the table itself;
+  // x^_l = g^ - (L D L^T)^-1 (H1_lr x^_r) with x^_r = s x_r, then x_l = x^_l / s
+  double s[H], si[H];
+  mtg_bwd_scales<H, DIR>(T, s, si);
+  const double* hc = mtg_h1<C>(P);
+  double (&y)[D][H] = ye.r;
+  double w[H][D], dinv[H];
+#pragma unroll
+  for (int q = 0; q < H; ++q) {
+#pragma unroll
+    for (int dm = 0; dm < D; ++dm) y[dm][q] = mtg_pin(mtg_mul(s[q], mtg_pin(xr[dm][q])));
+  }
+#else
+  (void)ye;
   double s[H], bs[H], tinv;
   int dummy = 0;
   mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, dummy);
@@ -1041,6 +1238,7 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) y[dm][q] = mtg_pin(mtg_mul(s[q], mtg_pin(xr[dm][q])));
   }
+#endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
     dinv[p] = F[p][p];
@@ -1058,11 +1256,13 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
       for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_fma(c, y[dm][q], w[p][dm]);
     }
   }
+#if !MTG_SCALED_CHAIN
 #pragma unroll
   for (int p = 0; p < H; ++p) {
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_pin(mtg_mul(bs[p], w[p][dm]));
   }
+#endif
   // (y above is formed from a pinned COPY of xr: the same product s x_r is formed by mtg_recover for the segment's coefficients
   // (dl), where the A^-1 row of coefficient h has entries +-1, fma(1, dl, acc) folds to an addition and the compiler contracts
   // the product into it or not depending on the product's other uses.  Sharing the product with this function changed that
@@ -1100,21 +1300,66 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
       for (int dm = 0; dm < D; ++dm) w[i][dm] = mtg_fma(-F[k][i], w[k][dm], w[i][dm]);
     }
   }
+#if MTG_SCALED_CHAIN
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      ye.l[dm][p] = ((ml >> p) & 1) ? mtg_pin(mtg_mul(s[p], fix_l[dm][p])) : mtg_pin(mtg_pin(g[dm][p]) - w[p][dm]);
+      xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(mtg_mul(ye.l[dm][p], si[p]));
+    }
+  }
+#else
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
     for (int p = 0; p < H; ++p) xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(g[dm][p]) - w[p][dm];
   }
+#endif
 }
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
 // Back-substitution of one chain step: xl = [fixed values | g - G xr] (all slots of the left vertex).  fix_l: the
 // (unscaled) fixed values of the left vertex, already in registers.  G and g are dead afterwards.
-template <class C>
-MTG_HD void mtg_bwd_backsub(int ml, int mr, const double (&fix_l)[C::D][C::H], const double (&G)[C::H][C::H],
-                            const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H], double (&xl)[C::D][C::H]) {
+template <class C, int DIR>
+MTG_HD void mtg_bwd_backsub(const MtgParams& P, int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
+                            const double (&G)[C::H][C::H], const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H],
+                            double (&xl)[C::D][C::H], MtgScaledEnds<C>& ye) {
   constexpr int H = C::H, D = C::D;
+  (void)P;
+#if MTG_SCALED_CHAIN
+  // scaled-variable chain: G, g relate x^ = s x of the two vertices
+  double s[H], si[H];
+  mtg_bwd_scales<H, DIR>(T, s, si);
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      ye.r[dm][p] = mtg_pin(mtg_mul(s[p], mtg_pin(xr[dm][p])));
+      ye.l[dm][p] = ((ml >> p) & 1) ? mtg_pin(mtg_mul(s[p], fix_l[dm][p])) : g[dm][p];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < H; ++q) {
+    if ((mr >> q) & 1) continue;
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if ((ml >> p) & 1) continue;
+#pragma unroll
+      for (int dm = 0; dm < D; ++dm) ye.l[dm][p] = mtg_fma(-G[p][q], ye.r[dm][q], ye.l[dm][p]);
+    }
+  }
+#pragma unroll
+  for (int dm = 0; dm < D; ++dm) {
+#pragma unroll
+    for (int p = 0; p < H; ++p) {
+      if (!((ml >> p) & 1)) ye.l[dm][p] = mtg_pin(ye.l[dm][p]);
+      xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(mtg_mul(ye.l[dm][p], si[p]));
+    }
+  }
+#else
+  (void)T; (void)ye;
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
@@ -1130,29 +1375,46 @@ MTG_HD void mtg_bwd_backsub(int ml, int mr, const double (&fix_l)[C::D][C::H], c
       for (int dm = 0; dm < D; ++dm) xl[dm][p] = mtg_fma(-G[p][q], xr[dm][q], xl[dm][p]);
     }
   }
+#endif
 }
 
 // Second half of a backward step: optional d_P output, coefficient recovery of the segment the step completes
-// (T: its time), xr <- xl.
+// (T: its time), xr <- xl.  ye: the scaled vertex values the back-substitution formed (scaled-variable chain); the overload
+// without it forms them in mtg_recover (a step whose left vertex is copied, not solved).
 // No `active` guard: tail lanes are clamped duplicates of the last trajectory and store identical values to identical
 // addresses.  A per-lane condition here makes the compiler unswitch the chain loop on it, and the wave-cooperative
 // coefficient drain (all 64 lanes must take part together) would run in two halves.
-template <class C, int DIR, int OUT, class IO>
-MTG_HD double mtg_bwd_finish(const MtgParams& P, long long b, int j, int ml, double T, const double (&xl)[C::D][C::H],
-                             double (&xr)[C::D][C::H], IO& io) {
+template <class C, int DIR, int OUT, bool PRE, class IO>
+MTG_HD double mtg_bwd_finish_impl(const MtgParams& P, long long b, int j, int ml, double T, const double (&xl)[C::D][C::H],
+                                  double (&xr)[C::D][C::H], IO& io, const MtgScaledEnds<C>* ye) {
   constexpr int H = C::H, D = C::D;
   const int K = mtg_nseg<C>(P);
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j);
   mtg_store_free<C, OUT>(P, b, vl, ml, xl);
   double cost;
-  if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr, io);
-  else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl, io);
+  if constexpr (PRE && MTG_SCALED_CHAIN != 0) {
+    if (DIR > 0) cost = mtg_recover<C, OUT, 1>(P, b, seg, T, xl, xr, io, ye->l, ye->r);
+    else cost = mtg_recover<C, OUT, -1>(P, b, seg, T, xr, xl, io, ye->r, ye->l);
+  } else {
+    if (DIR > 0) cost = mtg_recover<C, OUT>(P, b, seg, T, xl, xr, io);
+    else cost = mtg_recover<C, OUT>(P, b, seg, T, xr, xl, io);
+  }
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
     for (int p = 0; p < H; ++p) xr[dm][p] = xl[dm][p];
   }
   return cost;
+}
+template <class C, int DIR, int OUT, class IO>
+MTG_HD double mtg_bwd_finish(const MtgParams& P, long long b, int j, int ml, double T, const double (&xl)[C::D][C::H],
+                             double (&xr)[C::D][C::H], IO& io) {
+  return mtg_bwd_finish_impl<C, DIR, OUT, false>(P, b, j, ml, T, xl, xr, io, nullptr);
+}
+template <class C, int DIR, int OUT, class IO>
+MTG_HD double mtg_bwd_finish(const MtgParams& P, long long b, int j, int ml, double T, const double (&xl)[C::D][C::H],
+                             double (&xr)[C::D][C::H], IO& io, const MtgScaledEnds<C>& ye) {
+  return mtg_bwd_finish_impl<C, DIR, OUT, true>(P, b, j, ml, T, xl, xr, io, &ye);
 }
 
 template <class C, int DIR, int OUT, class IO>
@@ -1161,9 +1423,11 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
                            double (&xr)[C::D][C::H], IO& io, bool active) {
   (void)active;
   double fix_l[C::D][C::H], xl[C::D][C::H];
+  MtgScaledEnds<C> ye;
+  const double T = mtg_step_time<C, DIR>(P, b, j, ln);
   mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(mtg_nseg<C>(P), j), ml, ln, fix_l);
-  mtg_bwd_backsub<C>(ml, mr, fix_l, G, g, xr, xl);
-  return mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
+  mtg_bwd_backsub<C, DIR>(P, ml, mr, T, fix_l, G, g, xr, xl, ye);
+  return mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, T, xl, xr, io, ye);
 }
 
 // Back-substitution data of one chain step in the lane-coalesced workspace (element stride = number of lanes):
@@ -1367,18 +1631,8 @@ __device__ __forceinline__ void mtg_rs_unpack(const int (&perm)[C::DLW > 0 ? C::
 template <class C, int DIR>
 MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, double* wsl, bool do_preload = true) {
   constexpr int H = C::H, D = C::D;
-  ln.flags = 0;
   if (do_preload) mtg_preload<C, DIR>(P, b, ln);
-#pragma unroll
-  for (int p = 0; p < H; ++p) {
-#pragma unroll
-    for (int q = 0; q < H; ++q) ln.Sc[p][q] = 0.0;
-  }
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-#pragma unroll
-    for (int p = 0; p < H; ++p) ln.rc[dm][p] = 0.0;
-  }
+  mtg_lane_reset<C, DIR>(ln);
   if constexpr (C::kStatic) {
     constexpr int KC = DIR > 0 ? C::KA : C::KB;
 #pragma unroll
@@ -1453,9 +1707,11 @@ MTG_HD void mtg_lane_forward(const MtgParams& P, long long b, MtgLane<C>& ln, do
         mtg_ws_store<C>(mtg_glb(wsl + (long long)j * (H * H + D * H) * P.ws_stride), P.ws_stride, G, g, ml, mr);
       }
       // the middle vertex's explicit right-hand side: once, by the forward direction (both directions sum the two carried ones)
+      mtg_unscale_carried<C, DIR>(P, ln);
       if (DIR > 0) mtg_add_explicit_rhs<C>(P, b, (K + 1) / 2, mtg_mask<C>(P, (K + 1) / 2), ln);
     }
   }
+  if constexpr (C::kCT) mtg_unscale_carried<C, DIR>(P, ln);     // (the generic branch above has already left the scaling)
 }
 
 // `active` = this lane owns a real trajectory (tail tiles run clamped duplicates whose outputs
@@ -1515,20 +1771,21 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         double fix_l[D][H], xl[D][H];
         mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(C::KT, j), ml, ln, fix_l);
         const int jr = j - C::WSJ < 0 ? 0 : j - C::WSJ;
+        MtgScaledEnds<C> ye;
+        const double Tj = mtg_step_time<C, DIR>(P, b, j, ln);
         if constexpr (C::kFS) {
-          const double Tj = mtg_step_time<C, DIR>(P, b, j, ln);
-          if (j < C::WSJ) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, gw, xr, xl);
-          else if constexpr (C::kRegShared) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl);
-          else mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl);
+          if (j < C::WSJ) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, gw, xr, xl, ye);
+          else if constexpr (C::kRegShared) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl, ye);
+          else mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl, ye);
         } else {
-          if (j < C::WSJ) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, gw, xr, xl);
-          else if constexpr (C::kRegShared) mtg_bwd_backsub<C>(ml, mr, fix_l, Gw, ln.g[jr], xr, xl);
-          else mtg_bwd_backsub<C>(ml, mr, fix_l, ln.G[jr], ln.g[jr], xr, xl);
+          if (j < C::WSJ) mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, Gw, gw, xr, xl, ye);
+          else if constexpr (C::kRegShared) mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl, ye);
+          else mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl, ye);
         }
         // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
         // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
         if (j >= 1 && (j - 1 < C::WSJ || C::kRegShared)) request(j - 1);
-        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, mtg_step_time<C, DIR>(P, b, j, ln), xl, xr, io);
+        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, Tj, xl, xr, io, ye);
       } else {
         cost += mtg_bwd_step<C, DIR, OUT>(P, b, j, ml, mr, ln, ln.G[j], ln.g[j], xr, io, active);
       }
@@ -1557,10 +1814,11 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
       for (int j = kc - 1; j >= 0; --j) {
         double xl[D][H];
         const double T_use = T_cur;
-        if (j == 0) mtg_bwd_backsub<C>(M0, C::MI, fl, G, g, xr, xl);
-        else mtg_bwd_backsub<C>(C::MI, C::MI, fl, G, g, xr, xl);
+        MtgScaledEnds<C> ye;
+        if (j == 0) mtg_bwd_backsub<C, DIR>(P, M0, C::MI, T_use, fl, G, g, xr, xl, ye);
+        else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, G, g, xr, xl, ye);
         if (j > 0) request(j - 1);
-        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, j == 0 ? M0 : C::MI, T_use, xl, xr, io);
+        cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, j == 0 ? M0 : C::MI, T_use, xl, xr, io, ye);
       }
     } else {
       for (int j = kc - 1; j >= 0; --j) {

@@ -50,7 +50,7 @@ def test_emulated_rows_vs_oracle_and_lane_code(emu, n, k):
     assert helpers.poly_relerr(co, ref) < {8: 1e-10, 10: 2e-9, 12: 5e-6}[n]   # (N = 12: the float64 restatement is the side that is off)
     lane = ctypes.CDLL(os.path.join(ROOT, "tests", "libmtg_host_emu.so"))
     _, co_lane, _, _, st = helpers.emu_run(lane, n, 3, k, d, masks, times, d_fixed, want_cost=False)
-    assert st == 0 and helpers.poly_relerr(co, co_lane) < (1e-11 if n <= 10 else 1e-9)   # (another elimination order: round-off x cond)
+    assert st == 0 and helpers.poly_relerr(co, co_lane) < (1e-11 if n <= 10 else 1e-8)   # (another elimination order: round-off x cond; N = 12 / K = 33: each side is 1.4e-9 ... 1.8e-9 from the 50-digit solution on the trajectory with the segment-time ratio 16.5)
 
 
 def test_emulated_rows_other_derivatives_and_flags(emu):

@@ -111,7 +111,10 @@ def test_queue_update_and_mixed_entry_points_agree_with_single_solves(ctx, case)
     ctx.sync()
     rel, _ = ctx.compare_coefficients(cu, rc)
     assert rel < tol
-    assert torch.allclose(ju, rj, rtol=1e-9 if n <= 10 else 1e-7, atol=0)
+    # (the update path starts from the solver's d_P rounded to float64, the solve's own cost from the scaled vertex values of its
+    # back-substitution: coefficients one ulp apart.  For d = h - 1 that is 1e-11 in 0.5 c^T Q c; for d < h - 1 the monomial-basis
+    # quadratic form cancels and one ulp in c moves the cost by up to 2e-8 -- measured, tools/lab/cost_probe.py)
+    assert torch.allclose(ju, rj, rtol=(1e-9 if d == n // 2 - 1 else 1e-7) if n <= 10 else 1e-7, atol=0)
     if dim == 3 and k >= 2:
         solver = m.MixedBatchSolver(ctx, n_streams=1)
         buckets = [dict(n_coeffs=n, derivative=d, masks=masks, times=sets[i][0], d_fixed=sets[i][1], layout=layout) for i in (1, 2)]

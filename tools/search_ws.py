@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
 SHAPES = {4: (15, 1, 15, 3), 5: (31, 1, 31, 4), 6: (63, 1, 63, 5)}      # (start mask, interior mask, end mask, derivative)
-LDS_STEPS = {4: 8, 5: 5, 6: 3}                                          # steps that fit the LDS next to the output slabs
+LDS_STEPS = {4: 8, 5: 6, 6: 4}                                          # steps that fit the LDS next to the output slabs
 REG_STEPS = {4: 9, 5: 6, 6: 2}                                          # where the search starts (steps the registers hold)
 
 
@@ -43,7 +43,7 @@ def resources(H, K, WS, LS, RS=0, full=False):
     return scratch, spills
 
 
-RS_REG_STEPS = {4: 16, 5: 10, 6: 5}                                    # register steps with the shared storage (search start)
+RS_REG_STEPS = {4: 16, 5: 12, 6: 8}                                    # register steps with the shared storage (search start)
 
 
 def best(H, K, RS=1):
