@@ -215,7 +215,7 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
       }
       MtgScaledEnds<C> ye;
       if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl, ye);
-      else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl, ye);
+      else mtg_bwd_backsub<C, DIR>(C::MI, C::MI, T_use, fl, Gw, tail.g[r], xr, xl, ye);
       tie_on = xl[0][H - 1];
       if (r > 0 && j - 1 >= 1) request_inputs(j - 1);    // next: tail position r - 1 (its G comes from registers)
       else request_head(j - 1);                          // next: the last head step, or step 0
@@ -227,7 +227,7 @@ __device__ __forceinline__ void mtg_lane_finish_rt(const MtgParams& P, long long
     const double T_use = T_cur;
     MtgScaledEnds<C> ye;
     if constexpr (C::kFS) mtg_bwd_backsub_fs<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl, ye);
-    else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, Gw, gw, xr, xl, ye);
+    else mtg_bwd_backsub<C, DIR>(C::MI, C::MI, T_use, fl, Gw, gw, xr, xl, ye);
     tie_on = xl[0][H - 1];
     request_head(j - 1);
     mtg_bwd_finish<C, DIR, 0>(P, b, j, C::MI, T_use, xl, xr, io, ye);

@@ -14,6 +14,9 @@
 // H(1), A(1)^-1 are exact rational constants (mtg_tables.inc).  Time reversal maps the
 // end/end block onto the start/start block with signs (-1)^(a+b); wave B therefore runs the
 // very same code with the signed scale vector s_p = (-T)^p.
+// The chain is solved in the variables s_p x_p of the current segment (see "Scaled-variable chain" at MtgLane): there
+// the blocks of H(T) are the constant blocks of H(1), and only the carried Schur complement is converted from one
+// segment's scaling to the next.
 //
 // The file is plain C++17 so that tests/host_emu.cpp can run the identical code on the CPU
 // (test infrastructure only; the product path is the HIP build).
@@ -126,9 +129,10 @@ struct MtgCfg {
   static constexpr int LSJ = (kStatic && DLW_ > 0) ? LS_ : 0;
   // Factor store (round 4; shared-G configurations whose steps leave the registers): what a step keeps for the back-substitution
   // is the LDL^T factor of its pivot block (strict lower triangle of L + 1 / d: f (f + 1) / 2 numbers) instead of
-  // G = Dtilde^-1 U (f * f numbers).  The back-substitution then forms x_l = g - Dtilde^-1 (U x_r) with U rebuilt from the
-  // constant table and the segment time (mtg_bwd_backsub_fs): ~2 f^2 more FP64 operations per step and dimension lane, on a
-  // kernel whose time is the workspace round trip -- 14 -> 10 rows per step for N = 12, 10 -> 8 for N = 10, 6 -> 5 for N = 8.
+  // G = Dtilde^-1 U (f * f numbers).  The back-substitution then forms x_l = g - Dtilde^-1 (U x_r) with U read from the
+  // constant table (mtg_bwd_backsub_fs; in the segment's scaling U IS the table): ~2 f^2 more FP64 operations per step and
+  // dimension lane, on a kernel whose time is the workspace round trip -- 14 -> 10 rows per step for N = 12, 10 -> 8 for N = 10,
+  // 6 -> 5 for N = 8.
   static constexpr bool kFS = DLW_ > 0 && ((kStatic && WS_ > 0) || kRolled);
   // (factor-store entries are standard shapes: with fully fixed trajectory ends R_PP is positive definite for every T > 0)
   static_assert(!kFS || (MS_ == (1 << H_) - 1 && ME_ == (1 << H_) - 1), "factor-store kernels: trajectory ends fully fixed");
@@ -287,10 +291,7 @@ template <int DIR> MTG_HD int mtg_vr(int K, int j) { return DIR > 0 ? j + 1 : K 
 // back-substitution works on x^ as well and hands the scaled vertex values s_p x_p, which the coefficient recovery needs anyway
 // (impl/...:276-277 through the scaling identity), to mtg_recover.  Unscaled quantities cross the function boundaries: the two
 // directions exchange Sc, rc (mtg_unscale_carried at the end of the forward phase), xl / xr / d_P are plain derivatives.
-// MTG_SCALED_CHAIN=0: the assembly of rounds 1-5 (every block formed as T^(1-2d) S H1 S).
-#ifndef MTG_SCALED_CHAIN
-#define MTG_SCALED_CHAIN 1
-#endif
+// (Rounds 1-5 formed every block as T^(1-2d) S H1 S: the last commit with that assembly, selectable as MTG_SCALED_CHAIN=0, is 13d7019.)
 
 template <class C>
 struct MtgLane {
@@ -301,7 +302,7 @@ struct MtgLane {
   double rc[C::D][C::H];          // its right-hand side
   double T[C::KCS];               // static mode: this lane's segment times, chain order
   double fx[C::D][C::NC];         // static mode: this lane's fixed values (columns colBegin..colEnd)
-  double cT, cTinv;               // MTG_SCALED_CHAIN: signed time DIR T (and its reciprocal) of the segment whose scaling Sc / rc are in
+  double cT, cTinv;               // signed time DIR T (and its reciprocal) of the segment whose scaling Sc / rc are in
   int flags;
 };
 
@@ -560,7 +561,6 @@ MTG_HD void mtg_step_scales(const MtgParams& P, double T, const MtgLane<C>& ln, 
 // scaling -- the two directions add theirs at the middle vertex (mtg_pack_mid / mtg_solve_mid work on plain quantities).
 template <class C, int DIR>
 MTG_HD void mtg_unscale_carried(const MtgParams& P, MtgLane<C>& ln) {
-#if MTG_SCALED_CHAIN
   constexpr int H = C::H;
   const int deriv = mtg_deriv<C>(P);
   const double T = ln.cT < 0.0 ? -ln.cT : ln.cT, tinv = ln.cTinv < 0.0 ? -ln.cTinv : ln.cTinv;
@@ -581,7 +581,6 @@ MTG_HD void mtg_unscale_carried(const MtgParams& P, MtgLane<C>& ln) {
   }
   ln.cT = 1.0;       // plain quantities from here on
   ln.cTinv = 1.0;
-#endif
 }
 
 // One forward elimination step (chain step j): completes the left vertex, produces
@@ -594,13 +593,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
                               const double (&fix_l)[C::D][C::H], const double (&fix_r)[C::D][C::H],
                               double (&G)[C::H][C::H], double (&g)[C::D][C::H]) {
   constexpr int H = C::H, D = C::D, N = C::N;
-#if MTG_SCALED_CHAIN
   double s[H], pw[2 * H - 1], tinv;
   mtg_step_scales<C, DIR>(P, T, ln, s, pw, tinv, ln.flags);
-#else
-  double s[H], bs[H], tinv;
-  mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, ln.flags);
-#endif
 
   // scaled fixed values
   double val_l[D][H], val_r[D][H];
@@ -659,13 +653,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
     for (int p = 0; p < H; ++p) {
 #pragma unroll
       for (int dm = 0; dm < D; ++dm) {
-#if MTG_SCALED_CHAIN
         rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(pw[p], ln.rc[dm][p], -accl[p][dm]);
         rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : -accr[p][dm];
-#else
-        rv[dm][p] = ((ml >> p) & 1) ? 0.0 : mtg_fma(-bs[p], accl[p][dm], ln.rc[dm][p]);
-        rnext[dm][p] = ((mr >> p) & 1) ? 0.0 : mtg_mul(-bs[p], accr[p][dm]);
-#endif
       }
     }
   }
@@ -682,13 +671,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         A[p][q] = 0.0;
         U[p][q] = 0.0;
         if (!((ml >> p) & 1)) {
-#if MTG_SCALED_CHAIN
           if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(pw[p + q], ln.Sc[p][q], hc[p * N + q]);
           if (!((mr >> q) & 1)) U[p][q] = hc[p * N + H + q];
-#else
-          if (q <= p && !((ml >> q) & 1)) A[p][q] = mtg_fma(mtg_mul(bs[p], s[q]), hc[p * N + q], ln.Sc[p][q]);
-          if (!((mr >> q) & 1)) U[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hc[p * N + H + q]);
-#endif
         }
       }
     }
@@ -718,7 +702,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
       if ((ml >> i) & 1) continue;
 #pragma unroll
       for (int kk = 0; kk < i; ++kk) {
-        const int k = MTG_SCALED_CHAIN ? i - 1 - kk : kk;
+        const int k = i - 1 - kk;
         if ((ml >> k) & 1) continue;
 #pragma unroll
         for (int c = 0; c < H + D; ++c) {
@@ -737,11 +721,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
       for (int q = 0; q < H; ++q) {
         ln.Sc[p][q] = 0.0;
-#if MTG_SCALED_CHAIN
         if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = hrr[(H + p) * N + H + q];
-#else
-        if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
-#endif
       }
     }
 #pragma unroll
@@ -751,7 +731,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
     }
 #pragma unroll
     for (int mm = 0; mm < H; ++mm) {
-      const int m = MTG_SCALED_CHAIN ? H - 1 - mm : mm;     // (scaled chain: the literal row of X -- the first free one -- last)
+      const int m = H - 1 - mm;     // (the literal row of X -- the first free one -- last)
       if ((ml >> m) & 1) continue;
 #pragma unroll
       for (int p = 0; p < H; ++p) {
@@ -818,11 +798,7 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
 #pragma unroll
     for (int q = 0; q < H; ++q) {
       ln.Sc[p][q] = 0.0;
-#if MTG_SCALED_CHAIN
       if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = hrr[(H + p) * N + H + q];
-#else
-      if (q <= p && !((mr >> p) & 1) && !((mr >> q) & 1)) ln.Sc[p][q] = mtg_mul(mtg_mul(bs[p], s[q]), hrr[(H + p) * N + H + q]);
-#endif
     }
   }
 #pragma unroll
@@ -855,10 +831,8 @@ MTG_HD void mtg_fwd_step_core(const MtgParams& P, int ml, int mr, MtgLane<C>& ln
         G[p][q] = (((ml >> p) & 1) || ((ml >> q) & 1) || q > p) ? 0.0 : (q == p ? dinv[p] : A[p][q]);
     }
   }
-#if MTG_SCALED_CHAIN
   ln.cT = DIR > 0 ? T : -T;          // what is carried on is in this segment's scaling
   ln.cTinv = DIR > 0 ? tinv : -tinv;
-#endif
 }
 
 // segment time of chain step j (static mode: preloaded register; otherwise a global load)
@@ -877,7 +851,6 @@ template <class C>
 MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mask, MtgLane<C>& ln) {
   if constexpr (!C::kCT) {
     if (P.rhs == nullptr) return;
-#if MTG_SCALED_CHAIN
     // the carried right-hand side is in the scaling of ln.cT: entry p divided by t s_p, t = |cT|^(1-2d), s_p = cT^p
     double rs[C::H];
     {
@@ -886,7 +859,6 @@ MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mas
 #pragma unroll
       for (int p = 1; p < C::H; ++p) rs[p] = rs[p - 1] * ln.cTinv;
     }
-#endif
     const int off = mtg_offP<C>(P, v);
 #pragma unroll
     for (int dm = 0; dm < C::D; ++dm) {
@@ -894,11 +866,7 @@ MTG_HD void mtg_add_explicit_rhs(const MtgParams& P, long long b, int v, int mas
       for (int p = 0; p < C::H; ++p) {
         if ((mask >> p) & 1) continue;
         const int col = off + (p - mtg_popc(mask & ((1 << p) - 1)));
-#if MTG_SCALED_CHAIN
         ln.rc[dm][p] += P.rhs[b * P.rh_b + (long long)(P.dim0 + dm) * P.rh_d + (long long)col * P.rh_c] * rs[p];
-#else
-        ln.rc[dm][p] += P.rhs[b * P.rh_b + (long long)(P.dim0 + dm) * P.rh_d + (long long)col * P.rh_c];
-#endif
       }
     }
   }
@@ -1207,15 +1175,13 @@ MTG_HD void mtg_bwd_scales(double T, double (&s)[H], double (&si)[H]) {
 }
 
 // Back-substitution of one chain step from the FACTOR of its pivot block (MtgCfg::kFS): F strict lower = L, diagonal = 1 / d,
-// xl = [fixed values | g - (L D L^T)^-1 (U xr)], U = T^(1-2d) S_l H1_lr S_r rebuilt from the table and the segment time.
+// in the segment's scaling: x^_l = g^ - (L D L^T)^-1 (H1_lr x^_r) with x^_r = s x_r, then xl = [fixed values | x^_l / s]; the scaled
+// values of both vertices go on to the coefficient recovery (ye).
 template <class C, int DIR>
 MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
                                const double (&F)[C::H][C::H], const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H],
                                double (&xl)[C::D][C::H], MtgScaledEnds<C>& ye) {
   constexpr int H = C::H, D = C::D, N = C::N;
-#if MTG_SCALED_CHAIN
-  // scaled-variable chain: F factors the pivot block in the segment's scaling, U^ = H1_lr is the table itself;
-  // x^_l = g^ - (L D L^T)^-1 (H1_lr x^_r) with x^_r = s x_r, then x_l = x^_l / s
   double s[H], si[H];
   mtg_bwd_scales<H, DIR>(T, s, si);
   const double* hc = mtg_h1<C>(P);
@@ -1226,19 +1192,6 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
 #pragma unroll
     for (int dm = 0; dm < D; ++dm) y[dm][q] = mtg_pin(mtg_mul(s[q], mtg_pin(xr[dm][q])));
   }
-#else
-  (void)ye;
-  double s[H], bs[H], tinv;
-  int dummy = 0;
-  mtg_scales<H, DIR>(T, mtg_deriv<C>(P), s, bs, tinv, dummy);
-  const double* hc = mtg_h1<C>(P);
-  double y[D][H], w[H][D], dinv[H];
-#pragma unroll
-  for (int q = 0; q < H; ++q) {
-#pragma unroll
-    for (int dm = 0; dm < D; ++dm) y[dm][q] = mtg_pin(mtg_mul(s[q], mtg_pin(xr[dm][q])));
-  }
-#endif
 #pragma unroll
   for (int p = 0; p < H; ++p) {
     dinv[p] = F[p][p];
@@ -1256,13 +1209,6 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
       for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_fma(c, y[dm][q], w[p][dm]);
     }
   }
-#if !MTG_SCALED_CHAIN
-#pragma unroll
-  for (int p = 0; p < H; ++p) {
-#pragma unroll
-    for (int dm = 0; dm < D; ++dm) w[p][dm] = mtg_pin(mtg_mul(bs[p], w[p][dm]));
-  }
-#endif
   // (y above is formed from a pinned COPY of xr: the same product s x_r is formed by mtg_recover for the segment's coefficients
   // (dl), where the A^-1 row of coefficient h has entries +-1, fma(1, dl, acc) folds to an addition and the compiler contracts
   // the product into it or not depending on the product's other uses.  Sharing the product with this function changed that
@@ -1300,7 +1246,6 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
       for (int dm = 0; dm < D; ++dm) w[i][dm] = mtg_fma(-F[k][i], w[k][dm], w[i][dm]);
     }
   }
-#if MTG_SCALED_CHAIN
 #pragma unroll
   for (int dm = 0; dm < D; ++dm) {
 #pragma unroll
@@ -1309,27 +1254,18 @@ MTG_HD void mtg_bwd_backsub_fs(const MtgParams& P, int ml, int mr, double T, con
       xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(mtg_mul(ye.l[dm][p], si[p]));
     }
   }
-#else
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-#pragma unroll
-    for (int p = 0; p < H; ++p) xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(g[dm][p]) - w[p][dm];
-  }
-#endif
 }
 
 // One back-substitution step + coefficient recovery of the segment it completes.
 // xr: solution (all slots) at the right vertex on entry, at the left vertex on exit.
-// Back-substitution of one chain step: xl = [fixed values | g - G xr] (all slots of the left vertex).  fix_l: the
-// (unscaled) fixed values of the left vertex, already in registers.  G and g are dead afterwards.
+// Back-substitution of one chain step in the segment's scaling (s = (DIR T)^p): x^_l = g^ - G^ (s xr) over the free slots,
+// xl = [fixed values | x^_l / s] (all slots of the left vertex).  fix_l: the (unscaled) fixed values of the left vertex, already in
+// registers.  G and g are dead afterwards; ye: s x of both vertices for the coefficient recovery.
 template <class C, int DIR>
-MTG_HD void mtg_bwd_backsub(const MtgParams& P, int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
+MTG_HD void mtg_bwd_backsub(int ml, int mr, double T, const double (&fix_l)[C::D][C::H],
                             const double (&G)[C::H][C::H], const double (&g)[C::D][C::H], const double (&xr)[C::D][C::H],
                             double (&xl)[C::D][C::H], MtgScaledEnds<C>& ye) {
   constexpr int H = C::H, D = C::D;
-  (void)P;
-#if MTG_SCALED_CHAIN
-  // scaled-variable chain: G, g relate x^ = s x of the two vertices
   double s[H], si[H];
   mtg_bwd_scales<H, DIR>(T, s, si);
 #pragma unroll
@@ -1358,24 +1294,6 @@ MTG_HD void mtg_bwd_backsub(const MtgParams& P, int ml, int mr, double T, const 
       xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : mtg_pin(mtg_mul(ye.l[dm][p], si[p]));
     }
   }
-#else
-  (void)T; (void)ye;
-#pragma unroll
-  for (int dm = 0; dm < D; ++dm) {
-#pragma unroll
-    for (int p = 0; p < H; ++p) xl[dm][p] = ((ml >> p) & 1) ? fix_l[dm][p] : g[dm][p];
-  }
-#pragma unroll
-  for (int q = 0; q < H; ++q) {
-    if ((mr >> q) & 1) continue;
-#pragma unroll
-    for (int p = 0; p < H; ++p) {
-      if ((ml >> p) & 1) continue;
-#pragma unroll
-      for (int dm = 0; dm < D; ++dm) xl[dm][p] = mtg_fma(-G[p][q], xr[dm][q], xl[dm][p]);
-    }
-  }
-#endif
 }
 
 // Second half of a backward step: optional d_P output, coefficient recovery of the segment the step completes
@@ -1392,7 +1310,7 @@ MTG_HD double mtg_bwd_finish_impl(const MtgParams& P, long long b, int j, int ml
   const int seg = mtg_seg<DIR>(K, j), vl = mtg_vl<DIR>(K, j);
   mtg_store_free<C, OUT>(P, b, vl, ml, xl);
   double cost;
-  if constexpr (PRE && MTG_SCALED_CHAIN != 0) {
+  if constexpr (PRE) {
     if (DIR > 0) cost = mtg_recover<C, OUT, 1>(P, b, seg, T, xl, xr, io, ye->l, ye->r);
     else cost = mtg_recover<C, OUT, -1>(P, b, seg, T, xr, xl, io, ye->r, ye->l);
   } else {
@@ -1426,7 +1344,7 @@ MTG_HD double mtg_bwd_step(const MtgParams& P, long long b, int j, int ml, int m
   MtgScaledEnds<C> ye;
   const double T = mtg_step_time<C, DIR>(P, b, j, ln);
   mtg_load_vals<C, DIR>(P, b, mtg_vl<DIR>(mtg_nseg<C>(P), j), ml, ln, fix_l);
-  mtg_bwd_backsub<C, DIR>(P, ml, mr, T, fix_l, G, g, xr, xl, ye);
+  mtg_bwd_backsub<C, DIR>(ml, mr, T, fix_l, G, g, xr, xl, ye);
   return mtg_bwd_finish<C, DIR, OUT>(P, b, j, ml, T, xl, xr, io, ye);
 }
 
@@ -1778,9 +1696,9 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
           else if constexpr (C::kRegShared) mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl, ye);
           else mtg_bwd_backsub_fs<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl, ye);
         } else {
-          if (j < C::WSJ) mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, Gw, gw, xr, xl, ye);
-          else if constexpr (C::kRegShared) mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl, ye);
-          else mtg_bwd_backsub<C, DIR>(P, ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl, ye);
+          if (j < C::WSJ) mtg_bwd_backsub<C, DIR>(ml, mr, Tj, fix_l, Gw, gw, xr, xl, ye);
+          else if constexpr (C::kRegShared) mtg_bwd_backsub<C, DIR>(ml, mr, Tj, fix_l, Gw, ln.g[jr], xr, xl, ye);
+          else mtg_bwd_backsub<C, DIR>(ml, mr, Tj, fix_l, ln.G[jr], ln.g[jr], xr, xl, ye);
         }
         // the next step's data is requested right after this step's back-substitution and BEFORE its coefficient
         // stores (loads and stores retire through one in-order counter; the ds_bpermute round trip overlaps the recovery)
@@ -1815,8 +1733,8 @@ MTG_HD void mtg_lane_finish(const MtgParams& P, long long b, MtgLane<C>& ln, con
         double xl[D][H];
         const double T_use = T_cur;
         MtgScaledEnds<C> ye;
-        if (j == 0) mtg_bwd_backsub<C, DIR>(P, M0, C::MI, T_use, fl, G, g, xr, xl, ye);
-        else mtg_bwd_backsub<C, DIR>(P, C::MI, C::MI, T_use, fl, G, g, xr, xl, ye);
+        if (j == 0) mtg_bwd_backsub<C, DIR>(M0, C::MI, T_use, fl, G, g, xr, xl, ye);
+        else mtg_bwd_backsub<C, DIR>(C::MI, C::MI, T_use, fl, G, g, xr, xl, ye);
         if (j > 0) request(j - 1);
         cost += mtg_bwd_finish<C, DIR, OUT>(P, b, j, j == 0 ? M0 : C::MI, T_use, xl, xr, io, ye);
       }
