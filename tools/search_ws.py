@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mav_trajectory_generation_amd", "csrc")
 SHAPES = {4: (15, 1, 15, 3), 5: (31, 1, 31, 4), 6: (63, 1, 63, 5)}      # (start mask, interior mask, end mask, derivative)
 LDS_STEPS = {4: 8, 5: 6, 6: 4}                                          # steps that fit the LDS next to the output slabs
-REG_STEPS = {4: 9, 5: 6, 6: 2}                                          # where the search starts (steps the registers hold)
+REG_STEPS = {4: 12, 5: 9, 6: 5}                                          # where the search starts (steps the registers hold)
 
 
 def resources(H, K, WS, LS, RS=0, full=False):
@@ -79,5 +79,6 @@ if __name__ == "__main__":
     hs = [int(x) for x in sys.argv[3:]] or [4, 5, 6]
     jobs = [(H, K) for H in hs for K in range(k0, k1 + 1)]
     with cf.ThreadPoolExecutor(max(1, (os.cpu_count() or 2) - 1)) as ex:
-        for line in ex.map(lambda a: best(*a), jobs):
+        rs = int(os.environ.get('SEARCH_RS', '1'))      # SEARCH_RS=0: register steps unshared (MTG_DLW lines)
+        for line in ex.map(lambda a: best(*a, RS=rs), jobs):
             print(line, flush=True)
