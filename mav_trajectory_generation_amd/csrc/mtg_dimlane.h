@@ -360,14 +360,14 @@ __device__ __forceinline__ void mtg_dl_any_unit(const MtgDlAnyItem& it, int tile
   X(0, 4, 4, 15, 1, 15, 3, 0, 0, 0)       \
   X(1, 4, 8, 15, 1, 15, 3, 0, 0, 0)       \
   X(2, 4, 16, 15, 1, 15, 3, 0, 0, 0)      \
-  X(3, 4, 32, 15, 1, 15, 3, 0, 0, 1)      \
+  X(3, 4, 32, 15, 1, 15, 3, 4, 4, 0)      \
   X(4, 5, 4, 31, 1, 31, 4, 0, 0, 0)       \
   X(5, 5, 8, 31, 1, 31, 4, 0, 0, 0)       \
   X(6, 5, 16, 31, 1, 31, 4, 0, 0, 0)      \
   X(7, 5, 32, 31, 1, 31, 4, 4, 4, 1)      \
   X(8, 6, 4, 63, 1, 63, 5, 0, 0, 0)       \
   X(9, 6, 8, 63, 1, 63, 5, 0, 0, 0)       \
-  X(10, 6, 16, 63, 1, 63, 5, 1, 1, 1)     \
+  X(10, 6, 16, 63, 1, 63, 5, 3, 3, 0)     \
   X(11, 6, 32, 63, 1, 63, 5, 11, 4, 1)
 
 // The host hands every persistent workgroup its own list of units (wg_begin[w] .. wg_begin[w + 1] of `units`), longest chains

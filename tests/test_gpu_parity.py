@@ -365,14 +365,14 @@ def test_merged_mixed_request(ctx):
     solver.sync()
     def same(b, c, j, c0, j0):
         n_, k_ = b["n_coeffs"], b["times"].shape[1]
-        if (n_, k_) in ((10, 32), (12, 16), (12, 32)):
+        if (n_, k_) in ((8, 32), (10, 32), (12, 16), (12, 32)):
             # the per-bucket launches of these shapes are the factor-store dimension-in-lane kernels (MtgCfg::kFS, round 4: the
             # back-substitution works from the LDL^T factor of a step's pivot block), the merged launch WITH cost output runs the
             # G-form bodies: the same solution up to the association of f^2 products per chain step
             den = c0.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
             # (N = 12: on this batch either form is up to 1.0e-7 from the 50-digit solution -- K = 32, segment-time ratio 17.8)
-            assert float(((c - c0).abs() / den).max()) < (1e-11 if n_ == 10 else 1e-7)
-            assert torch.allclose(j, j0, rtol=1e-10 if n_ == 10 else 5e-8)
+            assert float(((c - c0).abs() / den).max()) < (1e-11 if n_ <= 10 else 1e-7)
+            assert torch.allclose(j, j0, rtol=1e-10 if n_ <= 10 else 5e-8)
         else:
             assert torch.equal(c, c0) and torch.allclose(j, j0, rtol=1e-12)
 
