@@ -509,11 +509,6 @@ MTG_HD void mtg_scales(double T, int deriv, double (&s)[H], double (&bs)[H], dou
   for (int p = 0; p < H; ++p) bs[p] = mtg_mul(base, s[p]);
 }
 
-// Scaled-variable chain: scale vector of the step, s[p] = (DIR T)^p, and the factors that bring the carried block from the previous
-// step's scaling (ln.cT) into this one:  pw[m] = kappa sigma^m,  sigma = tau_prev / tau,  kappa = (T_prev / T)^(1 - 2 d)
-// (entry (p, q) of the Schur complement takes pw[p + q], entry p of its right-hand side pw[p]).  With rho = 1 / sigma the factor
-// is rho^(2d - 1 - m): compile-time derivative => the non-negative exponents come from one power table of rho, the negative ones
-// from one of sigma (d = h - 1: 2h - 2 powers of rho and sigma itself).
 // pw[m] = rho^(2 DV - 1 - m), m = 0 .. 2H - 2, from the power tables of rho and sigma = 1 / rho
 template <int H, int DV>
 MTG_HD void mtg_pw_table(double rho, double sigma, double (&pw)[2 * H - 1]) {
@@ -540,6 +535,11 @@ MTG_HD void mtg_pw_dispatch(int deriv, double rho, double sigma, double (&pw)[2 
   else mtg_pw_table<H, DV>(rho, sigma, pw);     // (not reached: derivative_to_optimize < h)
 }
 
+// Scaled-variable chain: scale vector of the step, s[p] = (DIR T)^p, and the factors that bring the carried block from the previous
+// step's scaling (ln.cT) into this one:  pw[m] = kappa sigma^m,  sigma = tau_prev / tau,  kappa = (T_prev / T)^(1 - 2 d)
+// (entry (p, q) of the Schur complement takes pw[p + q], entry p of its right-hand side pw[p]).  With rho = 1 / sigma the factor
+// is rho^(2d - 1 - m): compile-time derivative => the non-negative exponents come from one power table of rho, the negative ones
+// from one of sigma (d = h - 1: 2h - 2 powers of rho and sigma itself).
 template <class C, int DIR>
 MTG_HD void mtg_step_scales(const MtgParams& P, double T, const MtgLane<C>& ln, double (&s)[C::H], double (&pw)[2 * C::H - 1],
                             double& tinv, int& flags) {
