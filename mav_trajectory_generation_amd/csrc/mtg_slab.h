@@ -106,10 +106,12 @@ struct MtgSlabOut {
   // generic mapping (chunk o of a range -> row o / nch: a multiply-high and a slot selection per chunk).
   static constexpr int row_width() { return kPhase ? ((S + 63) / 64) * 4 : MAXCH; }
   static constexpr bool row_ok(int w) { return w >= 4 && w <= 32 && 64 - (64 / w) * w <= 8; }
-  // (rows that are not a power of two wide only up to K = 16: the register-tight K = 32 hybrids of N = 8 / 12 spill to scratch
-  // with them -- 13 -> 27 us and 38 -> 54 us per 2500-trajectory bucket -- and keep the generic mapping)
+  // (rows that are not a power of two wide only up to K = 16 where the pieces are aligned: the register-tight K > 16 bodies of
+  // N = 8 / 12 spill to scratch with them -- round 6 again: N = 12 / K = 32 418 -> 549 us, N = 8 / K = 32 176 -> 262 at 100k -- and keep the
+  // generic mapping.  Phase-mapped pieces (N = 12 with an odd K) take the rows at every K: the generic phase mapping divides per lane
+  // and per chunk -- N = 12 / K = 17 253 -> 203 us, K = 25 392 -> 333, K = 31 478 -> 403, fewer registers, same bits.)
   static constexpr bool pow2(int w) { return (w & (w - 1)) == 0; }
-  static constexpr int CHP = (row_ok(row_width()) && (pow2(row_width()) || K <= 16)) ? row_width() : 0;
+  static constexpr int CHP = (row_ok(row_width()) && (pow2(row_width()) || K <= 16 || kPhase)) ? row_width() : 0;
   static constexpr bool kPhaseChp = kPhase && CHP != 0;   // phase mapping with rows: the piece's misaligned head / tail (up to 48
                                                           // bytes each) go out in a pass of their own, ranges stay <= CHP chunks
   // LDS rows.  CHP mapping: a RING of two segment slots per trajectory (slot = segment & 1): a range is read out of the
