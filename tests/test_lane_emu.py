@@ -179,3 +179,28 @@ def test_shared_workspace_factor_store_emulation(host_emu, n, k, mi):
     assert e_fs < (1e-7 if n == 12 else 1e-11)
     assert e_fs < 20 * e_g + 1e-13      # not materially further from the truth than the G form
     assert helpers.check_path(masks, times, fixed, co) < 1e-6
+
+
+@pytest.mark.parametrize("n,k", [(8, 8), (10, 8), (10, 16), (12, 8), (12, 16)])
+def test_scaled_variable_chain_generic_and_specialised_kernels_agree(host_emu, n, k):
+    """Round 6, the scaled-variable chain (mtg_lane.h): the sweep carries the Schur complement in the current segment's scaling and
+    converts it with the factors rho^(2d - 1 - p - q), rho = T / T'.  The generic kernels (run-time derivative) and the specialised ones
+    (static / rolled) must form those factors by the SAME power table -- a one-ulp difference in them is round-off x cond(R_PP) in the
+    solution (2e-10 on the worst of 125k config-2 trajectories when the generic kernel multiplied kappa sigma^m instead) -- and both
+    stay at round-off x conditioning of the 50-digit solution on uneven segment times."""
+    from oracle import oracle_mp as omp
+    d = n // 2 - 1
+    masks, times, d_fixed = helpers.reference_batch(16, k, n, 3, 4242 + n + k)
+    rng = np.random.default_rng(n * 100 + k)
+    times = times * np.exp(rng.uniform(np.log(0.3), np.log(3.0), times.shape))      # neighbouring segments up to 10x apart
+    rc0, c_gen, fr0, j0, st0 = helpers.emu_run(host_emu, n, 3, k, d, masks, times, d_fixed, 0)
+    assert rc0 == 0 and st0 == 0
+    for mode in (1, 3):
+        rc, c_sp, fr, j, st = helpers.emu_run(host_emu, n, 3, k, d, masks, times, d_fixed, mode)
+        if rc == -2:
+            continue
+        assert rc == 0 and st == 0
+        assert helpers.poly_relerr(c_sp, c_gen) < (1e-12 if n <= 10 else 1e-10), (mode, helpers.poly_relerr(c_sp, c_gen))
+        assert np.allclose(j, j0, rtol=1e-10)
+    c_mp = np.asarray(omp.solve_batch(n, d, masks, times, d_fixed)[0], dtype=np.float64)
+    assert helpers.poly_relerr(c_gen, c_mp) < {8: 1e-12, 10: 1e-10, 12: 1e-6}[n]
