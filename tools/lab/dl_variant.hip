@@ -34,6 +34,11 @@ template <class CC, int DL_, int NP_>
 __global__ __launch_bounds__(NP_ * 2 * kWave, LT_OCC) void lab_dl_kernel(const double* __restrict__ times, const double* __restrict__ dfix,
                                                                        double* __restrict__ coeffs, int* status, int* traj_status, int B,
                                                                        int ntiles, int nwg, int aos, double* ws) {
+#ifdef LT_MASK21
+  // power experiment: only the dimension-0 lanes of every wave run (the same instruction stream with a third of the lanes active;
+  // the outputs are garbage) -- how much of a tile's time is the FP64 lanes' power?
+  if ((threadIdx.x & 63) >= 21) return;
+#endif
   mtg_solve_dl_body<CC, DL_, NP_, 0, 18, false>(times, dfix, coeffs, status, traj_status, B, ntiles, nwg, ws, aos, nullptr, nullptr);
 }
 
